@@ -1,0 +1,291 @@
+// ============================================================================
+// oracle/flo_common.h  --  TEST INFRASTRUCTURE ONLY (CPU oracle).
+// Point types, transforms, VoxelGrid and the iVox map restated from the
+// reference.  See flo_api.h for the usage rule (tests / smoke / cpu_baseline).
+// ============================================================================
+#pragma once
+#include "flo_linalg.h"
+#include "flo_kdtree.h"
+#include <vector>
+#include <list>
+#include <unordered_map>
+#include <cstdint>
+#include <cmath>
+#include <algorithm>
+
+namespace flo {
+
+struct P4 { float x, y, z, i; };  // pcl::PointXYZI payload (padding dropped)
+using Cloud = std::vector<P4>;
+
+static inline Cloud make_cloud(const float* p, size_t n, int stride) {
+    Cloud c(n);
+    for (size_t k = 0; k < n; ++k) {
+        c[k].x = p[k * stride + 0];
+        c[k].y = p[k * stride + 1];
+        c[k].z = p[k * stride + 2];
+        c[k].i = stride >= 4 ? p[k * stride + 3] : 0.0f;
+    }
+    return c;
+}
+
+// pcl::transformPoint(pt, Eigen::Transform<double,3,Affine>) as called at
+// loam_point_to_plane_ivox.h:91,266  loam_full_kdtree.h:220,286  (PCL >= 1.9
+// Transformer<double>::se3: row evaluated left-to-right in double, cast to float).
+static inline P4 transform_point_d(const P4& p, const double* T /*4x4 col-major*/) {
+    P4 r = p;
+    const double x = p.x, y = p.y, z = p.z;
+    r.x = float(((T[0] * x + T[4] * y) + T[8] * z) + T[12]);
+    r.y = float(((T[1] * x + T[5] * y) + T[9] * z) + T[13]);
+    r.z = float(((T[2] * x + T[6] * y) + T[10] * z) + T[14]);
+    return r;
+}
+
+// TransformPoint(PCLPointXYZI, Mat3d, Vec3d)   pointcloud_utility.h:52-61 and
+// TransformPointCloud(cloud, Mat4d)            pointcloud_utility.h:141-195:
+// R,t cast to float FIRST, then pure float  R_f * p + t_f.  Eigen evaluates the
+// 3x3*3x1 float product coefficient-wise through the un-vectorised redux
+// unroller: e0 + (e1 + e2)  (Eigen/src/Core/Redux.h redux_novec_unroller).
+struct RtF { float R[9]; float t[3]; };
+static inline RtF make_rtf(const double* T) {
+    RtF o;
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) o.R[i + j * 3] = float(T[i + j * 4]);
+    for (int i = 0; i < 3; ++i) o.t[i] = float(T[12 + i]);
+    return o;
+}
+static inline P4 transform_point_f(const P4& p, const RtF& rt) {
+    P4 r = p;
+    r.x = (rt.R[0] * p.x + (rt.R[3] * p.y + rt.R[6] * p.z)) + rt.t[0];
+    r.y = (rt.R[1] * p.x + (rt.R[4] * p.y + rt.R[7] * p.z)) + rt.t[1];
+    r.z = (rt.R[2] * p.x + (rt.R[5] * p.y + rt.R[8] * p.z)) + rt.t[2];
+    return r;
+}
+static inline Cloud transform_cloud_f(const Cloud& c, const double* T) {
+    const RtF rt = make_rtf(T);
+    Cloud o(c.size());
+    for (size_t i = 0; i < c.size(); ++i) o[i] = transform_point_f(c[i], rt);
+    return o;
+}
+
+// DistanceSquared (pointcloud_utility.h:14-17): Vector3f d = a - b; d.squaredNorm()
+// -> float, Eigen redux order x*x + (y*y + z*z).
+static inline float dist2_ivox(const P4& a, const P4& b) {
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return dx * dx + (dy * dy + dz * dz);
+}
+
+// ---------------------------------------------------------------------------
+// pcl::VoxelGrid<PointXYZI>::filter as used by VoxelGridCloud
+// (pointcloud_utility.h:216-271; PCL 1.10 voxel_grid.hpp applyFilter,
+// downsample_all_data_=true, min_points_per_voxel_=0).  PCL is not vendored.
+// ---------------------------------------------------------------------------
+static inline Cloud voxel_grid(const Cloud& in, float leaf) {
+    if (in.empty()) return Cloud();
+    const float inv = 1.0f / leaf;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const P4& p : in) {
+        if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+        mn[0] = std::min(mn[0], p.x); mx[0] = std::max(mx[0], p.x);
+        mn[1] = std::min(mn[1], p.y); mx[1] = std::max(mx[1], p.y);
+        mn[2] = std::min(mn[2], p.z); mx[2] = std::max(mx[2], p.z);
+    }
+    const int64_t dx = int64_t((mx[0] - mn[0]) * inv) + 1;
+    const int64_t dy = int64_t((mx[1] - mn[1]) * inv) + 1;
+    const int64_t dz = int64_t((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > int64_t(std::numeric_limits<int32_t>::max())) return in;  // PCL warns + copies input
+    int min_b[3], max_b[3], div_b[3];
+    for (int a = 0; a < 3; ++a) {
+        min_b[a] = int(std::floor(mn[a] * inv));
+        max_b[a] = int(std::floor(mx[a] * inv));
+        div_b[a] = max_b[a] - min_b[a] + 1;
+    }
+    const int mul[3] = {1, div_b[0], div_b[0] * div_b[1]};
+    struct IdxPt { unsigned idx; unsigned pt; bool operator<(const IdxPt& o) const { return idx < o.idx; } };
+    std::vector<IdxPt> iv;
+    iv.reserve(in.size());
+    for (size_t k = 0; k < in.size(); ++k) {
+        const P4& p = in[k];
+        if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+        const int i0 = int(std::floor(p.x * inv) - float(min_b[0]));
+        const int i1 = int(std::floor(p.y * inv) - float(min_b[1]));
+        const int i2 = int(std::floor(p.z * inv) - float(min_b[2]));
+        iv.push_back(IdxPt{unsigned(i0 * mul[0] + i1 * mul[1] + i2 * mul[2]), unsigned(k)});
+    }
+    std::sort(iv.begin(), iv.end());
+    Cloud out;
+    size_t a = 0;
+    while (a < iv.size()) {
+        size_t b = a + 1;
+        while (b < iv.size() && iv[b].idx == iv[a].idx) ++b;
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;  // CentroidPoint: float accumulators
+        for (size_t k = a; k < b; ++k) {
+            const P4& p = in[iv[k].pt];
+            sx += p.x; sy += p.y; sz += p.z; si += p.i;
+        }
+        const float n = float(b - a);
+        out.push_back(P4{sx / n, sy / n, sz / n, si / n});
+        a = b;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// iVox  (include/ivox_map/ivox_map.h:16-74, src/ivox_map/ivox_map.cpp,
+//        src/ivox_map/voxel_grid_node.cpp, include/ivox_map/voxel_grid_node.h)
+// ---------------------------------------------------------------------------
+struct Key3 {
+    int x, y, z;
+    bool operator==(const Key3& o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct SpatialHash {  // include/common/hash_function.h:10-14 (int32 wrap-around made explicit)
+    size_t operator()(const Key3& v) const {
+        const int32_t a = int32_t(uint32_t(v.x) * 73856093u);
+        const int32_t b = int32_t(uint32_t(v.y) * 471943u);
+        const int32_t c = int32_t(uint32_t(v.z) * 83492791u);
+        return size_t(int64_t(a ^ b ^ c)) % 10000000;
+    }
+};
+
+struct VoxelNode {  // VoxelGridNode
+    std::vector<P4> points_;
+    std::vector<int> gids_;  // oracle-only: global insertion id of each point
+};
+
+struct DistPoint {  // voxel_grid_node.h:17-31  (operator< on dist only)
+    double dist;
+    VoxelNode* node;
+    int idx;
+    bool operator<(const DistPoint& r) const { return dist < r.dist; }
+};
+
+struct Near { P4 pt; int gid; };  // one element of nearest_points_[i] (+ id for parity checks)
+
+struct KnnCounters { uint64_t probes = 0, hits = 0, cand = 0, ties = 0; };
+
+class IVoxMap {
+public:
+    using List = std::list<std::pair<Key3, VoxelNode>>;
+    float resolution_ = 0.5f, inv_resolution_ = 2.0f;
+    size_t capacity_ = 1000000;
+    std::vector<Key3> nearby_;
+    std::unordered_map<Key3, List::iterator, SpatialHash> grids_map_;
+    List grids_cache_;
+    int next_gid_ = 0;
+
+    explicit IVoxMap(float resolution = 0.5f, int nearby = 18, size_t capacity = 1000000) {
+        resolution_ = resolution;
+        inv_resolution_ = 1.0f / resolution_;
+        capacity_ = capacity;
+        // GenerateNearbyGrids  ivox_map.cpp:43-66
+        nearby_ = {{0, 0, 0}, {-1, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, -1}, {0, 0, 1}};
+        if (nearby >= 18) {
+            const Key3 more[] = {{1, 1, 0}, {-1, 1, 0}, {1, -1, 0}, {-1, -1, 0}, {1, 0, 1}, {-1, 0, 1},
+                                 {1, 0, -1}, {-1, 0, -1}, {0, 1, 1}, {0, -1, 1}, {0, 1, -1}, {0, -1, -1}};
+            nearby_.insert(nearby_.end(), more, more + 12);
+        }
+        if (nearby >= 26) {
+            const Key3 more[] = {{1, 1, 1}, {-1, 1, 1}, {1, -1, 1}, {1, 1, -1}, {-1, -1, 1}, {-1, 1, -1},
+                                 {1, -1, -1}, {-1, -1, -1}};
+            nearby_.insert(nearby_.end(), more, more + 8);
+        }
+        if (nearby == 0) nearby_.resize(1);
+    }
+
+    Key3 Pos2Grid(const P4& p) const {  // ivox_map.cpp:145-147  (float mul, round half away, int)
+        return Key3{int(std::round(p.x * inv_resolution_)), int(std::round(p.y * inv_resolution_)),
+                    int(std::round(p.z * inv_resolution_))};
+    }
+
+    void AddPoints(const Cloud& pts) {  // ivox_map.cpp:122-143
+        for (const P4& pt : pts) {
+            const Key3 key = Pos2Grid(pt);
+            auto iter = grids_map_.find(key);
+            if (iter == grids_map_.end()) {
+                grids_cache_.push_front({key, VoxelNode()});
+                grids_map_.insert({key, grids_cache_.begin()});
+                grids_cache_.front().second.points_.push_back(pt);
+                grids_cache_.front().second.gids_.push_back(next_gid_++);
+                if (grids_map_.size() >= capacity_) {
+                    grids_map_.erase(grids_cache_.back().first);
+                    grids_cache_.pop_back();
+                }
+            } else {
+                iter->second->second.points_.push_back(pt);
+                iter->second->second.gids_.push_back(next_gid_++);
+                grids_cache_.splice(grids_cache_.begin(), grids_cache_, iter->second);
+                grids_map_[key] = grids_cache_.begin();
+            }
+        }
+    }
+
+    // VoxelGridNode::KNNPointByCondition  voxel_grid_node.cpp:23-42
+    static void KnnInVoxel(VoxelNode& node, std::vector<DistPoint>& dist_points, const P4& point, size_t K,
+                           float max_range) {
+        const size_t old_size = dist_points.size();
+        for (size_t k = 0; k < node.points_.size(); ++k) {
+            const double d = dist2_ivox(node.points_[k], point);
+            if (d < max_range * max_range) dist_points.push_back(DistPoint{d, &node, int(k)});
+        }
+        if (old_size + K >= dist_points.size()) {
+        } else {
+            std::nth_element(dist_points.begin() + int(old_size), dist_points.begin() + int(old_size) + K - 1,
+                             dist_points.end());
+            dist_points.resize(old_size + K);
+        }
+    }
+
+    // IVoxMap::GetClosestPoint  ivox_map.cpp:6-37.  NOTE the reference returns false
+    // BEFORE clearing closest_pt when no candidate exists: the caller's vector keeps
+    // its previous content (quirk reproduced).
+    bool GetClosestPoint(const P4& pt, std::vector<Near>& closest_pt, KnnCounters* cnt, size_t max_num = 5,
+                         float max_range = 5.0f) {
+        std::vector<DistPoint> candidates;
+        candidates.reserve(max_num * nearby_.size());
+        const Key3 key = Pos2Grid(pt);
+        std::vector<double> all_d;  // oracle-only: tie detection
+        for (const Key3& d : nearby_) {
+            const Key3 dkey{key.x + d.x, key.y + d.y, key.z + d.z};
+            auto iter = grids_map_.find(dkey);
+            if (cnt) cnt->probes++;
+            if (iter != grids_map_.end()) {
+                VoxelNode& node = iter->second->second;
+                if (cnt) {
+                    cnt->hits++;
+                    cnt->cand += node.points_.size();
+                    for (const P4& q : node.points_) {
+                        const double dd = dist2_ivox(q, pt);
+                        if (dd < max_range * max_range) all_d.push_back(dd);
+                    }
+                }
+                KnnInVoxel(node, candidates, pt, max_num, max_range);
+            }
+        }
+        if (candidates.empty()) return false;
+        if (cnt && all_d.size() >= 2) {
+            // exact tie of the nearest two, or across the K/K+1 boundary: the reference's
+            // result is then defined only by libstdc++'s introselect permutation.
+            std::sort(all_d.begin(), all_d.end());
+            bool tie = (all_d[0] == all_d[1]);
+            if (all_d.size() > max_num && all_d[max_num - 1] == all_d[max_num]) tie = true;
+            if (tie) cnt->ties++;
+        }
+        if (candidates.size() <= max_num) {
+        } else {
+            std::nth_element(candidates.begin(), candidates.begin() + max_num - 1, candidates.end());
+            candidates.resize(max_num);
+        }
+        std::nth_element(candidates.begin(), candidates.begin(), candidates.end());
+        closest_pt.clear();
+        for (auto& it : candidates) closest_pt.push_back(Near{it.node->points_[it.idx], it.node->gids_[it.idx]});
+        return closest_pt.empty() == false;
+    }
+
+    size_t NumPoints() const {
+        size_t n = 0;
+        for (auto& kv : grids_cache_) n += kv.second.points_.size();
+        return n;
+    }
+};
+
+}  // namespace flo
