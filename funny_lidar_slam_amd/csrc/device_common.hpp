@@ -1,0 +1,92 @@
+// device_common.hpp -- device-side data layout shared by all kernels (gfx950).
+//
+// HBM layout (DESIGN.md "Data layout"):
+//   * source scan        : SoA  sx[n], sy[n], sz[n]  (float)  -> lane i reads element i: coalesced
+//   * voxel / cell table : open-addressing hash, 16 B entries {u64 packed key, u32 begin, u32 count}
+//                          one dwordx4 load per probe; load factor <= 0.5
+//   * map points         : float4 {x, y, z, id-as-int-bits}, bucketed by voxel (CSR order), one
+//                          dwordx4 load per candidate (gather, so AoS-of-16B beats SoA here)
+//   * Gauss-Newton state : one GnState block (pose, stop flags, per-iteration log), device resident
+//                          for the whole Match; the host reads it back once at the end
+//   * per-wave partials  : 32 doubles per wave (21 upper-H + 6 g + res + count + 3 spare)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fls {
+
+constexpr int kMaxIter = 64;
+constexpr int kPartialStride = 32;  // doubles per wave partial row
+constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr int kKeyLimit = (1 << 20) - 2;  // |voxel key| bound per axis (21-bit packing)
+
+struct HashEntry {
+    unsigned long long key;
+    unsigned begin;
+    unsigned count;
+};
+static_assert(sizeof(HashEntry) == 16, "one dwordx4 per probe");
+
+struct DevGrid {
+    const HashEntry* table;
+    const float4* pts;  // xyz + id bits
+    unsigned mask;      // table size - 1 (power of two)
+    unsigned n_pts;
+};
+
+struct GnState {
+    double T[16];  // current pose, column-major 4x4 (world <- body)
+    double last_rot, last_pos;
+    double sum_res, sum_res2;
+    double last_dx[6];
+    double H[36], g[6];  // last assembled system (introspection)
+    int iter;            // iterations executed so far
+    int done;            // 1: stop rule hit / failed -> later launches exit at once
+    int converged;       // ICP: has_converge_;  NDT: 0 if min_effective check failed
+    int n_valid, n_valid2;
+    int pad;
+    double log_T[kMaxIter][16];
+    double log_res[kMaxIter];
+    int log_nv[kMaxIter];
+};
+
+struct TrafficCounters {
+    unsigned long long probes, hits, cand;
+};
+
+__host__ __device__ __forceinline__ unsigned long long pack_key(int x, int y, int z) {
+    return ((unsigned long long)((unsigned)x & 0x1FFFFFu) << 42) | ((unsigned long long)((unsigned)y & 0x1FFFFFu) << 21) |
+           (unsigned long long)((unsigned)z & 0x1FFFFFu);
+}
+__host__ __device__ __forceinline__ unsigned hash_key(unsigned long long k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return (unsigned)k;
+}
+
+// fixed-order 64-lane sum (same tree every run -> bit-reproducible results)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// running top-5 by (d2, arrival order): strict '<' keeps the earlier candidate on exact ties
+__device__ __forceinline__ void top5_insert(float (&d)[5], unsigned (&s)[5], float dc, unsigned sc) {
+    if (dc < d[4]) {
+        d[4] = dc;
+        s[4] = sc;
+#pragma unroll
+        for (int j = 4; j > 0; --j) {
+            if (d[j] < d[j - 1]) {
+                const float td = d[j]; d[j] = d[j - 1]; d[j - 1] = td;
+                const unsigned ts = s[j]; s[j] = s[j - 1]; s[j - 1] = ts;
+            }
+        }
+    }
+}
+
+}  // namespace fls

@@ -1,0 +1,196 @@
+// fls_reg.hip -- libfls_reg.so: C ABI (include/fls_reg.h) over the gfx950 registration back-end.
+// Single translation unit: device kernels (kernels_*.hpp) + host matchers (matcher*.hpp).
+// Built by csrc/Makefile:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+// There is no CPU fallback: without a gfx950 device fls_create fails with FLS_ERR_DEVICE.
+#include "matcher_p2plane_ivox.hpp"
+#include "matchers_kd.hpp"
+#include "matcher_ndt.hpp"
+#include <new>
+
+using namespace fls;
+
+namespace {
+
+int gfx950_device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+template <typename F>
+fls_status guarded(F&& f) {
+    try {
+        return f();
+    } catch (const HipError& e) {
+        std::fprintf(stderr, "[fls_reg] %s\n", e.what());
+        return FLS_ERR_DEVICE;
+    } catch (const std::bad_alloc&) {
+        return FLS_ERR_NOMEM;
+    } catch (...) {
+        return FLS_ERR_INVALID;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fls_abi_version(void) { return FLS_ABI_VERSION; }
+int fls_device_count(void) { return gfx950_device_count(); }
+
+const char* fls_status_string(int s) {
+    switch (s) {
+        case FLS_OK: return "ok (Match returned true)";
+        case FLS_NOT_CONVERGED: return "not converged (Match returned false)";
+        case FLS_ERR_INVALID: return "invalid argument or unset parameter";
+        case FLS_ERR_DEVICE: return "HIP error or no gfx950 device";
+        case FLS_ERR_RANGE: return "coordinate outside the voxel key range";
+        case FLS_ERR_NOMEM: return "out of memory";
+        case FLS_ERR_STATE: return "call order violated";
+        default: return "unknown status";
+    }
+}
+
+fls_status fls_create(fls_kind kind, const fls_params* params, int device_id, fls_handle* out) {
+    if (!out) return FLS_ERR_INVALID;
+    *out = nullptr;
+    if (!params) return FLS_ERR_INVALID;
+    const fls_status pc = check_common(*params);
+    if (pc != FLS_OK) return pc;
+    return guarded([&]() -> fls_status {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return FLS_ERR_DEVICE;
+        hipDeviceProp_t prop;
+        FLS_HIP(hipGetDeviceProperties(&prop, device_id));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            std::fprintf(stderr, "[fls_reg] device %d is %s; this library is built for gfx950 only\n", device_id, prop.gcnArchName);
+            return FLS_ERR_DEVICE;
+        }
+        std::unique_ptr<fls_matcher> m;
+        fls_status rc = FLS_ERR_INVALID;
+        switch (kind) {
+            case FLS_P2PLANE_IVOX: { auto* q = new P2PlaneIvoxMatcher(); m.reset(q); q->kind = kind; q->p = *params; q->device = device_id; rc = q->init(); break; }
+            case FLS_ICP_OPTIMIZED: { auto* q = new IcpMatcher(); m.reset(q); q->kind = kind; q->p = *params; q->device = device_id; rc = q->init(); break; }
+            case FLS_INCREMENTAL_NDT: { auto* q = new NdtMatcher(); m.reset(q); q->kind = kind; q->p = *params; q->device = device_id; rc = q->init(); break; }
+            case FLS_LOAM_FULL: { auto* q = new LoamFullMatcher(); m.reset(q); q->kind = kind; q->p = *params; q->device = device_id; rc = q->init(); break; }
+            case FLS_P2PLANE_KDTREE: { auto* q = new P2PlaneKdMatcher(); m.reset(q); q->kind = kind; q->p = *params; q->device = device_id; rc = q->init(); break; }
+            default: return FLS_ERR_INVALID;
+        }
+        if (rc != FLS_OK) return rc;
+        *out = m.release();
+        return FLS_OK;
+    });
+}
+
+void fls_destroy(fls_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    delete h;
+}
+
+fls_status fls_add_cloud_to_local_map(fls_handle h, const float* c0, size_t n0, const float* c1, size_t n1, int stride) {
+    if (!h || (!c0 && n0) || stride < 3) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(h->device));
+        return h->add_cloud(c0, n0, c1, n1, stride);
+    });
+}
+
+fls_status fls_scan_upload(fls_handle h, const float* s0, size_t n0, const float* s1, size_t n1, int stride) {
+    if (!h || (!s0 && n0) || stride < 3) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(h->device));
+        const fls_status rc = h->scan_upload(s0, n0, s1, n1, stride);
+        FLS_HIP(hipStreamSynchronize(h->stream));
+        return rc;
+    });
+}
+
+fls_status fls_match_resident(fls_handle h, double T[16], int update_map, fls_stats* stats) {
+    if (!h || !T) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(h->device));
+        return h->match_resident(T, update_map, stats);
+    });
+}
+
+fls_status fls_match(fls_handle h, const float* s0, size_t n0, const float* s1, size_t n1, int stride, double T[16], int update_map,
+                     fls_stats* stats) {
+    if (!h || !T || (!s0 && n0) || stride < 3) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(h->device));
+        const fls_status rc = h->scan_upload(s0, n0, s1, n1, stride);
+        if (rc != FLS_OK) return rc;
+        return h->match_resident(T, update_map, stats);
+    });
+}
+
+fls_status fls_get_fitness_score(fls_handle h, float max_range, float* score) {
+    if (!h || !score) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(h->device));
+        return h->fitness(max_range, score);
+    });
+}
+
+int fls_get_iteration_log(fls_handle h, double* T_iters, int32_t* n_valid, double* sum_res, int cap) {
+    if (!h || !h->h_state.p) return 0;
+    const GnState& s = *h->h_state.p;
+    const int n = std::min(cap, h->log_n);
+    for (int i = 0; i < n; ++i) {
+        if (T_iters) std::memcpy(T_iters + 16 * i, s.log_T[i], sizeof(double) * 16);
+        if (n_valid) n_valid[i] = s.log_nv[i];
+        if (sum_res) sum_res[i] = s.log_res[i];
+    }
+    return h->log_n;
+}
+
+int fls_get_correspondences(fls_handle h, int slot, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) {
+    if (!h || !ids || !cnt || !valid) return -1;
+    int n = -1;
+    const fls_status rc = guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(h->device));
+        n = h->correspondences(slot, ids, cnt, valid, cap);
+        return FLS_OK;
+    });
+    return rc == FLS_OK ? n : -1;
+}
+
+size_t fls_map_size(fls_handle h, int slot) { return h ? h->map_size(slot) : 0; }
+
+fls_status fls_set_profiling(fls_handle h, int enable) {
+    if (!h) return FLS_ERR_INVALID;
+    h->profiling = (enable & 1) != 0;
+    h->count_traffic = (enable & 2) != 0;
+    h->prof_ms = 0.0;
+    h->prof_launches = 0;
+    h->prof_point_iters = 0;
+    return FLS_OK;
+}
+
+fls_status fls_get_kernel_time(fls_handle h, double* ms_total, int64_t* launches, uint64_t* point_iters) {
+    if (!h) return FLS_ERR_INVALID;
+    if (ms_total) *ms_total = h->prof_ms;
+    if (launches) *launches = h->prof_launches;
+    if (point_iters) *point_iters = h->prof_point_iters;
+    h->prof_ms = 0.0;
+    h->prof_launches = 0;
+    h->prof_point_iters = 0;
+    return FLS_OK;
+}
+
+fls_status fls_get_traffic_counters(fls_handle h, uint64_t* probes, uint64_t* hit_voxels, uint64_t* cand_points) {
+    if (!h) return FLS_ERR_INVALID;
+    if (probes) *probes = h->last_tc.probes;
+    if (hit_voxels) *hit_voxels = h->last_tc.hits;
+    if (cand_points) *cand_points = h->last_tc.cand;
+    return FLS_OK;
+}
+
+}  // extern "C"

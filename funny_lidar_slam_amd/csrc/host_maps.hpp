@@ -1,0 +1,252 @@
+// host_maps.hpp -- host-side map bookkeeping of the product (C++), and flattening into the
+// device image (hash table + voxel-bucketed float4 points) the kernels read.
+//
+//   HostIvox      : authoritative iVox state with the reference's exact insert / LRU-evict
+//                   semantics (src/ivox_map/ivox_map.cpp:122-143, capacity rule :133-136).
+//                   Round 1 keeps it on the host and re-flattens after an update; the
+//                   device-side incremental insert is SURVEY.md 8f rank 1 ("next").
+//   voxel_grid    : pcl::VoxelGrid<PointXYZI>::filter semantics (centroid per leaf, ascending
+//                   leaf index) used inside Match by ICP/NDT and by the kd-tree map updates
+//                   (include/common/pointcloud_utility.h:216-271).
+//   CellGridImage : exact-kNN uniform grid over a flat map cloud (stand-in for the reference's
+//                   pcl::KdTreeFLANN, see kernels_knn.hpp for the exactness argument).
+#pragma once
+#include "device_common.hpp"
+#include "host_util.hpp"
+#include <unordered_map>
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace fls {
+
+struct Pt4 { float x, y, z; int id; };  // same 16 bytes as the device float4 {x,y,z,id-bits}
+static_assert(sizeof(Pt4) == 16, "Pt4 must alias float4");
+
+struct PtI { float x, y, z, i; };  // xyz + intensity (VoxelGrid averages all fields)
+
+inline std::vector<PtI> cloud_from(const float* p, size_t n, int stride) {
+    std::vector<PtI> c(n);
+    for (size_t k = 0; k < n; ++k) {
+        c[k].x = p[k * stride];
+        c[k].y = p[k * stride + 1];
+        c[k].z = p[k * stride + 2];
+        c[k].i = stride >= 4 ? p[k * stride + 3] : 0.0f;
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+class HostIvox {
+public:
+    struct Voxel {
+        unsigned long long key;
+        std::vector<Pt4> pts;
+        int prev = -1, next = -1;  // LRU list (head = most recently inserted-into)
+        bool alive = false;
+    };
+    float resolution = 0.5f, inv_resolution = 2.0f;
+    size_t capacity = 1000000;
+    std::vector<Voxel> pool;
+    std::vector<int> free_slots;
+    std::unordered_map<unsigned long long, int> index;
+    int head = -1, tail = -1;
+    size_t n_alive = 0, n_points = 0;
+    int next_id = 0;
+
+    void clear() {
+        pool.clear(); free_slots.clear(); index.clear();
+        head = tail = -1; n_alive = n_points = 0; next_id = 0;
+    }
+    static bool key_of(float x, float y, float z, float inv, int& kx, int& ky, int& kz) {
+        const float fx = std::round(x * inv), fy = std::round(y * inv), fz = std::round(z * inv);
+        if (!(std::fabs(fx) < float(kKeyLimit) && std::fabs(fy) < float(kKeyLimit) && std::fabs(fz) < float(kKeyLimit))) return false;
+        kx = int(fx); ky = int(fy); kz = int(fz);
+        return true;
+    }
+    // all-or-nothing range check, then the reference's sequential insert
+    fls_status add_points(const PtI* pts, size_t n) {
+        for (size_t i = 0; i < n; ++i) {
+            int a, b, c;
+            if (!key_of(pts[i].x, pts[i].y, pts[i].z, inv_resolution, a, b, c)) return FLS_ERR_RANGE;
+        }
+        for (size_t i = 0; i < n; ++i) {
+            int kx, ky, kz;
+            key_of(pts[i].x, pts[i].y, pts[i].z, inv_resolution, kx, ky, kz);
+            const unsigned long long key = pack_key(kx, ky, kz);
+            auto it = index.find(key);
+            const Pt4 p{pts[i].x, pts[i].y, pts[i].z, next_id++};
+            if (it == index.end()) {
+                int v;
+                if (!free_slots.empty()) { v = free_slots.back(); free_slots.pop_back(); }
+                else { v = int(pool.size()); pool.emplace_back(); }
+                Voxel& vx = pool[v];
+                vx.key = key; vx.pts.clear(); vx.pts.push_back(p); vx.alive = true;
+                link_front(v);
+                index.emplace(key, v);
+                ++n_alive; ++n_points;
+                if (n_alive >= capacity) evict_tail();
+            } else {
+                const int v = it->second;
+                pool[v].pts.push_back(p);
+                ++n_points;
+                unlink(v);
+                link_front(v);
+            }
+        }
+        return FLS_OK;
+    }
+
+private:
+    void link_front(int v) {
+        pool[v].prev = -1; pool[v].next = head;
+        if (head >= 0) pool[head].prev = v;
+        head = v;
+        if (tail < 0) tail = v;
+    }
+    void unlink(int v) {
+        const int p = pool[v].prev, nx = pool[v].next;
+        if (p >= 0) pool[p].next = nx; else head = nx;
+        if (nx >= 0) pool[nx].prev = p; else tail = p;
+    }
+    void evict_tail() {
+        const int v = tail;
+        if (v < 0) return;
+        unlink(v);
+        index.erase(pool[v].key);
+        n_points -= pool[v].pts.size();
+        pool[v].pts.clear(); pool[v].pts.shrink_to_fit();
+        pool[v].alive = false;
+        free_slots.push_back(v);
+        --n_alive;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Device image of a hash grid: built on the host, uploaded in two copies.
+// ---------------------------------------------------------------------------------------------
+struct GridImage {
+    std::vector<HashEntry> table;
+    std::vector<Pt4> pts;
+    DevBuf<HashEntry> d_table;
+    DevBuf<float4> d_pts;
+    unsigned mask = 0;
+
+    static unsigned table_size_for(size_t n_keys) {
+        size_t s = 1024;
+        while (s < 2 * n_keys + 2) s <<= 1;
+        return unsigned(s);
+    }
+    void begin_build(size_t n_keys, size_t n_pts) {
+        const unsigned ts = table_size_for(n_keys);
+        mask = ts - 1;
+        table.assign(ts, HashEntry{kEmptyKey, 0u, 0u});
+        pts.clear();
+        pts.reserve(n_pts);
+    }
+    void insert_bucket(unsigned long long key, const Pt4* p, size_t n) {
+        unsigned h = hash_key(key) & mask;
+        while (table[h].key != kEmptyKey) h = (h + 1) & mask;
+        table[h] = HashEntry{key, unsigned(pts.size()), unsigned(n)};
+        pts.insert(pts.end(), p, p + n);
+    }
+    void upload(hipStream_t s) {
+        d_table.reserve(table.size());
+        d_pts.reserve(std::max<size_t>(pts.size(), 1));
+        FLS_HIP(hipMemcpyAsync(d_table.p, table.data(), table.size() * sizeof(HashEntry), hipMemcpyHostToDevice, s));
+        if (!pts.empty()) FLS_HIP(hipMemcpyAsync(d_pts.p, pts.data(), pts.size() * sizeof(Pt4), hipMemcpyHostToDevice, s));
+        FLS_HIP(hipStreamSynchronize(s));
+    }
+    DevGrid dev() const { return DevGrid{d_table.p, d_pts.p, mask, unsigned(pts.size())}; }
+
+    void build_from_ivox(const HostIvox& m, hipStream_t s) {
+        begin_build(m.n_alive, m.n_points);
+        for (const auto& v : m.pool)
+            if (v.alive) insert_bucket(v.key, v.pts.data(), v.pts.size());
+        upload(s);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// pcl::VoxelGrid<PointXYZI>::filter (PCL 1.10 applyFilter; downsample_all_data_ = true)
+// ---------------------------------------------------------------------------------------------
+inline std::vector<PtI> voxel_grid(const std::vector<PtI>& in, float leaf) {
+    std::vector<PtI> out;
+    if (in.empty()) return out;
+    const float inv = 1.0f / leaf;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const PtI& p : in) {
+        if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+        mn[0] = std::min(mn[0], p.x); mx[0] = std::max(mx[0], p.x);
+        mn[1] = std::min(mn[1], p.y); mx[1] = std::max(mx[1], p.y);
+        mn[2] = std::min(mn[2], p.z); mx[2] = std::max(mx[2], p.z);
+    }
+    const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1,
+                    dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > (long long)std::numeric_limits<int>::max()) return in;  // PCL: "leaf size too small", input copied
+    int min_b[3], div_b[3];
+    for (int a = 0; a < 3; ++a) {
+        min_b[a] = int(std::floor(mn[a] * inv));
+        div_b[a] = int(std::floor(mx[a] * inv)) - min_b[a] + 1;
+    }
+    const int m1 = div_b[0], m2 = div_b[0] * div_b[1];
+    struct Leaf { unsigned idx, pt; bool operator<(const Leaf& o) const { return idx < o.idx; } };
+    std::vector<Leaf> lv;
+    lv.reserve(in.size());
+    for (size_t k = 0; k < in.size(); ++k) {
+        const PtI& p = in[k];
+        if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+        const int i0 = int(std::floor(p.x * inv) - float(min_b[0]));
+        const int i1 = int(std::floor(p.y * inv) - float(min_b[1]));
+        const int i2 = int(std::floor(p.z * inv) - float(min_b[2]));
+        lv.push_back(Leaf{unsigned(i0 + i1 * m1 + i2 * m2), unsigned(k)});
+    }
+    std::sort(lv.begin(), lv.end());
+    for (size_t a = 0; a < lv.size();) {
+        size_t b = a + 1;
+        while (b < lv.size() && lv[b].idx == lv[a].idx) ++b;
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        for (size_t k = a; k < b; ++k) { const PtI& p = in[lv[k].pt]; sx += p.x; sy += p.y; sz += p.z; si += p.i; }
+        const float cnt = float(b - a);
+        out.push_back(PtI{sx / cnt, sy / cnt, sz / cnt, si / cnt});
+        a = b;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact-kNN cell grid over a flat cloud: cell = floor(p * inv_cell), ids = index in the cloud.
+// ---------------------------------------------------------------------------------------------
+struct CellGridImage : GridImage {
+    float cell = 1.0f, inv_cell = 1.0f;
+    size_t n_cells = 0;
+    fls_status build(const std::vector<PtI>& cloud, float cell_size, hipStream_t s) {
+        cell = cell_size;
+        inv_cell = 1.0f / cell_size;
+        const size_t n = cloud.size();
+        std::vector<std::pair<unsigned long long, unsigned>> kv(n);
+        for (size_t i = 0; i < n; ++i) {
+            const float fx = std::floor(cloud[i].x * inv_cell), fy = std::floor(cloud[i].y * inv_cell), fz = std::floor(cloud[i].z * inv_cell);
+            if (!(std::fabs(fx) < float(kKeyLimit) && std::fabs(fy) < float(kKeyLimit) && std::fabs(fz) < float(kKeyLimit))) return FLS_ERR_RANGE;
+            kv[i] = {pack_key(int(fx), int(fy), int(fz)), unsigned(i)};
+        }
+        std::sort(kv.begin(), kv.end());
+        size_t cells = 0;
+        for (size_t a = 0; a < n; ++a) if (a == 0 || kv[a].first != kv[a - 1].first) ++cells;
+        n_cells = cells;
+        begin_build(cells, n);
+        std::vector<Pt4> bucket;
+        for (size_t a = 0; a < n;) {
+            size_t b = a + 1;
+            while (b < n && kv[b].first == kv[a].first) ++b;
+            bucket.clear();
+            for (size_t k = a; k < b; ++k) { const PtI& p = cloud[kv[k].second]; bucket.push_back(Pt4{p.x, p.y, p.z, int(kv[k].second)}); }
+            insert_bucket(kv[a].first, bucket.data(), bucket.size());
+            a = b;
+        }
+        upload(s);
+        return FLS_OK;
+    }
+};
+
+}  // namespace fls

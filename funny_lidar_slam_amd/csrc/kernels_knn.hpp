@@ -1,0 +1,573 @@
+// kernels_knn.hpp -- exact k-NN on a uniform hash grid (the GPU stand-in for the reference's
+// pcl::KdTreeFLANN) and the residual kernels built on it.   gfx950 only.
+//
+// Exactness (SURVEY.md 0 note 3): cells are floor(double(p) * inv_cell) per axis.  After scanning
+// every cell whose Chebyshev cell distance to the query cell is <= rho, every map point within
+// Euclidean distance rho*cell of the query has been seen.  The search stops when
+//   (a) K points are held and the K-th d2 <= (rho*cell)^2 (nothing unseen can beat it), or
+//   (b) (rho*cell)^2 >= gate (the caller rejects anything farther than `gate`, a SQUARED distance:
+//       icp_optimized.h:87, loam_full_kdtree.h:227,291, fitness loops), or
+//   (c) rho == kMaxRing, after which the query falls back to a brute-force scan of the whole map
+//       (only reachable for the un-gated LoamPointToPlaneKdtree search in nearly empty space).
+// Distances are FLANN L2_Simple<float>: ((dx*dx) + dy*dy) + dz*dz; ties resolve to the lower map
+// index (FLANN's order among equal distances is traversal-defined; the oracle fixes the same rule).
+//
+// Kernels (one lane = one source point, one wave per workgroup, shuffle-only reductions):
+//   icp_p2p_kernel        IcpOptimized::Match per-point lambda            icp_optimized.h:79-109
+//   plane_knn_kernel      LoamFull::PlanarMatch / LoamPointToPlaneKdtree::PlanerMatch
+//                                                                         loam_full_kdtree.h:275-345, loam_point_to_plane_kdtree.h:204-272
+//   corner_knn_kernel     LoamFull::CornerMatch                           loam_full_kdtree.h:211-273
+//   ndt_kernel            IncrementalNDT::Match per-point lambda          incremental_ndt.h:252-285
+//   nn_dist_kernel        GetFitnessScore loops                           icp_optimized.h:191-215 etc.
+//   gn_solve_lu_kernel    H.inverse()*B + right-multiplicative update     icp_optimized.h:129-148, incremental_ndt.h:306-322
+#pragma once
+#include "kernels_p2plane.hpp"
+
+namespace fls {
+
+constexpr int kMaxRing = 4;
+
+struct CellGridDev {
+    DevGrid g;
+    double inv_cell;
+    double cell;
+};
+
+template <int K>
+struct KnnResult {
+    float d[K];
+    int id[K];
+    unsigned slot[K];
+    int found;  // number of valid entries (<= K)
+};
+
+template <int K>
+__device__ __forceinline__ void knn_insert(KnnResult<K>& r, const float dc, const int idc, const unsigned sc) {
+    const bool better = dc < r.d[K - 1] || (dc == r.d[K - 1] && idc < r.id[K - 1]);
+    if (!better) return;
+    r.d[K - 1] = dc; r.id[K - 1] = idc; r.slot[K - 1] = sc;
+    if (r.found < K) r.found++;
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) {
+        const bool sw = r.d[j] < r.d[j - 1] || (r.d[j] == r.d[j - 1] && r.id[j] < r.id[j - 1]);
+        if (sw) {
+            const float td = r.d[j]; r.d[j] = r.d[j - 1]; r.d[j - 1] = td;
+            const int ti = r.id[j]; r.id[j] = r.id[j - 1]; r.id[j - 1] = ti;
+            const unsigned ts = r.slot[j]; r.slot[j] = r.slot[j - 1]; r.slot[j - 1] = ts;
+        }
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void knn_scan_cell(const DevGrid& g, const int cx, const int cy, const int cz, const float qx,
+                                              const float qy, const float qz, KnnResult<K>& r, unsigned long long& hits,
+                                              unsigned long long& cand) {
+    if (!(abs(cx) < kKeyLimit && abs(cy) < kKeyLimit && abs(cz) < kKeyLimit)) return;
+    const unsigned long long key = pack_key(cx, cy, cz);
+    unsigned h = hash_key(key) & g.mask;
+    HashEntry e = g.table[h];
+    while (e.key != key && e.key != kEmptyKey) {
+        h = (h + 1) & g.mask;
+        e = g.table[h];
+    }
+    if (e.key != key) return;
+    hits++;
+    cand += e.count;
+    const unsigned end = e.begin + e.count;
+    for (unsigned s = e.begin; s < end; ++s) {
+        const float4 p = g.pts[s];
+        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;  // flann::L2_Simple<float>
+        knn_insert<K>(r, d2, __float_as_int(p.w), s);
+    }
+}
+
+// gate: squared-distance beyond which the caller does not care (INFINITY = un-gated)
+template <int K>
+__device__ __forceinline__ void knn_grid(const CellGridDev& cg, const float qx, const float qy, const float qz, const float gate,
+                                         KnnResult<K>& r, unsigned long long& probes, unsigned long long& hits,
+                                         unsigned long long& cand) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) { r.d[j] = INFINITY; r.id[j] = 0x7fffffff; r.slot[j] = 0; }
+    r.found = 0;
+    const double fx = floor((double)qx * cg.inv_cell), fy = floor((double)qy * cg.inv_cell), fz = floor((double)qz * cg.inv_cell);
+    if (!(fabs(fx) < (double)kKeyLimit && fabs(fy) < (double)kKeyLimit && fabs(fz) < (double)kKeyLimit)) return;
+    const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+    bool complete = false;
+    for (int rho = 0; rho <= kMaxRing && !complete; ++rho) {
+        for (int dz = -rho; dz <= rho; ++dz)
+            for (int dy = -rho; dy <= rho; ++dy)
+                for (int dx = -rho; dx <= rho; ++dx) {
+                    const int m = max(abs(dx), max(abs(dy), abs(dz)));
+                    if (m != rho) continue;
+                    probes++;
+                    knn_scan_cell<K>(cg.g, cx + dx, cy + dy, cz + dz, qx, qy, qz, r, hits, cand);
+                }
+        const double rad = (double)rho * cg.cell;
+        const double rad2 = rad * rad * (1.0 - 1e-5);
+        if (r.found == K && (double)r.d[K - 1] <= rad2) complete = true;
+        if (rad2 >= (double)gate * (1.0 + 1e-5)) complete = true;
+    }
+    if (!complete) {
+        // brute force over the whole map (exact by construction)
+#pragma unroll
+        for (int j = 0; j < K; ++j) { r.d[j] = INFINITY; r.id[j] = 0x7fffffff; r.slot[j] = 0; }
+        r.found = 0;
+        for (unsigned s = 0; s < cg.g.n_pts; ++s) {
+            const float4 p = cg.g.pts[s];
+            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+            knn_insert<K>(r, (dx * dx + dy * dy) + dz * dz, __float_as_int(p.w), s);
+        }
+        cand += cg.g.n_pts;
+    }
+}
+
+// TransformPointCloud(.., Mat4d): R,t cast to float, then r0*x + (r1*y + r2*z) + t in float
+// (pointcloud_utility.h:141-158; Eigen un-vectorised 3-term redux order)
+struct RtFloat { float R[9]; float t[3]; };
+__device__ __forceinline__ RtFloat load_rt_float(const double* T) {
+    RtFloat o;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o.R[i + j * 3] = (float)T[i + j * 4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.t[i] = (float)T[12 + i];
+    return o;
+}
+__device__ __forceinline__ void xform_f(const RtFloat& rt, const float x, const float y, const float z, float& ox, float& oy, float& oz) {
+    ox = (rt.R[0] * x + (rt.R[3] * y + rt.R[6] * z)) + rt.t[0];
+    oy = (rt.R[1] * x + (rt.R[4] * y + rt.R[7] * z)) + rt.t[1];
+    oz = (rt.R[2] * x + (rt.R[5] * y + rt.R[8] * z)) + rt.t[2];
+}
+
+__device__ __forceinline__ void count_traffic(TrafficCounters* tc, unsigned long long p, unsigned long long h, unsigned long long c) {
+    const double sp = wave_sum((double)p), sh = wave_sum((double)h), sc = wave_sum((double)c);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&tc->probes, (unsigned long long)sp);
+        atomicAdd(&tc->hits, (unsigned long long)sh);
+        atomicAdd(&tc->cand, (unsigned long long)sc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1-NN squared distance of the float-transformed source (fitness loops); d2_out[i] = inf if none
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+nn_dist_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+               const double* __restrict__ T /* 16, device */, const CellGridDev cg, const float gate, float* __restrict__ d2_out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const RtFloat rt = load_rt_float(T);
+    float qx, qy, qz;
+    xform_f(rt, sx[i], sy[i], sz[i], qx, qy, qz);
+    KnnResult<1> r;
+    unsigned long long a = 0, b = 0, c = 0;
+    knn_grid<1>(cg, qx, qy, qz, gate, r, a, b, c);
+    d2_out[i] = r.found ? r.d[0] : INFINITY;
+}
+
+// ---------------------------------------------------------------------------------------------
+// IcpOptimized per-point stage.  nn_id[i] = nearest map index (or -1), eff[i] = effect_pts
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(64)
+icp_p2p_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+               const GnState* __restrict__ st, const CellGridDev cg, const double max_corr /* squared */,
+               int* __restrict__ nn_id, unsigned char* __restrict__ eff, double* __restrict__ partials,
+               TrafficCounters* __restrict__ tc) {
+    if (st->done) return;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    double Hc[21], Bc[6], res = 0.0;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) Hc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Bc[k] = 0.0;
+    bool contrib = false;
+    unsigned long long c_p = 0, c_h = 0, c_c = 0;
+    if (i < n) {
+        const RtFloat rt = load_rt_float(st->T);
+        const float px = sx[i], py = sy[i], pz = sz[i];
+        float qx, qy, qz;
+        xform_f(rt, px, py, pz, qx, qy, qz);
+        KnnResult<1> r;
+        knn_grid<1>(cg, qx, qy, qz, (float)max_corr, r, c_p, c_h, c_c);
+        int id = -1;
+        if (r.found) {
+            if (!((double)r.d[0] > max_corr)) {
+                id = r.id[0];  // ids are reported for accepted correspondences only
+                const float4 m = cg.g.pts[r.slot[0]];
+                const double e0 = (double)qx - (double)m.x, e1 = (double)qy - (double)m.y, e2 = (double)qz - (double)m.z;
+                const double o0 = px, o1 = py, o2 = pz;
+                // M = -(R * SO3Hat(o)), zero terms kept in place (they are exact)
+                double R[9];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) R[q + j * 3] = st->T[q + j * 4];
+                const double hat[9] = {0.0, o2, -o1, -o2, 0.0, o0, o1, -o0, 0.0};
+                double J[18];  // 3x6 column-major: [I | M]
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        J[q + j * 3] = (q == j) ? 1.0 : 0.0;
+                        J[q + (j + 3) * 3] = -((R[q] * hat[0 + j * 3] + R[q + 3] * hat[1 + j * 3]) + R[q + 6] * hat[2 + j * 3]);
+                    }
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = a; b < 6; ++b) {
+                        Hc[k] = (J[0 + a * 3] * J[0 + b * 3] + J[1 + a * 3] * J[1 + b * 3]) + J[2 + a * 3] * J[2 + b * 3];
+                        ++k;
+                    }
+#pragma unroll
+                for (int a = 0; a < 6; ++a) Bc[a] = ((-J[0 + a * 3]) * e0 + (-J[1 + a * 3]) * e1) + (-J[2 + a * 3]) * e2;
+                res = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+                contrib = true;
+            }
+        }
+        nn_id[i] = id;
+        eff[i] = contrib ? 1 : 0;
+    }
+    const int lane = threadIdx.x & 63;
+    double* row = partials + (size_t)blockIdx.x * kPartialStride;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) { const double v = wave_sum(Hc[k]); if (lane == 0) row[k] = v; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const double v = wave_sum(Bc[k]); if (lane == 0) row[21 + k] = v; }
+    const double sr = wave_sum(res), sc = wave_sum(contrib ? 1.0 : 0.0);
+    if (lane == 0) { row[27] = sr; row[28] = sc; }
+    if (COUNT) count_traffic(tc, c_p, c_h, c_c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// point-to-plane on the exact 5-NN (LoamFull planar set / LoamPointToPlaneKdtree)
+// gate = point_search_thres (squared) for LoamFull, INFINITY for LoamPointToPlaneKdtree
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(64)
+plane_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                 const GnState* __restrict__ st, const CellGridDev cg, const float gate, const double plane_thres,
+                 int* __restrict__ nn_id /* [n][5] */, unsigned char* __restrict__ nn_cnt, double* __restrict__ Jst /* [7][n] */,
+                 unsigned char* __restrict__ flag, double* __restrict__ partials, TrafficCounters* __restrict__ tc) {
+    if (st->done) return;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    double T44[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T44[k] = st->T[k];
+    bool contrib = false;
+    double J[6] = {0, 0, 0, 0, 0, 0}, res = 0.0;
+    unsigned long long c_p = 0, c_h = 0, c_c = 0;
+    if (i < n) {
+        const float px = sx[i], py = sy[i], pz = sz[i];
+        const double x = px, y = py, z = pz;
+        const float ptx = (float)(((T44[0] * x + T44[4] * y) + T44[8] * z) + T44[12]);
+        const float pty = (float)(((T44[1] * x + T44[5] * y) + T44[9] * z) + T44[13]);
+        const float ptz = (float)(((T44[2] * x + T44[6] * y) + T44[10] * z) + T44[14]);
+        KnnResult<5> r;
+        knn_grid<5>(cg, ptx, pty, ptz, gate, r, c_p, c_h, c_c);
+        const bool accepted = r.found == 5 && !(r.d[4] > gate);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) nn_id[(size_t)i * 5 + j] = accepted ? r.id[j] : -1;
+        nn_cnt[i] = accepted ? 5 : 0;
+        bool valid_now = false;
+        if (accepted) {
+            float4 nn[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) nn[j] = cg.g.pts[r.slot[j]];
+            valid_now = plane_residual_dev(nn, px, py, pz, ptx, pty, ptz, T44, plane_thres, J, res);
+        }
+        if (valid_now) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) Jst[(size_t)a * n + i] = J[a];
+            Jst[(size_t)6 * n + i] = res;
+            flag[i] = 1;
+            contrib = true;
+        } else if (flag[i]) {  // Q1 stale slot
+#pragma unroll
+            for (int a = 0; a < 6; ++a) J[a] = Jst[(size_t)a * n + i];
+            res = Jst[(size_t)6 * n + i];
+            contrib = true;
+        }
+    }
+    reduce_rank1_and_store(contrib, J, res, partials + (size_t)blockIdx.x * kPartialStride);
+    if (COUNT) count_traffic(tc, c_p, c_h, c_c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// point-to-line on the exact 5-NN of the corner map (Appendix C.2)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool line_residual_dev(const float4 (&nn)[5], const float spx, const float spy, const float spz,
+                                                  const float ptx, const float pty, const float ptz, const double* __restrict__ T,
+                                                  const double ratio, double (&J)[6], double& dist) {
+    double P[5][3];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { P[j][0] = (double)nn[j].x; P[j][1] = (double)nn[j].y; P[j][2] = (double)nn[j].z; }
+    double c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = ((((P[0][a] + P[1][a]) + P[2][a]) + P[3][a]) + P[4][a]) / 5.0;
+    double D[5][3];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) D[j][a] = P[j][a] - c[a];
+    double C[3][3];  // [col][row]
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) s += D[k][i] * D[k][j];
+            C[j][i] = s / 5.0;
+        }
+    double S[3], V[3][3];
+    jacobi_svd3_v(C, S, V);
+    if (S[0] <= ratio * S[1]) return false;
+    const double n0 = V[0][0], n1 = V[0][1], n2 = V[0][2];
+    const double ps0 = (double)spx, ps1 = (double)spy, ps2 = (double)spz;
+    const double a0 = (double)ptx - c[0], a1 = (double)pty - c[1], a2 = (double)ptz - c[2];
+    const double w0 = a1 * n2 - a2 * n1, w1 = a2 * n0 - a0 * n2, w2 = a0 * n1 - a1 * n0;
+    dist = sqrt((w0 * w0 + w1 * w1) + w2 * w2);
+    const double u0 = w0 / dist, u1 = w1 / dist, u2 = w2 / dist;
+    const double v0 = (T[0] * ps0 + T[4] * ps1) + T[8] * ps2;
+    const double v1 = (T[1] * ps0 + T[5] * ps1) + T[9] * ps2;
+    const double v2 = (T[2] * ps0 + T[6] * ps1) + T[10] * ps2;
+    // M = SO3Hat(n) * SO3Hat(v)   (column-major 3x3, zero terms kept)
+    const double hn[9] = {0.0, n2, -n1, -n2, 0.0, n0, n1, -n0, 0.0};
+    const double hv[9] = {0.0, v2, -v1, -v2, 0.0, v0, v1, -v0, 0.0};
+    double M[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) M[i + j * 3] = (hn[i] * hv[0 + j * 3] + hn[i + 3] * hv[1 + j * 3]) + hn[i + 6] * hv[2 + j * 3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) J[i] = (M[0 + i * 3] * u0 + M[1 + i * 3] * u1) + M[2 + i * 3] * u2;
+    // SO3Hat(-n)^T u
+    const double hm[9] = {0.0, -n2, n1, n2, 0.0, -n0, -n1, n0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) J[3 + i] = (hm[0 + i * 3] * u0 + hm[1 + i * 3] * u1) + hm[2 + i * 3] * u2;
+    return true;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(64)
+corner_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                  const GnState* __restrict__ st, const CellGridDev cg, const float gate, const double line_ratio,
+                  int* __restrict__ nn_id, unsigned char* __restrict__ nn_cnt, double* __restrict__ Jst, unsigned char* __restrict__ flag,
+                  double* __restrict__ partials, TrafficCounters* __restrict__ tc) {
+    if (st->done) return;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    double T44[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T44[k] = st->T[k];
+    bool contrib = false;
+    double J[6] = {0, 0, 0, 0, 0, 0}, res = 0.0;
+    unsigned long long c_p = 0, c_h = 0, c_c = 0;
+    if (i < n) {
+        const float px = sx[i], py = sy[i], pz = sz[i];
+        const double x = px, y = py, z = pz;
+        const float ptx = (float)(((T44[0] * x + T44[4] * y) + T44[8] * z) + T44[12]);
+        const float pty = (float)(((T44[1] * x + T44[5] * y) + T44[9] * z) + T44[13]);
+        const float ptz = (float)(((T44[2] * x + T44[6] * y) + T44[10] * z) + T44[14]);
+        KnnResult<5> r;
+        knn_grid<5>(cg, ptx, pty, ptz, gate, r, c_p, c_h, c_c);
+        const bool accepted = r.found == 5 && !(r.d[4] > gate);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) nn_id[(size_t)i * 5 + j] = accepted ? r.id[j] : -1;
+        nn_cnt[i] = accepted ? 5 : 0;
+        bool valid_now = false;
+        if (accepted) {
+            float4 nn[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) nn[j] = cg.g.pts[r.slot[j]];
+            valid_now = line_residual_dev(nn, px, py, pz, ptx, pty, ptz, T44, line_ratio, J, res);
+        }
+        if (valid_now) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) Jst[(size_t)a * n + i] = J[a];
+            Jst[(size_t)6 * n + i] = res;
+            flag[i] = 1;
+            contrib = true;
+        } else if (flag[i]) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) J[a] = Jst[(size_t)a * n + i];
+            res = Jst[(size_t)6 * n + i];
+            contrib = true;
+        }
+    }
+    reduce_rank1_and_store(contrib, J, res, partials + (size_t)blockIdx.x * kPartialStride);
+    if (COUNT) count_traffic(tc, c_p, c_h, c_c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// IncrementalNDT per-point stage.  Voxel table: key -> voxel slot v (entry.begin), with
+// mu[v][3], info[v][9] (column-major), vid[v] (creation id); only estimated voxels are in the table.
+// ---------------------------------------------------------------------------------------------
+struct NdtGridDev {
+    const HashEntry* table;
+    unsigned mask;
+    const double* mu;    // [nv][3]
+    const double* info;  // [nv][9]
+    const int* vid;      // [nv]
+    double inv_voxel;
+};
+
+template <bool COUNT>
+__global__ void __launch_bounds__(64)
+ndt_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+           const GnState* __restrict__ st, const NdtGridDev ng, const double outlier_thr, int* __restrict__ hit_vid /* [n][7] */,
+           unsigned char* __restrict__ eff7 /* [n][7] */, double* __restrict__ partials, TrafficCounters* __restrict__ tc) {
+    if (st->done) return;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    double Hc[21], Bc[6], res = 0.0, cnt = 0.0;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) Hc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Bc[k] = 0.0;
+    unsigned long long c_p = 0, c_h = 0, c_c = 0;
+    if (i < n) {
+        double P[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) P[k] = st->T[k];
+        const double p0 = sx[i], p1 = sy[i], p2 = sz[i];
+        const double q0 = ((P[0] * p0 + P[4] * p1) + P[8] * p2) + P[12];
+        const double q1 = ((P[1] * p0 + P[5] * p1) + P[9] * p2) + P[13];
+        const double q2 = ((P[2] * p0 + P[6] * p1) + P[10] * p2) + P[14];
+        // (point_transformed * inv_voxel_size_).cast<int>(): truncation toward zero (incremental_ndt.h:256)
+        const double f0 = q0 * ng.inv_voxel, f1 = q1 * ng.inv_voxel, f2 = q2 * ng.inv_voxel;
+        const bool in_range = fabs(f0) < (double)kKeyLimit && fabs(f1) < (double)kKeyLimit && fabs(f2) < (double)kKeyLimit;
+        const int kx = in_range ? (int)f0 : 0, ky = in_range ? (int)f1 : 0, kz = in_range ? (int)f2 : 0;
+        // J = [ -R*SO3Hat(p) | I ]
+        const double hat[9] = {0.0, p2, -p1, -p2, 0.0, p0, p1, -p0, 0.0};
+        double J[18];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                J[q + j * 3] = -((P[q] * hat[0 + j * 3] + P[q + 4] * hat[1 + j * 3]) + P[q + 8] * hat[2 + j * 3]);
+                J[q + (j + 3) * 3] = (q == j) ? 1.0 : 0.0;
+            }
+        const int nb[7][3] = {{0, 0, 0}, {-1, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, -1}, {0, 0, 1}};  // :122-127
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            int vid = -1;
+            unsigned char ef = 0;
+            if (in_range) {
+                const unsigned long long key = pack_key(kx + nb[k][0], ky + nb[k][1], kz + nb[k][2]);
+                unsigned h = hash_key(key) & ng.mask;
+                HashEntry e = ng.table[h];
+                while (e.key != key && e.key != kEmptyKey) { h = (h + 1) & ng.mask; e = ng.table[h]; }
+                if (COUNT) c_p++;
+                if (e.key == key) {
+                    if (COUNT) c_h++;
+                    const unsigned v = e.begin;
+                    const double e0 = q0 - ng.mu[3 * v], e1 = q1 - ng.mu[3 * v + 1], e2 = q2 - ng.mu[3 * v + 2];
+                    double I[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) I[q] = ng.info[9 * (size_t)v + q];
+                    const double ei0 = (e0 * I[0] + e1 * I[1]) + e2 * I[2];
+                    const double ei1 = (e0 * I[3] + e1 * I[4]) + e2 * I[5];
+                    const double ei2 = (e0 * I[6] + e1 * I[7]) + e2 * I[8];
+                    const double r = (ei0 * e0 + ei1 * e1) + ei2 * e2;
+                    if (!(r != r) && !(r > outlier_thr)) {
+                        double JtI[18];  // 6x3 col-major
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+#pragma unroll
+                            for (int a = 0; a < 6; ++a)
+                                JtI[a + c * 6] = (J[0 + a * 3] * I[0 + c * 3] + J[1 + a * 3] * I[1 + c * 3]) + J[2 + a * 3] * I[2 + c * 3];
+                        int kk = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+#pragma unroll
+                            for (int b = a; b < 6; ++b) {
+                                Hc[kk] += (JtI[a + 0 * 6] * J[0 + b * 3] + JtI[a + 1 * 6] * J[1 + b * 3]) + JtI[a + 2 * 6] * J[2 + b * 3];
+                                ++kk;
+                            }
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) Bc[a] += ((-JtI[a + 0 * 6]) * e0 + (-JtI[a + 1 * 6]) * e1) + (-JtI[a + 2 * 6]) * e2;
+                        res += r;
+                        cnt += 1.0;
+                        ef = 1;
+                        vid = ng.vid[v];
+                    }
+                }
+            }
+            hit_vid[(size_t)i * 7 + k] = vid;
+            eff7[(size_t)i * 7 + k] = ef;
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    double* row = partials + (size_t)blockIdx.x * kPartialStride;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) { const double v = wave_sum(Hc[k]); if (lane == 0) row[k] = v; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const double v = wave_sum(Bc[k]); if (lane == 0) row[21 + k] = v; }
+    const double sr = wave_sum(res), sc = wave_sum(cnt);
+    if (lane == 0) { row[27] = sr; row[28] = sc; }
+    if (COUNT) count_traffic(tc, c_p, c_h, c_c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ICP / NDT Gauss-Newton tail.  mode 0 = IcpOptimized (state [dt, dtheta], det==0 skip, converged
+// flag), mode 1 = IncrementalNDT (state [dtheta, dt], min_effective early-out).  Both right-multiply.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+gn_solve_lu_kernel(GnState* __restrict__ st, const double* __restrict__ partials, const int nrows, const int mode,
+                   const double rot_thr, const double pos_thr, const int min_effective) {
+    if (st->done) return;
+    __shared__ double red[32][33];
+    __shared__ double tot[32];
+    __shared__ double Hs[36], inv[36], gs[6], xs[6];
+    __shared__ int tr[6];
+    reduce_partials(partials, nrows, tot, red);
+    if (threadIdx.x == 0) {
+        int k = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) { Hs[a + b * 6] = tot[k]; Hs[b + a * 6] = tot[k]; ++k; }
+        for (int a = 0; a < 6; ++a) gs[a] = tot[21 + a];
+        for (int q = 0; q < 36; ++q) st->H[q] = Hs[q];
+        for (int q = 0; q < 6; ++q) st->g[q] = gs[q];
+        const int it = st->iter;
+        const int effective = (int)tot[28];
+        st->n_valid = effective;
+        st->sum_res = tot[27];
+        bool log_now = true;
+        if (mode == 1 && effective < min_effective) {  // incremental_ndt.h:306-309: T = pose; return false
+            st->done = 1;
+            st->converged = 0;
+        } else {
+            const double det = lu6_inverse_det(Hs, inv, tr);
+            if (mode == 0 && det == 0.0) {
+                // icp_optimized.h:129-131: skip the update, keep iterating
+            } else {
+                for (int a = 0; a < 6; ++a) { double s = 0.0; for (int q = 0; q < 6; ++q) s += inv[a + q * 6] * gs[q]; xs[a] = s; }
+                const double* dth = (mode == 0) ? xs + 3 : xs;
+                const double* dt = (mode == 0) ? xs : xs + 3;
+                double Rd[9], R[9], Rn[9];
+                if (mode == 0) { st->T[12] += dt[0]; st->T[13] += dt[1]; st->T[14] += dt[2]; }
+                so3_exp_dev(dth, Rd);
+                for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) R[i + j * 3] = st->T[i + j * 4];
+                mat3_mul_dev(R, Rd, Rn);  // right-multiplicative
+                for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) st->T[i + j * 4] = Rn[i + j * 3];
+                if (mode == 1) { st->T[12] += dt[0]; st->T[13] += dt[1]; st->T[14] += dt[2]; }
+                for (int q = 0; q < 6; ++q) st->last_dx[q] = xs[q];
+                if (norm3d(dth) < rot_thr && norm3d(dt) < pos_thr) {
+                    st->done = 1;
+                    st->converged = 1;
+                }
+            }
+        }
+        if (log_now && it < kMaxIter) {
+            for (int q = 0; q < 16; ++q) st->log_T[it][q] = st->T[q];
+            st->log_nv[it] = effective;
+            st->log_res[it] = tot[27];
+        }
+        st->iter = it + 1;
+    }
+}
+
+}  // namespace fls

@@ -1,0 +1,296 @@
+// matcher_ndt.hpp -- host side of FLS_INCREMENTAL_NDT, the replacement of IncrementalNDT
+// (include/registration/incremental_ndt.h:16-383).
+//   AddCloudToLocalMap :182-227  voxel insert with LRU eviction + UpdateVoxel (:130-179) on the host;
+//                                the estimated voxels are flattened into a device hash table
+//                                {key -> slot} with mu[slot], info[slot] in FP64.
+//   Match              :229-337  device-resident loop: ndt_kernel (7-voxel Mahalanobis scoring,
+//                                FP64) + gn_solve_lu_kernel (mode 1).
+#pragma once
+#include "matcher_base.hpp"
+#include "host_math.hpp"
+#include "kernels_knn.hpp"
+#include "fitness_host.hpp"
+#include <list>
+#include <set>
+#include <unordered_map>
+
+namespace fls {
+
+struct NdtMatcher final : fls_matcher {
+    struct Voxel {
+        int kx, ky, kz;
+        std::vector<double> pts;  // xyz triples waiting for the next estimate
+        double mu[3] = {0, 0, 0}, sigma[9] = {0}, info[9] = {0};
+        bool estimated = false;
+        int num_points = 0;
+        int vid = 0;
+    };
+    struct KeyHash {
+        size_t operator()(unsigned long long k) const { return size_t(hash_key(k)); }
+    };
+    std::list<Voxel> data;  // front = most recently touched
+    std::unordered_map<unsigned long long, std::list<Voxel>::iterator, KeyHash> grids;
+    bool flag_first_scan = true;
+    int next_vid = 0;
+    double inv_voxel = 1.0;
+
+    // device image
+    std::vector<HashEntry> h_table;
+    std::vector<double> h_mu, h_info;
+    std::vector<int> h_vid;
+    DevBuf<HashEntry> d_table;
+    DevBuf<double> d_mu, d_info;
+    DevBuf<int> d_vid;
+    unsigned mask = 0;
+    bool have_map = false;
+
+    DevScan scan;
+    std::vector<PtI> source;
+    DevBuf<int> d_hit_vid;
+    DevBuf<unsigned char> d_eff7;
+    double final_T[16]{};
+    bool have_final = false;
+    CellGridImage fitness_grid;
+    bool have_fitness_grid = false;
+
+    fls_status init() {
+        if (unset_d(p.ndt_voxel_size) || unset_d(p.ndt_res_outlier_threshold) || unset_d(p.rotation_converge_thres) ||
+            unset_d(p.position_converge_thres) || unset_f(p.source_cloud_filter_size) || p.ndt_min_points_in_voxel == 0x7fffffff ||
+            p.ndt_max_points_in_voxel == 0x7fffffff || p.ndt_min_effective_pts == 0x7fffffff || p.ndt_capacity == 0x7fffffff)
+            return FLS_ERR_INVALID;  // CHECK_NE block incremental_ndt.h:27-36
+        if (!(p.ndt_voxel_size > 0.0) || !(p.source_cloud_filter_size > 0.f) || p.ndt_capacity <= 0) return FLS_ERR_INVALID;
+        init_common();
+        inv_voxel = 1.0 / p.ndt_voxel_size;
+        return FLS_OK;
+    }
+
+    static void mean_cov(const std::vector<double>& pts, double* mean, double* cov) {  // ComputeMeanAndCov :91-110
+        const size_t len = pts.size() / 3;
+        double s[3] = {0, 0, 0};
+        for (size_t k = 0; k < len; ++k) { s[0] += pts[3 * k]; s[1] += pts[3 * k + 1]; s[2] += pts[3 * k + 2]; }
+        for (int a = 0; a < 3; ++a) mean[a] = s[a] / double(len);
+        double c[9] = {0};
+        for (size_t k = 0; k < len; ++k) {
+            const double v[3] = {pts[3 * k] - mean[0], pts[3 * k + 1] - mean[1], pts[3 * k + 2] - mean[2]};
+            for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) c[i + j * 3] += v[i] * v[j];
+        }
+        for (int k = 0; k < 9; ++k) cov[k] = c[k] / double(len - 1);
+    }
+    void regularised_info(Voxel& v) const {
+        double m[9];
+        for (int k = 0; k < 9; ++k) m[k] = v.sigma[k] + ((k % 4 == 0) ? 1.0 : 0.0) * 1.0e-3;
+        hm::inv3(m, v.info);
+    }
+    void update_voxel(Voxel& v) const {  // UpdateVoxel :130-179
+        if (flag_first_scan) {
+            if (v.pts.size() / 3 > 1u) { mean_cov(v.pts, v.mu, v.sigma); regularised_info(v); }
+            else {
+                v.mu[0] = v.pts[0]; v.mu[1] = v.pts[1]; v.mu[2] = v.pts[2];
+                for (int k = 0; k < 9; ++k) v.info[k] = ((k % 4 == 0) ? 1.0 : 0.0) * 1.0e2;
+            }
+            v.estimated = true;
+            v.pts.clear();
+            return;
+        }
+        if (v.estimated && v.num_points > p.ndt_max_points_in_voxel) return;
+        const int npts = int(v.pts.size() / 3);
+        if (!v.estimated && npts > p.ndt_min_points_in_voxel) {
+            mean_cov(v.pts, v.mu, v.sigma);
+            regularised_info(v);
+            v.estimated = true;
+            v.pts.clear();
+        } else if (v.estimated && npts > p.ndt_min_points_in_voxel) {
+            double cmu[3], cvar[9], nmu[3], nvar[9];
+            mean_cov(v.pts, cmu, cvar);
+            const int hm_ = v.num_points, cn = npts;  // UpdateMeanAndCov :112-120
+            for (int a = 0; a < 3; ++a) nmu[a] = (double(hm_) * v.mu[a] + double(cn) * cmu[a]) / double(hm_ + cn);
+            const double dh[3] = {v.mu[0] - nmu[0], v.mu[1] - nmu[1], v.mu[2] - nmu[2]};
+            const double dc[3] = {cmu[0] - nmu[0], cmu[1] - nmu[1], cmu[2] - nmu[2]};
+            for (int j = 0; j < 3; ++j)
+                for (int i = 0; i < 3; ++i)
+                    nvar[i + j * 3] = (double(hm_) * (v.sigma[i + j * 3] + dh[i] * dh[j]) + double(cn) * (cvar[i + j * 3] + dc[i] * dc[j])) / double(hm_ + cn);
+            std::memcpy(v.mu, nmu, sizeof(nmu));
+            std::memcpy(v.sigma, nvar, sizeof(nvar));
+            v.num_points += npts;
+            v.pts.clear();
+            double U[9], S[3], V[9];
+            hm::svd3(v.sigma, U, S, V);
+            if (S[1] < S[0] * 1e-3) S[1] = S[0] * 1e-3;
+            if (S[2] < S[0] * 1e-3) S[2] = S[0] * 1e-3;
+            const double il[3] = {1.0 / S[0], 1.0 / S[1], 1.0 / S[2]};
+            double VL[9];
+            for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) VL[i + k * 3] = V[i + k * 3] * il[k];
+            for (int j = 0; j < 3; ++j)
+                for (int i = 0; i < 3; ++i)
+                    v.info[i + j * 3] = (VL[i] * U[j] + VL[i + 3] * U[j + 3]) + VL[i + 6] * U[j + 6];
+        }
+    }
+
+    void rebuild_image() {
+        size_t n_est = 0;
+        for (const auto& v : data) n_est += v.estimated ? 1 : 0;
+        const unsigned ts = GridImage::table_size_for(n_est);
+        mask = ts - 1;
+        h_table.assign(ts, HashEntry{kEmptyKey, 0u, 0u});
+        h_mu.clear(); h_info.clear(); h_vid.clear();
+        unsigned slot = 0;
+        for (const auto& v : data) {
+            if (!v.estimated) continue;
+            const unsigned long long key = pack_key(v.kx, v.ky, v.kz);
+            unsigned h = hash_key(key) & mask;
+            while (h_table[h].key != kEmptyKey) h = (h + 1) & mask;
+            h_table[h] = HashEntry{key, slot, 1u};
+            h_mu.insert(h_mu.end(), v.mu, v.mu + 3);
+            h_info.insert(h_info.end(), v.info, v.info + 9);
+            h_vid.push_back(v.vid);
+            ++slot;
+        }
+        d_table.reserve(ts);
+        d_mu.reserve(std::max<size_t>(h_mu.size(), 3));
+        d_info.reserve(std::max<size_t>(h_info.size(), 9));
+        d_vid.reserve(std::max<size_t>(h_vid.size(), 1));
+        FLS_HIP(hipMemcpyAsync(d_table.p, h_table.data(), ts * sizeof(HashEntry), hipMemcpyHostToDevice, stream));
+        if (slot) {
+            FLS_HIP(hipMemcpyAsync(d_mu.p, h_mu.data(), h_mu.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+            FLS_HIP(hipMemcpyAsync(d_info.p, h_info.data(), h_info.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+            FLS_HIP(hipMemcpyAsync(d_vid.p, h_vid.data(), h_vid.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        }
+        FLS_HIP(hipStreamSynchronize(stream));
+        have_map = true;
+    }
+
+    fls_status add_cloud_impl(const std::vector<PtI>& cloud_world_full) {  // :182-227
+        const std::vector<PtI> cloud_world = voxel_grid(cloud_world_full, p.source_cloud_filter_size);
+        // range check first (all-or-nothing)
+        for (const PtI& pt : cloud_world) {
+            const double f[3] = {double(pt.x) * inv_voxel, double(pt.y) * inv_voxel, double(pt.z) * inv_voxel};
+            for (int a = 0; a < 3; ++a)
+                if (!(std::fabs(f[a]) < double(kKeyLimit))) return FLS_ERR_RANGE;
+        }
+        if (p.is_localization_mode) { have_fitness_grid = fitness_grid.build(cloud_world, 1.0f, stream) == FLS_OK; }
+        std::set<unsigned long long> active;
+        for (const PtI& pt : cloud_world) {
+            const double pe[3] = {double(pt.x), double(pt.y), double(pt.z)};
+            const int kx = int(pe[0] * inv_voxel), ky = int(pe[1] * inv_voxel), kz = int(pe[2] * inv_voxel);  // cast<int>: truncation (:195)
+            const unsigned long long key = pack_key(kx, ky, kz);
+            auto it = grids.find(key);
+            if (it == grids.end()) {
+                Voxel v;
+                v.kx = kx; v.ky = ky; v.kz = kz;
+                v.pts = {pe[0], pe[1], pe[2]};
+                v.num_points = 1;
+                v.vid = next_vid++;
+                data.push_front(std::move(v));
+                grids.emplace(key, data.begin());
+                if (data.size() >= size_t(p.ndt_capacity)) {  // :202-205
+                    const Voxel& b = data.back();
+                    grids.erase(pack_key(b.kx, b.ky, b.kz));
+                    data.pop_back();
+                }
+            } else {
+                Voxel& v = *it->second;
+                v.pts.push_back(pe[0]); v.pts.push_back(pe[1]); v.pts.push_back(pe[2]);
+                if (!v.estimated) v.num_points++;
+                data.splice(data.begin(), data, it->second);
+                it->second = data.begin();
+            }
+            active.insert(key);
+        }
+        for (unsigned long long k : active) {
+            auto it = grids.find(k);
+            if (it == grids.end()) continue;  // evicted within this very call (the reference would dereference a null entry)
+            update_voxel(*it->second);
+        }
+        flag_first_scan = p.is_localization_mode ? true : false;  // :222-226
+        rebuild_image();
+        return FLS_OK;
+    }
+    fls_status add_cloud(const float* c0, size_t n0, const float* c1, size_t n1, int stride) override {
+        if (c1 != nullptr && n1 != 0) return FLS_ERR_INVALID;
+        return add_cloud_impl(cloud_from(c0, n0, stride));
+    }
+    fls_status scan_upload(const float* s0, size_t n0, const float*, size_t, int stride) override {
+        source = voxel_grid(cloud_from(s0, n0, stride), p.source_cloud_filter_size);  // :232
+        scan.upload(source, stream);
+        return FLS_OK;
+    }
+    fls_status match_resident(double* T, int update_map, fls_stats* out) override {
+        if (grids.empty() || !have_map) return FLS_ERR_STATE;  // CHECK(!grids_.empty()) :230
+        const size_t n = scan.n;
+        const int nblk = int((n + 63) / 64);
+        stats = fls_stats{};
+        stats.n_source = int(n);
+        double T_in[16];
+        std::memcpy(T_in, T, sizeof(T_in));
+        d_hit_vid.reserve(std::max<size_t>(n * 7, 1));
+        d_eff7.reserve(std::max<size_t>(n * 7, 1));
+        d_partials_b.reserve(size_t(std::max(nblk, 1)) * kPartialStride);
+        push_state(T);
+        const int iters = int(p.max_iterations);
+        if (profiling) ensure_events(iters);
+        const NdtGridDev ng{d_table.p, mask, d_mu.p, d_info.p, d_vid.p, inv_voxel};
+        for (int it = 0; it < iters; ++it) {
+            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
+            if (nblk > 0) {
+                if (count_traffic)
+                    hipLaunchKernelGGL(ndt_kernel<true>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, ng,
+                                       p.ndt_res_outlier_threshold, d_hit_vid.p, d_eff7.p, d_partials_b.p, d_tc.p);
+                else
+                    hipLaunchKernelGGL(ndt_kernel<false>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, ng,
+                                       p.ndt_res_outlier_threshold, d_hit_vid.p, d_eff7.p, d_partials_b.p, d_tc.p);
+            }
+            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
+            hipLaunchKernelGGL(gn_solve_lu_kernel, dim3(1), dim3(1024), 0, stream, d_state.p, (const double*)d_partials_b.p, nblk, 1,
+                               p.rotation_converge_thres, p.position_converge_thres, p.ndt_min_effective_pts);
+        }
+        FLS_HIP(hipGetLastError());
+        pull_state(n);
+        const GnState& s = *h_state.p;
+        stats.iterations = s.iter;
+        stats.n_valid = s.n_valid;
+        stats.sum_res = s.sum_res;
+        std::memcpy(stats.last_dx, s.last_dx, sizeof(stats.last_dx));
+        // the min_effective early-out sets done with converged == 0 on the device (:306-309: T = pose; return false)
+        const bool early_fail = s.done && !s.converged && s.n_valid < p.ndt_min_effective_pts;
+        if (early_fail) {
+            std::memcpy(T, s.T, sizeof(double) * 16);
+            stats.converged = 0;
+            if (out) *out = stats;
+            return FLS_NOT_CONVERGED;
+        }
+        // has_converge = true unconditionally (:325, Q10)
+        if (!p.is_localization_mode && update_map) {
+            add_cloud_impl(hm::xform_cloud_f(source, T_in));  // Q11: transformed with the INPUT T (:327-329)
+            stats.map_updated = 1;
+        }
+        std::memcpy(T, s.T, sizeof(double) * 16);
+        std::memcpy(final_T, s.T, sizeof(final_T));
+        have_final = true;
+        stats.converged = 1;
+        if (out) *out = stats;
+        return FLS_OK;
+    }
+    fls_status fitness(float max_range, float* score) override {
+        if (!p.is_localization_mode) { *score = std::numeric_limits<float>::max(); return FLS_OK; }  // :346-348
+        if (!have_fitness_grid || !have_final) return FLS_ERR_STATE;
+        return fitness_score_device(*this, fitness_grid, scan, final_T, max_range, score);
+    }
+    int correspondences(int, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) override {
+        const size_t n = std::min(cap, scan.n);
+        if (!n) return 0;
+        std::vector<unsigned char> ef(n * 7);
+        FLS_HIP(hipMemcpyAsync(ids, d_hit_vid.p, n * 7 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipMemcpyAsync(ef.data(), d_eff7.p, n * 7, hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipStreamSynchronize(stream));
+        for (size_t i = 0; i < n; ++i) {
+            int c = 0;
+            for (int k = 0; k < 7; ++k) c += ef[i * 7 + k];
+            cnt[i] = uint8_t(c);
+            valid[i] = c > 0;
+        }
+        return int(n);
+    }
+    size_t map_size(int) const override { return data.size(); }
+};
+
+}  // namespace fls

@@ -1,0 +1,229 @@
+// matcher_p2plane_ivox.hpp -- host side of FLS_P2PLANE_IVOX, the replacement of
+// LoamPointToPlaneIVOX<double> (include/registration/loam_point_to_plane_ivox.h:30-355).
+//
+//   AddCloudToLocalMap  :60-139   first call / localization: insert all; later: the
+//                                 centre-distance down-sampling rule on the last kNN result
+//   Match               :141-216  device-resident Gauss-Newton loop (2 launches / iteration,
+//                                 one host synchronisation per Match)
+//   GetFitnessScore     :225-253  localization mode only (FloatNaN otherwise)
+#pragma once
+#include "matcher_base.hpp"
+#include "kernels_p2plane.hpp"
+#include "kernels_knn.hpp"
+#include "fitness_host.hpp"
+
+namespace fls {
+
+struct P2PlaneIvoxMatcher final : fls_matcher {
+    HostIvox ivox;
+    GridImage image;
+    bool image_dirty = true;
+    bool is_first = true;  // the reference's function-static flag (:62), per handle here
+    const double filter_size_map_min = 0.5;  // :351
+
+    DevScan scan;
+    // per-point state that outlives an iteration (Q1) or a Match (nearest_points_, :257)
+    DevBuf<float4> d_nn;          // [n][5]
+    DevBuf<unsigned char> d_nn_cnt;
+    size_t nn_n = 0;              // logical size of nearest_points_
+    DevBuf<double> d_J;           // [7][n]
+    DevBuf<unsigned char> d_flag;
+    size_t number_planar_point = 0;
+    double T_[16]{}, final_T[16]{};
+    bool have_final = false;
+    // localization-mode fitness map (kd-tree stand-in)
+    CellGridImage fitness_grid;
+    bool have_fitness_grid = false;
+    std::vector<Pt4> h_nn;
+    std::vector<unsigned char> h_cnt, h_flag;
+
+    fls_status init() {
+        if (unset_d(p.point_to_planar_thres) || unset_d(p.position_converge_thres) || unset_d(p.rotation_converge_thres))
+            return FLS_ERR_INVALID;  // CHECK_NE(..., max()) at :45-48
+        init_common();
+        ivox.resolution = 0.5f;       // InitIVox :53-58
+        ivox.inv_resolution = 1.0f / 0.5f;
+        ivox.capacity = 1000000;
+        return FLS_OK;
+    }
+
+    void refresh_image() {
+        if (image_dirty) { image.build_from_ivox(ivox, stream); image_dirty = false; }
+    }
+
+    // pcl::transformPoint with Affine3d(T_): double evaluation, float result
+    static PtI xform_d(const PtI& p, const double* T) {
+        PtI r = p;
+        const double x = p.x, y = p.y, z = p.z;
+        r.x = float(((T[0] * x + T[4] * y) + T[8] * z) + T[12]);
+        r.y = float(((T[1] * x + T[5] * y) + T[9] * z) + T[13]);
+        r.z = float(((T[2] * x + T[6] * y) + T[10] * z) + T[14]);
+        return r;
+    }
+
+    void download_nn() {
+        const size_t n = nn_n;
+        h_nn.resize(n * 5);
+        h_cnt.resize(n);
+        if (n == 0) return;
+        FLS_HIP(hipMemcpyAsync(h_nn.data(), d_nn.p, n * 5 * sizeof(float4), hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipMemcpyAsync(h_cnt.data(), d_nn_cnt.p, n, hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipStreamSynchronize(stream));
+    }
+
+    fls_status add_cloud(const float* c0, size_t n0, const float* c1, size_t n1, int stride) override {
+        if (c1 != nullptr && n1 != 0) return FLS_ERR_INVALID;  // CHECK_EQ(cloud_list.size(), 1) :61
+        const std::vector<PtI> cloud = cloud_from(c0, n0, stride);
+        return add_cloud_impl(cloud);
+    }
+
+    fls_status add_cloud_impl(const std::vector<PtI>& planar_cloud) {
+        if (p.is_localization_mode) { is_first = true; ivox.clear(); }
+        fls_status rc = FLS_OK;
+        if (is_first) {
+            rc = ivox.add_points(planar_cloud.data(), planar_cloud.size());
+            if (rc != FLS_OK) return rc;
+            is_first = false;
+        } else {
+            // :79-131  decisions use nearest_points_ of the LAST PlanerMatch and T_ (body-frame cloud expected)
+            download_nn();
+            std::vector<PtI> to_add, no_downsample;
+            const double fs = filter_size_map_min, half = 0.5 * filter_size_map_min;
+            const size_t n = std::min(number_planar_point, planar_cloud.size());
+            for (size_t i = 0; i < n; ++i) {
+                const PtI pw = xform_d(planar_cloud[i], T_);
+                const int cnt = i < nn_n ? h_cnt[i] : 0;
+                if (cnt > 0) {
+                    const Pt4* near = &h_nn[i * 5];
+                    const double c[3] = {(std::floor(double(pw.x) / fs) + 0.5) * fs, (std::floor(double(pw.y) / fs) + 0.5) * fs,
+                                         (std::floor(double(pw.z) / fs) + 0.5) * fs};
+                    const double d0[3] = {double(near[0].x) - c[0], double(near[0].y) - c[1], double(near[0].z) - c[2]};
+                    if (std::fabs(d0[0]) > half && std::fabs(d0[1]) > half && std::fabs(d0[2]) > half) {
+                        no_downsample.push_back(pw);
+                        continue;
+                    }
+                    bool need_add = true;
+                    const double e[3] = {double(pw.x) - c[0], double(pw.y) - c[1], double(pw.z) - c[2]};
+                    const double dist = (e[0] * e[0] + e[1] * e[1]) + e[2] * e[2];
+                    if (cnt >= 5) {
+                        for (int k = 0; k < 5; ++k) {
+                            const double f[3] = {double(near[k].x) - c[0], double(near[k].y) - c[1], double(near[k].z) - c[2]};
+                            if ((f[0] * f[0] + f[1] * f[1]) + f[2] * f[2] < dist + 1.0e-6) { need_add = false; break; }
+                        }
+                    }
+                    if (need_add) to_add.push_back(pw);
+                } else {
+                    to_add.push_back(pw);
+                }
+            }
+            rc = ivox.add_points(to_add.data(), to_add.size());
+            if (rc != FLS_OK) return rc;
+            rc = ivox.add_points(no_downsample.data(), no_downsample.size());
+            if (rc != FLS_OK) return rc;
+        }
+        image_dirty = true;
+        refresh_image();
+        if (p.is_localization_mode) {  // :134-138 kd-tree for GetFitnessScore
+            rc = fitness_grid.build(planar_cloud, 1.0f, stream);
+            have_fitness_grid = (rc == FLS_OK);
+        }
+        return rc;
+    }
+
+    fls_status scan_upload(const float* s0, size_t n0, const float* s1, size_t n1, int stride) override {
+        (void)s1; (void)n1;
+        scan.upload(cloud_from(s0, n0, stride), stream);
+        return FLS_OK;
+    }
+
+    fls_status match_resident(double* T, int update_map, fls_stats* out) override {
+        const size_t n = scan.n;
+        const int nblk = int((n + 63) / 64);
+        number_planar_point = n;
+        stats = fls_stats{};
+        stats.n_source = int(n);
+        std::memcpy(T_, T, sizeof(T_));
+        if (n == 0) {
+            // empty planar cloud: H = g = 0 -> dx = 0 -> stop rule fires in iteration 0, n_valid = 0 < 50 -> false (:201-203)
+            stats.iterations = 1; stats.converged = 0;
+            if (out) *out = stats;
+            log_n = 0;
+            return FLS_NOT_CONVERGED;
+        }
+        refresh_image();
+        // nearest_points_.resize(n) semantics (:257): grown tail is empty, shrink forgets
+        d_nn.reserve(n * 5, /*keep=*/true, stream);
+        d_nn_cnt.reserve(n, /*keep=*/true, stream);
+        if (n > nn_n) FLS_HIP(hipMemsetAsync(d_nn_cnt.p + nn_n, 0, n - nn_n, stream));
+        nn_n = n;
+        d_J.reserve(7 * n);
+        d_flag.reserve(n);
+        FLS_HIP(hipMemsetAsync(d_flag.p, 0, n, stream));  // std::fill(flags, false) once per Match (:156, Q1)
+        d_partials_b.reserve(size_t(nblk) * kPartialStride);
+        push_state(T);
+        const int iters = int(p.max_iterations);
+        if (profiling) ensure_events(iters);
+        const DevGrid g = image.dev();
+        for (int it = 0; it < iters; ++it) {
+            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
+            if (count_traffic)
+                hipLaunchKernelGGL(p2plane_ivox_kernel<true>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),
+                                   d_state.p, g, ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,
+                                   p.point_to_planar_thres, d_tc.p);
+            else
+                hipLaunchKernelGGL(p2plane_ivox_kernel<false>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),
+                                   d_state.p, g, ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,
+                                   p.point_to_planar_thres, d_tc.p);
+            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
+            hipLaunchKernelGGL(gn_solve_loam_kernel, dim3(1), dim3(1024), 0, stream, d_state.p, (const double*)nullptr, 0,
+                               (const double*)d_partials_b.p, nblk, p.rotation_converge_thres, p.position_converge_thres);
+        }
+        FLS_HIP(hipGetLastError());
+        pull_state(n);
+        const GnState& s = *h_state.p;
+        std::memcpy(T, s.T, sizeof(double) * 16);
+        std::memcpy(T_, s.T, sizeof(T_));
+        std::memcpy(final_T, s.T, sizeof(final_T));
+        have_final = true;
+        bool has_converge = true;
+        if (s.n_valid < 50) has_converge = false;  // :201-203
+        stats.iterations = s.iter;
+        stats.n_valid = s.n_valid;
+        stats.sum_res = s.sum_res;
+        std::memcpy(stats.last_dx, s.last_dx, sizeof(stats.last_dx));
+        stats.converged = has_converge ? 1 : 0;
+        fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
+        if (has_converge && !p.is_localization_mode && update_map) {  // :205-206
+            const fls_status arc = add_cloud_impl(scan.host);
+            if (arc != FLS_OK) rc = arc;
+            stats.map_updated = 1;
+        }
+        if (out) *out = stats;
+        return rc;
+    }
+
+    fls_status fitness(float max_range, float* score) override {
+        if (!p.is_localization_mode) { *score = std::numeric_limits<float>::max(); return FLS_OK; }  // FloatNaN :226-228
+        if (!have_fitness_grid || !have_final) return FLS_ERR_STATE;
+        return fitness_score_device(*this, fitness_grid, scan, final_T, max_range, score);
+    }
+
+    int correspondences(int, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) override {
+        download_nn();
+        const size_t n = std::min(cap, nn_n);
+        h_flag.resize(nn_n);
+        if (nn_n) {
+            FLS_HIP(hipMemcpyAsync(h_flag.data(), d_flag.p, nn_n, hipMemcpyDeviceToHost, stream));
+            FLS_HIP(hipStreamSynchronize(stream));
+        }
+        for (size_t i = 0; i < n; ++i) {
+            cnt[i] = h_cnt[i];
+            for (int j = 0; j < 5; ++j) ids[i * 5 + j] = j < h_cnt[i] ? h_nn[i * 5 + j].id : -1;
+            valid[i] = h_flag[i];
+        }
+        return int(n);
+    }
+    size_t map_size(int) const override { return ivox.n_points; }
+};
+
+}  // namespace fls

@@ -1,0 +1,371 @@
+// matchers_kd.hpp -- host side of the three kinds whose reference uses pcl::KdTreeFLANN:
+//   IcpMatcher       <- IcpOptimized<double>            include/registration/icp_optimized.h
+//   LoamFullMatcher  <- LoamFull<double>                include/registration/loam_full_kdtree.h
+//   P2PlaneKdMatcher <- LoamPointToPlaneKdtree<double>  include/registration/loam_point_to_plane_kdtree.h
+// Map bookkeeping (deque of clouds, VoxelGrid, rebuild) stays on the host like the reference's
+// AddCloudToLocalMap; the kd-tree is replaced by an exact-kNN hash grid rebuilt at the same moments.
+#pragma once
+#include "matcher_base.hpp"
+#include "host_math.hpp"
+#include "kernels_knn.hpp"
+#include "fitness_host.hpp"
+#include <deque>
+
+namespace fls {
+
+inline float cell_for_gate(double gate_sq) {  // smallest safe cell for a squared-distance gate
+    return float(std::sqrt(gate_sq) * 1.0001);
+}
+
+// ---------------------------------------------------------------------------------------------
+struct IcpMatcher final : fls_matcher {
+    std::deque<std::vector<PtI>> cloud_deque;
+    std::vector<PtI> local_map, source;
+    CellGridImage grid;
+    bool have_map = false;
+    DevScan scan;
+    size_t raw_n = 0;
+    hm::KeyframeGate gate;
+    double final_T[16]{};
+    bool have_final = false;
+    DevBuf<int> d_nn_id;
+    DevBuf<unsigned char> d_eff;
+
+    fls_status init() {
+        if (unset_f(p.map_cloud_filter_size) || unset_f(p.source_cloud_filter_size) || unset_d(p.point_search_thres) ||
+            unset_d(p.position_converge_thres) || unset_d(p.rotation_converge_thres) || unset_d(p.rot_thre_add_cloud) ||
+            unset_d(p.dist_thre_add_cloud) || p.local_map_size == 0x7fffffffu)
+            return FLS_ERR_INVALID;  // CHECK_NE block icp_optimized.h:33-41
+        if (!(p.point_search_thres > 0.0) || !(p.map_cloud_filter_size > 0.f) || !(p.source_cloud_filter_size > 0.f)) return FLS_ERR_INVALID;
+        init_common();
+        return FLS_OK;
+    }
+    fls_status add_cloud_impl(const std::vector<PtI>& new_cloud) {  // :165-189
+        if (p.is_localization_mode) {
+            local_map = new_cloud;
+        } else {
+            cloud_deque.push_back(new_cloud);
+            if (cloud_deque.size() > p.local_map_size) cloud_deque.pop_front();
+            local_map.clear();
+            for (const auto& c : cloud_deque) local_map.insert(local_map.end(), c.begin(), c.end());
+        }
+        local_map = voxel_grid(local_map, p.map_cloud_filter_size);  // Q13: always
+        const fls_status rc = grid.build(local_map, cell_for_gate(p.point_search_thres), stream);
+        have_map = rc == FLS_OK;
+        return rc;
+    }
+    fls_status add_cloud(const float* c0, size_t n0, const float* c1, size_t n1, int stride) override {
+        if (c1 != nullptr && n1 != 0) return FLS_ERR_INVALID;
+        return add_cloud_impl(cloud_from(c0, n0, stride));
+    }
+    fls_status scan_upload(const float* s0, size_t n0, const float*, size_t, int stride) override {
+        raw_n = n0;
+        source = voxel_grid(cloud_from(s0, n0, stride), p.source_cloud_filter_size);  // :57
+        scan.upload(source, stream);
+        return FLS_OK;
+    }
+    fls_status match_resident(double* T, int update_map, fls_stats* out) override {
+        if (raw_n <= 10) return FLS_ERR_INVALID;  // CHECK_GT(ordered_cloud_.size(), 10u) :55
+        if (!have_map) return FLS_ERR_STATE;
+        const size_t n = scan.n;
+        const int nblk = int((n + 63) / 64);
+        stats = fls_stats{};
+        stats.n_source = int(n);
+        d_nn_id.reserve(n);
+        d_eff.reserve(n);
+        d_partials_b.reserve(size_t(nblk) * kPartialStride);
+        push_state(T);
+        const int iters = int(p.max_iterations);
+        if (profiling) ensure_events(iters);
+        const CellGridDev cg = cell_dev(grid);
+        for (int it = 0; it < iters; ++it) {
+            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
+            if (count_traffic)
+                hipLaunchKernelGGL(icp_p2p_kernel<true>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, cg,
+                                   p.point_search_thres, d_nn_id.p, d_eff.p, d_partials_b.p, d_tc.p);
+            else
+                hipLaunchKernelGGL(icp_p2p_kernel<false>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, cg,
+                                   p.point_search_thres, d_nn_id.p, d_eff.p, d_partials_b.p, d_tc.p);
+            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
+            hipLaunchKernelGGL(gn_solve_lu_kernel, dim3(1), dim3(1024), 0, stream, d_state.p, (const double*)d_partials_b.p, nblk, 0,
+                               p.rotation_converge_thres, p.position_converge_thres, 0);
+        }
+        FLS_HIP(hipGetLastError());
+        pull_state(n);
+        const GnState& s = *h_state.p;
+        std::memcpy(T, s.T, sizeof(double) * 16);
+        std::memcpy(final_T, s.T, sizeof(final_T));
+        have_final = true;
+        const bool has_converge = s.converged != 0;  // Q10: false after max iterations
+        stats.iterations = s.iter;
+        stats.n_valid = s.n_valid;
+        stats.sum_res = s.sum_res;
+        std::memcpy(stats.last_dx, s.last_dx, sizeof(stats.last_dx));
+        stats.converged = has_converge ? 1 : 0;
+        fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
+        if (has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode && update_map) {  // :154-157
+            const fls_status arc = add_cloud_impl(hm::xform_cloud_f(source, final_T));
+            if (arc != FLS_OK) rc = arc;
+            stats.map_updated = 1;
+        }
+        if (out) *out = stats;
+        return rc;
+    }
+    fls_status fitness(float max_range, float* score) override {
+        if (!have_map || !have_final) return FLS_ERR_STATE;
+        return fitness_score_device(*this, grid, scan, final_T, max_range, score);
+    }
+    int correspondences(int, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) override {
+        const size_t n = std::min(cap, scan.n);
+        if (!n) return 0;
+        std::vector<int> id(n);
+        std::vector<unsigned char> ef(n);
+        FLS_HIP(hipMemcpyAsync(id.data(), d_nn_id.p, n * sizeof(int), hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipMemcpyAsync(ef.data(), d_eff.p, n, hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipStreamSynchronize(stream));
+        for (size_t i = 0; i < n; ++i) { ids[i] = id[i]; cnt[i] = id[i] >= 0 ? 1 : 0; valid[i] = ef[i]; }
+        return int(n);
+    }
+    size_t map_size(int) const override { return local_map.size(); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// per-feature-class device buffers of the LOAM kinds
+struct FeatureDev {
+    DevScan scan;
+    DevBuf<int> nn_id;
+    DevBuf<unsigned char> nn_cnt, flag;
+    DevBuf<double> J;
+    void prepare(hipStream_t s) {
+        const size_t n = std::max<size_t>(scan.n, 1);
+        nn_id.reserve(n * 5); nn_cnt.reserve(n); flag.reserve(n); J.reserve(7 * n);
+        FLS_HIP(hipMemsetAsync(flag.p, 0, n, s));  // flags cleared once per Match (Q1)
+    }
+    int fetch(hipStream_t s, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) {
+        const size_t n = std::min(cap, scan.n);
+        if (!n) return 0;
+        FLS_HIP(hipMemcpyAsync(ids, nn_id.p, n * 5 * sizeof(int), hipMemcpyDeviceToHost, s));
+        FLS_HIP(hipMemcpyAsync(cnt, nn_cnt.p, n, hipMemcpyDeviceToHost, s));
+        FLS_HIP(hipMemcpyAsync(valid, flag.p, n, hipMemcpyDeviceToHost, s));
+        FLS_HIP(hipStreamSynchronize(s));
+        return int(n);
+    }
+};
+
+struct LoamFullMatcher final : fls_matcher {
+    std::deque<std::vector<PtI>> corner_deque, planar_deque;
+    std::vector<PtI> local_corner, local_planar;
+    CellGridImage corner_grid, planar_grid;
+    bool have_map = false;
+    FeatureDev corner, planar;
+    hm::KeyframeGate gate;
+
+    fls_status init() {
+        if (unset_d(p.point_to_planar_thres) || unset_d(p.point_search_thres) || unset_d(p.line_ratio_thres) ||
+            unset_d(p.position_converge_thres) || unset_d(p.rotation_converge_thres) || unset_d(p.rot_thre_add_cloud) ||
+            unset_d(p.dist_thre_add_cloud))
+            return FLS_ERR_INVALID;  // CHECK_NE block loam_full_kdtree.h:44-53
+        if (p.local_planar_size == 0 || p.local_corner_size == 0) return FLS_ERR_INVALID;  // CHECK_GT :55-56
+        if (!(p.point_search_thres > 0.0) || !(p.corner_voxel_filter_size > 0.f) || !(p.planar_voxel_filter_size > 0.f)) return FLS_ERR_INVALID;
+        init_common();
+        return FLS_OK;
+    }
+    fls_status add_cloud_impl(const std::vector<PtI>& planar_cloud, const std::vector<PtI>& corner_cloud) {  // :65-104
+        corner_deque.push_back(corner_cloud);
+        planar_deque.push_back(planar_cloud);
+        if (planar_deque.size() > p.local_planar_size) planar_deque.pop_front();
+        if (corner_deque.size() > p.local_corner_size) corner_deque.pop_front();
+        local_planar.clear();
+        local_corner.clear();
+        for (const auto& c : planar_deque) local_planar.insert(local_planar.end(), c.begin(), c.end());
+        for (const auto& c : corner_deque) local_corner.insert(local_corner.end(), c.begin(), c.end());
+        if (planar_deque.size() > 5) local_planar = voxel_grid(local_planar, p.planar_voxel_filter_size);
+        if (corner_deque.size() > 5) local_corner = voxel_grid(local_corner, p.corner_voxel_filter_size);
+        const float cs = cell_for_gate(p.point_search_thres);
+        fls_status rc = planar_grid.build(local_planar, cs, stream);
+        if (rc != FLS_OK) return rc;
+        rc = corner_grid.build(local_corner, cs, stream);
+        have_map = rc == FLS_OK;
+        return rc;
+    }
+    fls_status add_cloud(const float* c0, size_t n0, const float* c1, size_t n1, int stride) override {
+        if (c1 == nullptr && n1 != 0) return FLS_ERR_INVALID;  // CHECK_EQ(cloud_list.size(), 2) :66
+        return add_cloud_impl(cloud_from(c0, n0, stride), c1 ? cloud_from(c1, n1, stride) : std::vector<PtI>());
+    }
+    fls_status scan_upload(const float* s0, size_t n0, const float* s1, size_t n1, int stride) override {
+        planar.scan.upload(cloud_from(s0, n0, stride), stream);
+        corner.scan.upload(s1 ? cloud_from(s1, n1, stride) : std::vector<PtI>(), stream);
+        return FLS_OK;
+    }
+    fls_status match_resident(double* T, int update_map, fls_stats* out) override {
+        if (!have_map) return FLS_ERR_STATE;
+        const size_t np = planar.scan.n, nc = corner.scan.n;
+        const int nbp = int((np + 63) / 64), nbc = int((nc + 63) / 64);
+        stats = fls_stats{};
+        stats.n_source = int(np);
+        stats.n_source_corner = int(nc);
+        planar.prepare(stream);
+        corner.prepare(stream);
+        d_partials_a.reserve(size_t(std::max(nbc, 1)) * kPartialStride);
+        d_partials_b.reserve(size_t(std::max(nbp, 1)) * kPartialStride);
+        push_state(T);
+        const int iters = int(p.max_iterations);
+        if (profiling) ensure_events(iters);
+        const CellGridDev cgp = cell_dev(planar_grid), cgc = cell_dev(corner_grid);
+        const float gate_f = float(p.point_search_thres);
+        for (int it = 0; it < iters; ++it) {
+            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
+            if (nbc > 0) {
+                if (count_traffic)
+                    hipLaunchKernelGGL(corner_knn_kernel<true>, dim3(nbc), dim3(64), 0, stream, corner.scan.x.p, corner.scan.y.p, corner.scan.z.p,
+                                       int(nc), d_state.p, cgc, gate_f, p.line_ratio_thres, corner.nn_id.p, corner.nn_cnt.p, corner.J.p,
+                                       corner.flag.p, d_partials_a.p, d_tc.p);
+                else
+                    hipLaunchKernelGGL(corner_knn_kernel<false>, dim3(nbc), dim3(64), 0, stream, corner.scan.x.p, corner.scan.y.p, corner.scan.z.p,
+                                       int(nc), d_state.p, cgc, gate_f, p.line_ratio_thres, corner.nn_id.p, corner.nn_cnt.p, corner.J.p,
+                                       corner.flag.p, d_partials_a.p, d_tc.p);
+            }
+            if (nbp > 0) {
+                if (count_traffic)
+                    hipLaunchKernelGGL(plane_knn_kernel<true>, dim3(nbp), dim3(64), 0, stream, planar.scan.x.p, planar.scan.y.p, planar.scan.z.p,
+                                       int(np), d_state.p, cgp, gate_f, p.point_to_planar_thres, planar.nn_id.p, planar.nn_cnt.p, planar.J.p,
+                                       planar.flag.p, d_partials_b.p, d_tc.p);
+                else
+                    hipLaunchKernelGGL(plane_knn_kernel<false>, dim3(nbp), dim3(64), 0, stream, planar.scan.x.p, planar.scan.y.p, planar.scan.z.p,
+                                       int(np), d_state.p, cgp, gate_f, p.point_to_planar_thres, planar.nn_id.p, planar.nn_cnt.p, planar.J.p,
+                                       planar.flag.p, d_partials_b.p, d_tc.p);
+            }
+            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
+            hipLaunchKernelGGL(gn_solve_loam_kernel, dim3(1), dim3(1024), 0, stream, d_state.p, (const double*)d_partials_a.p, nbc,
+                               (const double*)d_partials_b.p, nbp, p.rotation_converge_thres, p.position_converge_thres);
+        }
+        FLS_HIP(hipGetLastError());
+        pull_state(np + nc);
+        const GnState& s = *h_state.p;
+        std::memcpy(T, s.T, sizeof(double) * 16);
+        bool has_converge = true;
+        if (s.n_valid < 50) has_converge = false;  // number_valid_planar_ < 50 :181
+        stats.iterations = s.iter;
+        stats.n_valid = s.n_valid;
+        stats.n_valid_corner = s.n_valid2;
+        stats.sum_res = s.sum_res;
+        stats.sum_res_corner = s.sum_res2;
+        std::memcpy(stats.last_dx, s.last_dx, sizeof(stats.last_dx));
+        stats.converged = has_converge ? 1 : 0;
+        fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
+        if (has_converge && gate.need(s.T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && update_map) {  // :185-193 (no localization switch)
+            const fls_status arc = add_cloud_impl(hm::xform_cloud_d(planar.scan.host, s.T), hm::xform_cloud_d(corner.scan.host, s.T));
+            if (arc != FLS_OK) rc = arc;
+            stats.map_updated = 1;
+        }
+        if (out) *out = stats;
+        return rc;
+    }
+    fls_status fitness(float, float* score) override { *score = std::numeric_limits<float>::max(); return FLS_OK; }  // FloatNaN :206-208
+    int correspondences(int slot, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) override {
+        return (slot == 1 ? corner : planar).fetch(stream, ids, cnt, valid, cap);
+    }
+    size_t map_size(int slot) const override { return slot == 1 ? local_corner.size() : local_planar.size(); }
+};
+
+// ---------------------------------------------------------------------------------------------
+struct P2PlaneKdMatcher final : fls_matcher {
+    std::deque<std::vector<PtI>> cloud_deque;
+    std::vector<PtI> local_map;
+    CellGridImage grid;
+    bool have_map = false;
+    FeatureDev planar;
+    hm::KeyframeGate gate;
+    double final_T[16]{};
+    bool have_final = false;
+
+    fls_status init() {
+        if (unset_d(p.point_to_planar_thres) || unset_d(p.position_converge_thres) || unset_d(p.rotation_converge_thres) ||
+            unset_d(p.rot_thre_add_cloud) || unset_d(p.dist_thre_add_cloud) || unset_f(p.map_cloud_filter_size))
+            return FLS_ERR_INVALID;  // CHECK_NE block loam_point_to_plane_kdtree.h:43-50
+        if (!(p.map_cloud_filter_size > 0.f)) return FLS_ERR_INVALID;
+        init_common();
+        return FLS_OK;
+    }
+    fls_status add_cloud_impl(const std::vector<PtI>& planar_cloud) {  // :56-79
+        if (p.is_localization_mode) {
+            local_map = planar_cloud;
+        } else {
+            cloud_deque.push_back(planar_cloud);
+            if (cloud_deque.size() > p.local_map_size) cloud_deque.pop_front();
+            local_map.clear();
+            for (const auto& c : cloud_deque) local_map.insert(local_map.end(), c.begin(), c.end());
+        }
+        local_map = voxel_grid(local_map, p.map_cloud_filter_size);
+        // un-gated 5-NN: ring search with a cell of two map leaves (>= 1 point per leaf after VoxelGrid)
+        const fls_status rc = grid.build(local_map, std::max(2.0f * p.map_cloud_filter_size, 0.5f), stream);
+        have_map = rc == FLS_OK;
+        return rc;
+    }
+    fls_status add_cloud(const float* c0, size_t n0, const float* c1, size_t n1, int stride) override {
+        if (c1 != nullptr && n1 != 0) return FLS_ERR_INVALID;
+        return add_cloud_impl(cloud_from(c0, n0, stride));
+    }
+    fls_status scan_upload(const float* s0, size_t n0, const float*, size_t, int stride) override {
+        planar.scan.upload(cloud_from(s0, n0, stride), stream);
+        return FLS_OK;
+    }
+    fls_status match_resident(double* T, int update_map, fls_stats* out) override {
+        if (!have_map) return FLS_ERR_STATE;
+        const size_t n = planar.scan.n;
+        const int nblk = int((n + 63) / 64);
+        stats = fls_stats{};
+        stats.n_source = int(n);
+        planar.prepare(stream);
+        d_partials_b.reserve(size_t(std::max(nblk, 1)) * kPartialStride);
+        push_state(T);
+        const int iters = int(p.max_iterations);
+        if (profiling) ensure_events(iters);
+        const CellGridDev cg = cell_dev(grid);
+        for (int it = 0; it < iters; ++it) {
+            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
+            if (nblk > 0) {
+                if (count_traffic)
+                    hipLaunchKernelGGL(plane_knn_kernel<true>, dim3(nblk), dim3(64), 0, stream, planar.scan.x.p, planar.scan.y.p, planar.scan.z.p,
+                                       int(n), d_state.p, cg, INFINITY, p.point_to_planar_thres, planar.nn_id.p, planar.nn_cnt.p, planar.J.p,
+                                       planar.flag.p, d_partials_b.p, d_tc.p);
+                else
+                    hipLaunchKernelGGL(plane_knn_kernel<false>, dim3(nblk), dim3(64), 0, stream, planar.scan.x.p, planar.scan.y.p, planar.scan.z.p,
+                                       int(n), d_state.p, cg, INFINITY, p.point_to_planar_thres, planar.nn_id.p, planar.nn_cnt.p, planar.J.p,
+                                       planar.flag.p, d_partials_b.p, d_tc.p);
+            }
+            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
+            hipLaunchKernelGGL(gn_solve_loam_kernel, dim3(1), dim3(1024), 0, stream, d_state.p, (const double*)nullptr, 0,
+                               (const double*)d_partials_b.p, nblk, p.rotation_converge_thres, p.position_converge_thres);
+        }
+        FLS_HIP(hipGetLastError());
+        pull_state(n);
+        const GnState& s = *h_state.p;
+        std::memcpy(T, s.T, sizeof(double) * 16);
+        std::memcpy(final_T, s.T, sizeof(final_T));
+        have_final = true;
+        bool has_converge = true;
+        if (s.n_valid < 50) has_converge = false;
+        stats.iterations = s.iter;
+        stats.n_valid = s.n_valid;
+        stats.sum_res = s.sum_res;
+        std::memcpy(stats.last_dx, s.last_dx, sizeof(stats.last_dx));
+        stats.converged = has_converge ? 1 : 0;
+        fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
+        if (has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode && update_map) {  // :145-149
+            const fls_status arc = add_cloud_impl(hm::xform_cloud_f(planar.scan.host, final_T));
+            if (arc != FLS_OK) rc = arc;
+            stats.map_updated = 1;
+        }
+        if (out) *out = stats;
+        return rc;
+    }
+    fls_status fitness(float max_range, float* score) override {
+        if (!have_map || !have_final) return FLS_ERR_STATE;
+        return fitness_score_device(*this, grid, planar.scan, final_T, max_range, score);
+    }
+    int correspondences(int, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) override { return planar.fetch(stream, ids, cnt, valid, cap); }
+    size_t map_size(int) const override { return local_map.size(); }
+};
+
+}  // namespace fls

@@ -1,0 +1,297 @@
+"""Python mirror of the reference's registration plug-in interface, backed by libfls_reg.so.
+
+The production integration is C++ (include/fls_hip_registration.h implements the
+reference's ``RegistrationInterface`` on top of the same C ABI); this module gives the
+tests and bench.py the same surface with the reference's class names, constructor
+argument order and semantics:
+
+    RegistrationInterface            include/registration/registration_interface.h:11-20
+      Match(cluster, T) -> bool      (T is in/out: a (4,4) float64 numpy array, world <- body)
+      AddCloudToLocalMap([clouds])
+      GetFitnessScore(max_range)
+    PointcloudCluster                include/lidar/pointcloud_cluster.h:13-85 (the three clouds Match reads)
+
+Clouds are (n,3|4|8) float32 arrays (xyz[i][pad], the 8-wide form is pcl::PointXYZI's memory).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import FlsError, Params, Stats
+
+FloatNaN = float(np.finfo(np.float32).max)  # include/common/constant_variable.h:11
+
+# mode strings added next to include/common/constant_variable.h:21-25 by the integration
+kPointToPlane_IVOX_HIP = "PointToPlane_IVOX_HIP"
+kPointToPlane_KdTree_HIP = "PointToPlane_KdTree_HIP"
+kLoamFull_KdTree_HIP = "LoamFull_KdTree_HIP"
+kIcpOptimized_HIP = "IcpOptimized_HIP"
+kIncrementalNDT_HIP = "IncrementalNDT_HIP"
+
+
+@dataclass
+class PointcloudCluster:
+    ordered_cloud_: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    planar_cloud_: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    corner_cloud_: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+
+
+def _cloud(c):
+    if c is None:
+        return None, None, 0, 3
+    a = np.ascontiguousarray(c, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] < 3:
+        raise ValueError("cloud must be (n, >=3) float32")
+    return a, a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0], a.shape[1]
+
+
+class RegistrationInterface:
+    """Base: owns one fls_handle.  Not thread-safe (one owner thread, like the reference)."""
+
+    KIND = None
+    K = 5
+
+    def __init__(self, params: Params, device_id: int = 0):
+        self.params = params
+        self.stats = Stats()
+        self._h = C.c_void_p()
+        rc = _lib.lib().fls_create(self.KIND, C.byref(params), device_id, C.byref(self._h))
+        if rc != _lib.FLS_OK:
+            self._h = C.c_void_p()
+            raise FlsError(rc, f"fls_create(kind={self.KIND})")
+
+    # -- the three virtuals -------------------------------------------------------------------
+    def AddCloudToLocalMap(self, cloud_list) -> None:
+        clouds = list(cloud_list)
+        a0, p0, n0, s0 = _cloud(clouds[0])
+        a1, p1, n1, s1 = _cloud(clouds[1]) if len(clouds) > 1 else (None, None, 0, s0)
+        if a1 is not None and s1 != s0:
+            raise ValueError("clouds must share a stride")
+        rc = _lib.lib().fls_add_cloud_to_local_map(self._h, p0, n0, p1, n1, s0)
+        if rc != _lib.FLS_OK:
+            raise FlsError(rc, "fls_add_cloud_to_local_map")
+
+    def _sources(self, cluster: PointcloudCluster):
+        return cluster.planar_cloud_, None
+
+    def Match(self, cluster: PointcloudCluster, T: np.ndarray, update_map: bool = True) -> bool:
+        s0, s1 = self._sources(cluster)
+        a0, p0, n0, st0 = _cloud(s0)
+        a1, p1, n1, st1 = _cloud(s1)
+        if a1 is not None and st1 != st0:
+            raise ValueError("clouds must share a stride")
+        Tf = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4).T).reshape(-1)  # column-major
+        rc = _lib.lib().fls_match(self._h, p0, n0, p1, n1, st0, Tf.ctypes.data_as(C.POINTER(C.c_double)),
+                                  1 if update_map else 0, C.byref(self.stats))
+        if rc < 0:
+            raise FlsError(rc, "fls_match")
+        T[...] = Tf.reshape(4, 4).T
+        return rc == _lib.FLS_OK
+
+    def GetFitnessScore(self, max_range: float) -> float:
+        out = C.c_float()
+        rc = _lib.lib().fls_get_fitness_score(self._h, max_range, C.byref(out))
+        if rc != _lib.FLS_OK:
+            raise FlsError(rc, "fls_get_fitness_score")
+        return float(out.value)
+
+    # -- resident-scan variant (benchmarks) -------------------------------------------------------
+    def UploadScan(self, cluster: PointcloudCluster) -> None:
+        s0, s1 = self._sources(cluster)
+        a0, p0, n0, st0 = _cloud(s0)
+        a1, p1, n1, st1 = _cloud(s1)
+        rc = _lib.lib().fls_scan_upload(self._h, p0, n0, p1, n1, st0)
+        if rc != _lib.FLS_OK:
+            raise FlsError(rc, "fls_scan_upload")
+
+    def MatchResident(self, T: np.ndarray, update_map: bool = False) -> bool:
+        Tf = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4).T).reshape(-1)
+        rc = _lib.lib().fls_match_resident(self._h, Tf.ctypes.data_as(C.POINTER(C.c_double)), 1 if update_map else 0,
+                                           C.byref(self.stats))
+        if rc < 0:
+            raise FlsError(rc, "fls_match_resident")
+        T[...] = Tf.reshape(4, 4).T
+        return rc == _lib.FLS_OK
+
+    # -- introspection --------------------------------------------------------------------------
+    def iteration_log(self, cap: int = 64):
+        T = np.zeros((cap, 16)); nv = np.zeros(cap, np.int32); sr = np.zeros(cap)
+        n = _lib.lib().fls_get_iteration_log(self._h, T.ctypes.data_as(C.POINTER(C.c_double)),
+                                             nv.ctypes.data_as(C.POINTER(C.c_int32)), sr.ctypes.data_as(C.POINTER(C.c_double)), cap)
+        n = min(n, cap)
+        Ts = np.stack([T[i].reshape(4, 4).T for i in range(n)]) if n else np.zeros((0, 4, 4))
+        return Ts, nv[:n].copy(), sr[:n].copy()
+
+    def correspondences(self, slot: int = 0):
+        n = self.stats.n_source_corner if slot == 1 else self.stats.n_source
+        ids = np.full((n, self.K), -1, np.int32); cnt = np.zeros(n, np.uint8); valid = np.zeros(n, np.uint8)
+        if n:
+            m = _lib.lib().fls_get_correspondences(self._h, slot, ids.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                   cnt.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                   valid.ctypes.data_as(C.POINTER(C.c_uint8)), n)
+            if m < 0:
+                raise FlsError(_lib.FLS_ERR_DEVICE, "fls_get_correspondences")
+        return ids, cnt, valid
+
+    def map_size(self, slot: int = 0) -> int:
+        return int(_lib.lib().fls_map_size(self._h, slot))
+
+    def set_profiling(self, events: bool, counters: bool = False) -> None:
+        _lib.lib().fls_set_profiling(self._h, (1 if events else 0) | (2 if counters else 0))
+
+    def kernel_time(self):
+        ms = C.c_double(); n = C.c_int64(); pi = C.c_uint64()
+        _lib.lib().fls_get_kernel_time(self._h, C.byref(ms), C.byref(n), C.byref(pi))
+        return ms.value, n.value, pi.value
+
+    def traffic_counters(self):
+        a = C.c_uint64(); b = C.c_uint64(); c = C.c_uint64()
+        _lib.lib().fls_get_traffic_counters(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().fls_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LoamPointToPlaneIVOX(RegistrationInterface):
+    """loam_point_to_plane_ivox.h:37-51 ctor argument order."""
+
+    KIND = _lib.P2PLANE_IVOX
+
+    def __init__(self, point_to_planar_thres, position_converge_thres, rotation_converge_thres, opti_iter_num=30,
+                 is_localization_mode=False, device_id=0):
+        super().__init__(Params(point_to_planar_thres=point_to_planar_thres, position_converge_thres=position_converge_thres,
+                                rotation_converge_thres=rotation_converge_thres, max_iterations=opti_iter_num,
+                                is_localization_mode=int(is_localization_mode)), device_id)
+
+
+class IcpOptimized(RegistrationInterface):
+    """icp_optimized.h:23-32 ctor argument order."""
+
+    KIND = _lib.ICP_OPTIMIZED
+    K = 1
+
+    def __init__(self, max_iterations, local_map_size, map_cloud_filter_size, source_cloud_filter_size, max_correspond_distance,
+                 position_converge_thres, rotation_converge_thres, rot_thre_add_cloud, dist_thre_add_cloud,
+                 is_localization_mode=False, device_id=0):
+        super().__init__(Params(max_iterations=max_iterations, local_map_size=local_map_size,
+                                map_cloud_filter_size=map_cloud_filter_size, source_cloud_filter_size=source_cloud_filter_size,
+                                point_search_thres=max_correspond_distance, position_converge_thres=position_converge_thres,
+                                rotation_converge_thres=rotation_converge_thres, rot_thre_add_cloud=rot_thre_add_cloud,
+                                dist_thre_add_cloud=dist_thre_add_cloud, is_localization_mode=int(is_localization_mode)), device_id)
+
+    def _sources(self, cluster):
+        return cluster.ordered_cloud_, None
+
+
+class IncrementalNDT(RegistrationInterface):
+    """incremental_ndt.h:22-26 ctor argument order."""
+
+    KIND = _lib.INCREMENTAL_NDT
+    K = 7
+
+    def __init__(self, voxel_size, res_outlier_threshold, source_cloud_filter_size, rotation_converge_thres, position_converge_thres,
+                 min_points_in_voxel, max_points_in_voxel, min_effective_pts, capacity, max_iteration, is_localization_mode=False,
+                 device_id=0):
+        super().__init__(Params(ndt_voxel_size=voxel_size, ndt_res_outlier_threshold=res_outlier_threshold,
+                                source_cloud_filter_size=source_cloud_filter_size, rotation_converge_thres=rotation_converge_thres,
+                                position_converge_thres=position_converge_thres, ndt_min_points_in_voxel=min_points_in_voxel,
+                                ndt_max_points_in_voxel=max_points_in_voxel, ndt_min_effective_pts=min_effective_pts,
+                                ndt_capacity=capacity, max_iterations=max_iteration, is_localization_mode=int(is_localization_mode)),
+                         device_id)
+
+    def _sources(self, cluster):
+        return cluster.ordered_cloud_, None
+
+
+class LoamFull(RegistrationInterface):
+    """loam_full_kdtree.h:31-36 ctor argument order.  AddCloudToLocalMap([planar, corner])."""
+
+    KIND = _lib.LOAM_FULL
+
+    def __init__(self, point_to_planar_thres, point_search_thres, line_ratio_thres, position_converge_thres, rotation_converge_thres,
+                 dist_thre_add_cloud, rot_thre_add_cloud, local_corner_size, local_planar_size, corner_voxel_filter_size,
+                 planar_voxel_filter_size, max_iteration, device_id=0):
+        super().__init__(Params(point_to_planar_thres=point_to_planar_thres, point_search_thres=point_search_thres,
+                                line_ratio_thres=line_ratio_thres, position_converge_thres=position_converge_thres,
+                                rotation_converge_thres=rotation_converge_thres, dist_thre_add_cloud=dist_thre_add_cloud,
+                                rot_thre_add_cloud=rot_thre_add_cloud, local_corner_size=local_corner_size,
+                                local_planar_size=local_planar_size, corner_voxel_filter_size=corner_voxel_filter_size,
+                                planar_voxel_filter_size=planar_voxel_filter_size, max_iterations=max_iteration), device_id)
+
+    def _sources(self, cluster):
+        return cluster.planar_cloud_, cluster.corner_cloud_
+
+
+class LoamPointToPlaneKdtree(RegistrationInterface):
+    """loam_point_to_plane_kdtree.h:32-42 ctor argument order."""
+
+    KIND = _lib.P2PLANE_KDTREE
+
+    def __init__(self, point_to_planar_thres, position_converge_thres, rotation_converge_thres, rot_thre_add_cloud,
+                 dist_thre_add_cloud, local_map_size, map_cloud_filter_size, opti_iter_num=30, is_localization_mode=False,
+                 device_id=0):
+        super().__init__(Params(point_to_planar_thres=point_to_planar_thres, position_converge_thres=position_converge_thres,
+                                rotation_converge_thres=rotation_converge_thres, rot_thre_add_cloud=rot_thre_add_cloud,
+                                dist_thre_add_cloud=dist_thre_add_cloud, local_map_size=local_map_size,
+                                map_cloud_filter_size=map_cloud_filter_size, max_iterations=opti_iter_num,
+                                is_localization_mode=int(is_localization_mode)), device_id)
+
+
+def make_matcher(mode: str, cfg: dict, is_localization_mode: bool = False, device_id: int = 0) -> RegistrationInterface:
+    """FrontEnd::InitMatcher / Localization::InitMatcher (src/slam/frontend.cpp:30-88, localization.cpp:43-92):
+    choose the implementation from the YAML mode string, arguments from the `registration` YAML block."""
+    r = cfg
+    if mode in ("PointToPlane_IVOX", kPointToPlane_IVOX_HIP):
+        return LoamPointToPlaneIVOX(r["point_to_planar_thres"], r["position_converge_thres"], r["rotation_converge_thres"],
+                                    r["optimization_iter_num"], is_localization_mode, device_id)
+    if mode in ("IcpOptimized", kIcpOptimized_HIP):
+        return IcpOptimized(r["optimization_iter_num"], r["local_map_size"], r["local_map_cloud_filter_size"],
+                            r["source_cloud_filter_size"], r["point_search_thres"], r["position_converge_thres"],
+                            r["rotation_converge_thres"], r["keyframe_delta_rotation"], r["keyframe_delta_distance"],
+                            is_localization_mode, device_id)
+    if mode in ("IncrementalNDT", kIncrementalNDT_HIP):
+        return IncrementalNDT(r["ndt_voxel_size"], r["ndt_outlier_threshold"], r["source_cloud_filter_size"],
+                              r["rotation_converge_thres"], r["position_converge_thres"], r["ndt_min_points_in_voxel"],
+                              r["ndt_max_points_in_voxel"], r["ndt_min_effective_pts"], r["ndt_capacity"], r["optimization_iter_num"],
+                              is_localization_mode, device_id)
+    if mode in ("LoamFull_KdTree", kLoamFull_KdTree_HIP):
+        return LoamFull(r["point_to_planar_thres"], r["point_search_thres"], r["line_ratio_thres"], r["position_converge_thres"],
+                        r["rotation_converge_thres"], r["keyframe_delta_distance"], r["keyframe_delta_rotation"],
+                        r["local_corner_map_size"], r["local_planar_map_size"], r["local_corner_voxel_filter_size"],
+                        r["local_planar_voxel_filter_size"], r["optimization_iter_num"], device_id)
+    if mode in ("PointToPlane_KdTree", kPointToPlane_KdTree_HIP):
+        return LoamPointToPlaneKdtree(r["point_to_planar_thres"], r["position_converge_thres"], r["rotation_converge_thres"],
+                                      r["keyframe_delta_rotation"], r["keyframe_delta_distance"], r["local_map_size"],
+                                      r["local_map_cloud_filter_size"], r["optimization_iter_num"], is_localization_mode, device_id)
+    raise ValueError(f"Unsupported registration type {mode!r}")
+
+
+# the reference's YAML `registration:` blocks
+YAML_NCLT_IVOX = dict(optimization_iter_num=10, point_to_planar_thres=0.1, position_converge_thres=0.005,
+                      rotation_converge_thres=0.001)  # config/mapping/config_nclt.yaml:43-47
+YAML_NCLT_ICP = dict(local_map_size=50, point_search_thres=1.0, optimization_iter_num=30, local_map_cloud_filter_size=0.4,
+                     source_cloud_filter_size=0.4, position_converge_thres=0.005, rotation_converge_thres=0.005,
+                     keyframe_delta_distance=1.0, keyframe_delta_rotation=0.2)  # config_nclt_icp.yaml:41-50
+YAML_NCLT_NDT = dict(ndt_voxel_size=1.0, ndt_outlier_threshold=5.0, source_cloud_filter_size=0.2, optimization_iter_num=30,
+                     ndt_min_points_in_voxel=5, ndt_max_points_in_voxel=50, ndt_min_effective_pts=50, ndt_capacity=100000,
+                     position_converge_thres=0.005, rotation_converge_thres=0.005)  # config_nclt_ndt.yaml:41-51
+YAML_NCLT_LOAM_FULL = dict(optimization_iter_num=30, local_corner_map_size=50, local_planar_map_size=40, point_search_thres=1.0,
+                           line_ratio_thres=3.0, point_to_planar_thres=0.2, position_converge_thres=0.01,
+                           rotation_converge_thres=0.05, keyframe_delta_distance=1.0, keyframe_delta_rotation=0.2,
+                           local_corner_voxel_filter_size=0.2, local_planar_voxel_filter_size=0.4)  # config_nclt_loam_full.yaml:47-58
+YAML_NCLT_LOC_KDTREE = dict(optimization_iter_num=8, point_to_planar_thres=0.1, position_converge_thres=0.005,
+                            rotation_converge_thres=0.005, local_map_size=0, local_map_cloud_filter_size=0.5,
+                            keyframe_delta_distance=0.0, keyframe_delta_rotation=0.0)  # config/localization/config_nclt.yaml:40-50

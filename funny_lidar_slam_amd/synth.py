@@ -98,7 +98,7 @@ def _ray_dirs(rings: np.ndarray, az: np.ndarray, elev0_deg: float, elev_step_deg
 
 
 def cast_scan(scene: dict, T_gt: np.ndarray, n_rings: int, n_az: int, elev0_deg: float, elev_step_deg: float,
-              rng: np.random.Generator, range_noise: float = 0.02) -> np.ndarray:
+              rng: np.random.Generator, range_noise: float = 0.02, max_range: float = MAX_RANGE) -> np.ndarray:
     """Body-frame scan with exactly n_rings * n_az points (misses are re-cast with jitter)."""
     R, t = T_gt[:3, :3], T_gt[:3, 3]
     o_body = np.array([0.0, 0.0, SENSOR_Z])
@@ -111,7 +111,7 @@ def cast_scan(scene: dict, T_gt: np.ndarray, n_rings: int, n_az: int, elev0_deg:
     for attempt in range(64):
         d_body = _ray_dirs(ring[todo], az[todo], elev0_deg, elev_step_deg)
         r = _ray_cast(scene, o_world, d_body @ R.T)
-        ok = np.isfinite(r) & (r >= MIN_RANGE) & (r <= MAX_RANGE)
+        ok = np.isfinite(r) & (r >= MIN_RANGE) & (r <= max_range)
         rr = r[ok] + rng.normal(0.0, range_noise, ok.sum())
         pts[todo[ok]] = o_body[None, :] + rr[:, None] * d_body[ok]
         todo = todo[~ok]
@@ -145,7 +145,17 @@ def sample_map(scene: dict, n: int, rng: np.random.Generator, noise: float = 0.0
     boxes = scene["boxes"]
     foot = ((boxes[:, 3] - boxes[:, 0]) * (boxes[:, 4] - boxes[:, 1])).sum()
     ground_area = np.pi * radius * radius - foot
-    total = areas.sum() + ground_area
+    if radius < MAX_RANGE:
+        # wall area inside the radius (coarse estimate from rectangle centres) and footprints inside it
+        cen = np.stack([r[0] + 0.5 * r[1] for r in rects])
+        inside = np.hypot(cen[:, 0], cen[:, 1]) <= radius
+        wall_area = float(areas[inside].sum())
+        bc = 0.5 * (boxes[:, 0:2] + boxes[:, 3:5])
+        foot_in = ((boxes[:, 3] - boxes[:, 0]) * (boxes[:, 4] - boxes[:, 1]))[np.hypot(bc[:, 0], bc[:, 1]) <= radius].sum()
+        ground_area = np.pi * radius * radius - foot_in
+    else:
+        wall_area = float(areas.sum())
+    total = wall_area + ground_area
     n_ground = int(round(n * ground_area / total))
     n_wall = n - n_ground
     out = np.zeros((n, 3))
@@ -165,14 +175,21 @@ def sample_map(scene: dict, n: int, rng: np.random.Generator, noise: float = 0.0
         out[filled:filled + k, 1] = y[:k]
         out[filled:filled + k, 2] = rng.normal(0.0, noise, k)
         filled += k
-    # walls
-    which = rng.choice(len(rects), size=n_wall, p=areas / areas.sum())
-    a = rng.uniform(0, 1, n_wall)
-    b_ = rng.uniform(0, 1, n_wall)
-    off = rng.normal(0.0, noise, n_wall)
+    # walls (rejection on the horizontal radius so that reduced-size configs keep the full-size density)
     O = np.stack([r[0] for r in rects]); U = np.stack([r[1] for r in rects])
     V = np.stack([r[2] for r in rects]); Nn = np.stack([r[3] for r in rects])
-    out[n_ground:] = O[which] + a[:, None] * U[which] + b_[:, None] * V[which] + off[:, None] * Nn[which]
+    filled = 0
+    while filled < n_wall:
+        m = int((n_wall - filled) * 1.5) + 64
+        which = rng.choice(len(rects), size=m, p=areas / areas.sum())
+        a = rng.uniform(0, 1, m)
+        b_ = rng.uniform(0, 1, m)
+        off = rng.normal(0.0, noise, m)
+        w = O[which] + a[:, None] * U[which] + b_[:, None] * V[which] + off[:, None] * Nn[which]
+        w = w[np.hypot(w[:, 0], w[:, 1]) <= radius]
+        k = min(w.shape[0], n_wall - filled)
+        out[n_ground + filled:n_ground + filled + k] = w[:k]
+        filled += k
     perm = rng.permutation(n)
     return out[perm].astype(np.float32)
 
@@ -269,10 +286,14 @@ def make_config(config_id: int, job: int = 0, scale: float = 1.0) -> dict:
     else:
         lid = dict(VELODYNE_64)
         m = int(1000000 * scale)
+    radius = MAX_RANGE
     if scale < 1.0:
+        # keep the full-size map density: shrink the mapped disc (and the sensor range) instead of thinning
         lid["n_az"] = max(36, int(lid["n_az"] * scale))
-    out["scan"] = cast_scan(scene, T_gt, rng=rng, **lid)
-    out["map"] = sample_map(scene, m, rng_for(config_id, 0, salt=1))  # the map is shared by all jobs of a config
+        radius = max(18.0, MAX_RANGE * float(np.sqrt(scale)))
+    out["radius"] = radius
+    out["scan"] = cast_scan(scene, T_gt, rng=rng, max_range=radius, **lid)
+    out["map"] = sample_map(scene, m, rng_for(config_id, 0, salt=1), radius=radius)  # the map is shared by all jobs of a config
     if config_id == 3:
         n_corner = max(64, int(7680 * scale))
         out["corner_scan"] = cast_edge_scan(scene, T_gt, n_corner, rng)

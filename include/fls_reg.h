@@ -1,0 +1,171 @@
+/* ============================================================================
+ * fls_reg.h -- C ABI of libfls_reg.so, the MI355X (gfx950) scan-to-map
+ * registration back-end for funny_lidar_slam's RegistrationInterface.
+ *
+ * Drop-in boundary: the reference's plug-in interface is
+ *
+ *   class RegistrationInterface {                      // include/registration/registration_interface.h:11-20
+ *     virtual bool  Match(const PointcloudClusterPtr&, Mat4d& T) = 0;                          // :13
+ *     virtual void  AddCloudToLocalMap(const std::initializer_list<PCLPointCloudXYZI>&) = 0;   // :17
+ *     virtual float GetFitnessScore(float max_range) const = 0;                                // :19
+ *   };
+ *
+ * Each entry point below replaces one of those virtuals (or one constructor)
+ * of the five implementations; the header-only adapter
+ * include/fls_hip_registration.h turns them back into a RegistrationInterface.
+ * Plain C: pointers + sizes only, no Eigen / PCL / torch types.  No exception
+ * crosses this boundary; a handle is NOT thread-safe (same contract as the
+ * reference: one owner thread, frontend.cpp:207-210 / localization.cpp:246-249).
+ *
+ * Clouds are passed as float AoS with a stride in floats: pcl::PointXYZI is
+ * 32 B => pass cloud.points.data() with stride_floats = 8; a packed xyz array
+ * uses 3, xyzi uses 4.  Poses are Eigen::Matrix4d::data(): 16 doubles,
+ * COLUMN-major, world <- body.
+ *
+ * The library has no CPU fallback: every entry point that computes fails with
+ * FLS_ERR_DEVICE when no gfx950 device is usable.
+ * ==========================================================================*/
+#ifndef FLS_REG_H
+#define FLS_REG_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLS_ABI_VERSION 1
+
+/* Which reference class the handle replaces (mode strings: include/common/constant_variable.h:21-25). */
+typedef enum fls_kind {
+    FLS_ICP_OPTIMIZED = 0,   /* IcpOptimized<double>            include/registration/icp_optimized.h:15          */
+    FLS_P2PLANE_IVOX = 1,    /* LoamPointToPlaneIVOX<double>    include/registration/loam_point_to_plane_ivox.h:30 */
+    FLS_INCREMENTAL_NDT = 2, /* IncrementalNDT                  include/registration/incremental_ndt.h:16        */
+    FLS_LOAM_FULL = 3,       /* LoamFull<double>                include/registration/loam_full_kdtree.h:24       */
+    FLS_P2PLANE_KDTREE = 4   /* LoamPointToPlaneKdtree<double>  include/registration/loam_point_to_plane_kdtree.h:25 */
+} fls_kind;
+
+typedef enum fls_status {
+    FLS_OK = 0,             /* Match() == true                                                   */
+    FLS_NOT_CONVERGED = 1,  /* Match() == false (T is still written, as in the reference)        */
+    FLS_ERR_INVALID = -1,   /* bad argument / parameter left at its "unset" sentinel (CHECK_NE)  */
+    FLS_ERR_DEVICE = -2,    /* HIP runtime error or no gfx950 device                             */
+    FLS_ERR_RANGE = -3,     /* coordinate outside the +-2^20 voxel key range                     */
+    FLS_ERR_NOMEM = -4,
+    FLS_ERR_STATE = -5      /* call order violated (e.g. Match before any map cloud)             */
+} fls_status;
+
+/* Superset of the five constructors' argument lists (src/slam/frontend.cpp:30-88,
+ * src/slam/localization.cpp:43-92).  Unused fields are ignored by a kind.
+ *   P2PLANE_IVOX   : point_to_planar_thres, position/rotation_converge_thres, max_iterations, is_localization_mode
+ *                    (iVox resolution 0.5 / NEARBY18 / capacity 1e6 / map filter 0.5 are hard-coded in the
+ *                     reference, loam_point_to_plane_ivox.h:53-58,351, and therefore here)
+ *   ICP_OPTIMIZED  : max_iterations, local_map_size, map_cloud_filter_size, source_cloud_filter_size,
+ *                    point_search_thres (= max_correspond_distance, a SQUARED distance), position/rotation_converge_thres,
+ *                    rot_thre_add_cloud, dist_thre_add_cloud, is_localization_mode
+ *   INCREMENTAL_NDT: ndt_voxel_size, ndt_res_outlier_threshold, source_cloud_filter_size, rotation/position_converge_thres,
+ *                    ndt_min/max_points_in_voxel, ndt_min_effective_pts, ndt_capacity, max_iterations, is_localization_mode
+ *   LOAM_FULL      : point_to_planar_thres, point_search_thres, line_ratio_thres, position/rotation_converge_thres,
+ *                    dist_thre_add_cloud, rot_thre_add_cloud, local_corner_size, local_planar_size,
+ *                    corner/planar_voxel_filter_size, max_iterations
+ *   P2PLANE_KDTREE : point_to_planar_thres, position/rotation_converge_thres, rot/dist_thre_add_cloud, local_map_size,
+ *                    map_cloud_filter_size, max_iterations, is_localization_mode                                     */
+typedef struct fls_params {
+    uint32_t struct_size; /* = sizeof(fls_params); ABI guard */
+    uint32_t max_iterations;
+    int32_t is_localization_mode;
+    uint32_t local_map_size;
+    uint32_t local_corner_size;
+    uint32_t local_planar_size;
+    int32_t ndt_min_points_in_voxel;
+    int32_t ndt_max_points_in_voxel;
+    int32_t ndt_min_effective_pts;
+    int32_t ndt_capacity;
+    float map_cloud_filter_size;
+    float source_cloud_filter_size;
+    float corner_voxel_filter_size;
+    float planar_voxel_filter_size;
+    double point_to_planar_thres;
+    double point_search_thres;
+    double line_ratio_thres;
+    double position_converge_thres;
+    double rotation_converge_thres;
+    double rot_thre_add_cloud;
+    double dist_thre_add_cloud;
+    double ndt_voxel_size;
+    double ndt_res_outlier_threshold;
+} fls_params;
+
+/* What the reference only prints in its DLOG line (icp_optimized.h:140-144 etc.). */
+typedef struct fls_stats {
+    int32_t iterations;      /* Gauss-Newton iterations executed                         */
+    int32_t converged;       /* Match() return value                                     */
+    int32_t n_valid;         /* valid planar / effective points of the last iteration    */
+    int32_t n_valid_corner;  /* LOAM_FULL: valid corner points                           */
+    int32_t n_source;        /* source points after the in-Match VoxelGrid (ICP, NDT)    */
+    int32_t n_source_corner;
+    int32_t map_updated;     /* 1 if Match() went on to AddCloudToLocalMap               */
+    int32_t reserved;
+    double sum_res;          /* overall_res_planar_ / total_res                          */
+    double sum_res_corner;
+    double last_dx[6];       /* last Gauss-Newton step, in the matcher's own state order */
+} fls_stats;
+
+typedef struct fls_matcher* fls_handle;
+
+/* ---- constructors / destructor ---------------------------------------------------------------
+ * replaces std::make_shared<Impl<double>>(...) at frontend.cpp:32,44,59,71 / localization.cpp:45,57,70,77 */
+fls_status fls_create(fls_kind kind, const fls_params* params, int device_id, fls_handle* out);
+void fls_destroy(fls_handle h);
+
+/* ---- RegistrationInterface::AddCloudToLocalMap  (registration_interface.h:17) ------------------
+ * cloud0 = the single cloud (ICP / NDT / P2PLANE_*: world frame on external calls) or the PLANAR cloud
+ * (LOAM_FULL); cloud1 = the CORNER cloud (LOAM_FULL only, else NULL / 0) -- the initializer_list order
+ * of loam_full_kdtree.h:67-69.                                                                          */
+fls_status fls_add_cloud_to_local_map(fls_handle h, const float* cloud0, size_t n0, const float* cloud1, size_t n1,
+                                      int stride_floats);
+
+/* ---- RegistrationInterface::Match  (registration_interface.h:13) -------------------------------
+ * src0 = cluster->ordered_cloud_ (ICP, NDT) or cluster->planar_cloud_ (others); src1 = cluster->corner_cloud_
+ * (LOAM_FULL).  T_colmajor is in/out.  update_map != 0 reproduces the reference (Match itself grows the
+ * local map in mapping mode); 0 skips that step (benchmarks time the registration alone).
+ * Returns FLS_OK (true), FLS_NOT_CONVERGED (false) or an error (< 0).                                   */
+fls_status fls_match(fls_handle h, const float* src0, size_t n0, const float* src1, size_t n1, int stride_floats,
+                     double T_colmajor[16], int update_map, fls_stats* stats);
+
+/* ---- RegistrationInterface::GetFitnessScore  (registration_interface.h:19) ---------------------- */
+fls_status fls_get_fitness_score(fls_handle h, float max_range, float* score);
+
+/* ---- resident-scan variant: the scan is uploaded once (and VoxelGrid-ed for ICP / NDT), then matched
+ * from HBM.  fls_match == fls_scan_upload + fls_match_resident.                                          */
+fls_status fls_scan_upload(fls_handle h, const float* src0, size_t n0, const float* src1, size_t n1, int stride_floats);
+fls_status fls_match_resident(fls_handle h, double T_colmajor[16], int update_map, fls_stats* stats);
+
+/* ---- introspection (parity tests, DLOG-equivalent) ---------------------------------------------- */
+/* pose / n_valid / sum_res after every executed iteration; returns the number of iterations logged. */
+int fls_get_iteration_log(fls_handle h, double* T_iters /* cap x 16, col-major */, int32_t* n_valid, double* sum_res,
+                          int cap);
+/* neighbours held for each source point after the last Match: ids are map insertion ids (iVox), map cloud
+ * indices (kd-tree kinds), voxel creation ids (NDT); K = 5 (1 for ICP, 7 for NDT).  slot 1 = corner set. */
+int fls_get_correspondences(fls_handle h, int slot, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap_points);
+size_t fls_map_size(fls_handle h, int slot);
+
+/* ---- measurement hooks ----------------------------------------------------------------------------
+ * fls_set_profiling(h, flags): bit 0 = bracket every correspondence-kernel launch with hipEvents on the
+ * handle's own stream; bit 1 = run the counting variant of the correspondence kernel, which tallies
+ * probes / hit voxels / candidate points on the device (SURVEY.md 8d formula inputs; a few % slower).
+ * fls_get_kernel_time returns the summed duration [ms] and launch count of the launches that did work
+ * (early-exit launches after convergence are excluded) since the last call.                             */
+fls_status fls_set_profiling(fls_handle h, int enable);
+fls_status fls_get_kernel_time(fls_handle h, double* ms_total, int64_t* launches, uint64_t* point_iters);
+/* traffic counters of the last Match run with flag bit 1 set */
+fls_status fls_get_traffic_counters(fls_handle h, uint64_t* probes, uint64_t* hit_voxels, uint64_t* cand_points);
+
+const char* fls_status_string(int status);
+int fls_abi_version(void);
+/* number of visible HIP devices whose arch is gfx950 (0 => every compute call fails with FLS_ERR_DEVICE) */
+int fls_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLS_REG_H */

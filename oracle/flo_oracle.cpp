@@ -373,8 +373,8 @@ struct IcpOptimized final : MatcherBase {
                 KdTree::Hit h;
                 const float q[3] = {tp.x, tp.y, tp.z};
                 if (tree.Knn(q, 1, &h) < 1) continue;
-                nn_idx[size_t(i)] = h.idx;
                 if (double(h.d2) > p.point_search_thres) continue;
+                nn_idx[size_t(i)] = h.idx;  // introspection only: ids are reported for accepted correspondences
                 const float* mp = tree.point(h.idx);
                 const double e[3] = {double(tp.x) - double(mp[0]), double(tp.y) - double(mp[1]), double(tp.z) - double(mp[2])};
                 const double o[3] = {double(op.x), double(op.y), double(op.z)};
@@ -795,10 +795,12 @@ struct LoamFull final : MatcherBase {
             KdTree::Hit h[5];
             const float q[3] = {tp.x, tp.y, tp.z};
             const int k = corner_tree.Knn(q, 5, h);
-            corner.cnt[size_t(i)] = uint8_t(k);
-            for (int j = 0; j < 5; ++j) corner.nn[size_t(i) * 5 + j] = j < k ? h[j].idx : -1;
+            corner.cnt[size_t(i)] = 0;
+            for (int j = 0; j < 5; ++j) corner.nn[size_t(i) * 5 + j] = -1;
             if (k < 5) continue;  // reference would read out of bounds; maps always hold >= 5 points
             if (double(h[4].d2) > p.point_search_thres) continue;
+            corner.cnt[size_t(i)] = 5;  // introspection only: ids are reported for gate-accepted neighbour sets
+            for (int j = 0; j < 5; ++j) corner.nn[size_t(i) * 5 + j] = h[j].idx;
             P4 nn[5];
             for (int j = 0; j < 5; ++j) { const float* m = corner_tree.point(h[j].idx); nn[j] = P4{m[0], m[1], m[2], 0}; }
             double J[6], d;
@@ -817,10 +819,12 @@ struct LoamFull final : MatcherBase {
             KdTree::Hit h[5];
             const float q[3] = {tp.x, tp.y, tp.z};
             const int k = planar_tree.Knn(q, 5, h);
-            planar.cnt[size_t(i)] = uint8_t(k);
-            for (int j = 0; j < 5; ++j) planar.nn[size_t(i) * 5 + j] = j < k ? h[j].idx : -1;
+            planar.cnt[size_t(i)] = 0;
+            for (int j = 0; j < 5; ++j) planar.nn[size_t(i) * 5 + j] = -1;
             if (k < 5) continue;
             if (double(h[4].d2) > p.point_search_thres) continue;
+            planar.cnt[size_t(i)] = 5;
+            for (int j = 0; j < 5; ++j) planar.nn[size_t(i) * 5 + j] = h[j].idx;
             P4 nn[5];
             for (int j = 0; j < 5; ++j) { const float* m = planar_tree.point(h[j].idx); nn[j] = P4{m[0], m[1], m[2], 0}; }
             double J[6], r;

@@ -1,0 +1,113 @@
+"""GPU parity tests (the tests proper): HIP path through the C ABI vs the CPU oracle on identical inputs.
+
+Bar (BASELINE.json north_star): correspondence indices bit-exact, SE(3) pose within 1e-4 m / 1e-4 rad
+after the same iteration count.  The tests are stricter: n_valid and the pose are compared after EVERY
+Gauss-Newton iteration, the valid flags and neighbour counts of every source point must be identical.
+"""
+import numpy as np
+import pytest
+
+from funny_lidar_slam_amd import _lib, registration as reg, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(built):
+    assert _lib.device_count() >= 1, "gpu tests need an MI355X (gfx950): the HIP path has no CPU fallback"
+
+
+def run_pair(mode, y, map_clouds, scan, corner=None, loc=False, T_init=None, update_map=False, tie_ok=True, sets_only_tail=False):
+    m = reg.make_matcher(mode, y, is_localization_mode=loc)
+    o = util.oracle_for(mode, y, loc)
+    m.AddCloudToLocalMap(map_clouds)
+    o.AddCloudToLocalMap(*map_clouds)
+    T = (np.eye(4) if T_init is None else T_init).copy()
+    ok = m.Match(util.cluster_for(mode, scan, corner), T, update_map=update_map)
+    ok_ref, T_ref = o.Match(scan, np.eye(4) if T_init is None else T_init, src1=corner, update_map=update_map)
+    ties = int(o.counters().tie_queries) if tie_ok else 0
+    slots = (0, 1) if mode == "LoamFull_KdTree" else (0,)
+    dt, dr = util.assert_same_registration(m, o, ok, T, ok_ref, T_ref, slots=slots, sets_only_tail=sets_only_tail, max_tie_rows=ties)
+    return m, o, T, T_ref
+
+
+@pytest.mark.parametrize("scale", [0.05, 1.0])
+def test_config2_p2plane_ivox(scale):
+    """BASELINE configs[1]: 64x1800 scan, point-to-plane into the 1e6-pt iVox map (also a 5% slice)."""
+    cfg = synth.make_config(1, scale=scale)
+    m, o, T, T_ref = run_pair("PointToPlane_IVOX", reg.YAML_NCLT_IVOX, [cfg["map"]], cfg["scan"], sets_only_tail=True)
+    assert m.stats.converged == 1
+    dt, dr = synth.pose_error(T, cfg["T_gt"])
+    assert dt < 0.05 and dr < 0.005  # it actually registers (not only agrees with the oracle)
+
+
+def test_config1_icp_localization():
+    """BASELINE configs[0]: 16x900 scan, Optimized-ICP vs the 50k-pt fixed map (localization mode), + GetFitnessScore."""
+    cfg = synth.make_config(0)
+    m, o, T, T_ref = run_pair("IcpOptimized", reg.YAML_NCLT_ICP, [cfg["map"]], cfg["scan"], loc=True)
+    f, f_ref = m.GetFitnessScore(2.0), o.GetFitnessScore(2.0)
+    assert f == pytest.approx(f_ref, rel=1e-6)
+
+
+@pytest.mark.parametrize("scale", [0.1, 1.0])
+def test_config3_incremental_ndt(scale):
+    """BASELINE configs[2]: Incremental-NDT, 1.0 m voxels."""
+    cfg = synth.make_config(2, scale=scale)
+    run_pair("IncrementalNDT", reg.YAML_NCLT_NDT, [cfg["map"]], cfg["scan"])
+
+
+@pytest.mark.parametrize("scale", [0.1, 1.0])
+def test_config4_loam_full(scale):
+    """BASELINE configs[3]: LOAM frontend, point-to-line (corner) + point-to-plane (surf) residuals."""
+    cfg = synth.make_config(3, scale=scale)
+    m, o, T, T_ref = run_pair("LoamFull_KdTree", reg.YAML_NCLT_LOAM_FULL, [cfg["map"], cfg["corner_map"]], cfg["scan"], corner=cfg["corner_scan"])
+    assert m.stats.n_valid_corner > 0
+
+
+def test_p2plane_kdtree_localization():
+    """LoamPointToPlaneKdtree (localization only in the reference): un-gated exact 5-NN + fitness."""
+    cfg = synth.make_config(1, scale=0.1)
+    m, o, T, T_ref = run_pair("PointToPlane_KdTree", reg.YAML_NCLT_LOC_KDTREE, [cfg["map"]], cfg["scan"], loc=True)
+    assert m.GetFitnessScore(2.0) == pytest.approx(o.GetFitnessScore(2.0), rel=1e-6)
+
+
+def test_p2plane_ivox_localization_fitness():
+    cfg = synth.make_config(1, scale=0.05)
+    m, o, T, T_ref = run_pair("PointToPlane_IVOX", reg.YAML_NCLT_IVOX, [cfg["map"]], cfg["scan"], loc=True, sets_only_tail=True)
+    assert m.GetFitnessScore(2.0) == pytest.approx(o.GetFitnessScore(2.0), rel=1e-6)
+    m2 = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+    assert m2.GetFitnessScore(2.0) == reg.FloatNaN  # mapping mode: FloatNaN (loam_point_to_plane_ivox.h:226-228)
+
+
+def test_determinism_two_runs_bit_identical():
+    cfg = synth.make_config(1, scale=0.1)
+    outs = []
+    for _ in range(2):
+        m = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+        m.AddCloudToLocalMap([cfg["map"]])
+        T = np.eye(4)
+        m.Match(reg.PointcloudCluster(planar_cloud_=cfg["scan"]), T, update_map=False)
+        outs.append((T.copy(), m.iteration_log()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1][0], outs[1][1][0]) and np.array_equal(outs[0][1][2], outs[1][1][2])
+
+
+def test_pcl_layout_stride8_equals_packed():
+    """pcl::PointXYZI memory (8 floats / point) through the ABI gives the same result as packed xyz."""
+    cfg = synth.make_config(1, scale=0.05)
+
+    def pad8(c):
+        o = np.zeros((c.shape[0], 8), np.float32)
+        o[:, :3] = c
+        o[:, 3] = 1.0
+        return o
+
+    res = []
+    for f in (lambda c: c, pad8):
+        m = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+        m.AddCloudToLocalMap([f(cfg["map"])])
+        T = np.eye(4)
+        m.Match(reg.PointcloudCluster(planar_cloud_=f(cfg["scan"])), T, update_map=False)
+        res.append(T.copy())
+    assert np.array_equal(res[0], res[1])
