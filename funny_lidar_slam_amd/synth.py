@@ -6,7 +6,7 @@ with the reference's own sensor models (``src/lidar/lidar_model.cpp:24-30``
 Velodyne_16-like 16 x 900 grid for config 1, ``:39-45`` Velodyne_64: 64 rings,
 -24.9 deg + 0.4 deg * ring, 1800 azimuth steps of 0.2 deg).
 
-Scene ("campus"): ground plane z = 0, a jittered grid of axis-aligned building
+Scene ("campus"): ground plane z = -1.8 (sensor/body origin 1.8 m above it), a jittered grid of axis-aligned building
 boxes and square 0.6 x 0.6 x 6 m pillars.  SURVEY.md 8d proposed a single
 80 x 50 x 12 m room; that room has ~8e3 m^2 of surface, i.e. 1e6 map points would
 give ~30 points per 0.5 m iVox voxel, whereas the survey's own traffic model
@@ -23,7 +23,9 @@ from __future__ import annotations
 import numpy as np
 
 BASE_SEED = 20241022
-SENSOR_Z = 1.8
+SENSOR_Z = 0.0    # the sensor / body origin ...
+GROUND_Z = -1.8   # ... rides 1.8 m above the ground plane (the reference's plane model A x = -1 cannot
+                  # represent a plane through the world origin, loam_point_to_plane_ivox.h:275-284)
 MAX_RANGE = 100.0
 MIN_RANGE = 4.0
 
@@ -49,7 +51,7 @@ def make_scene(seed: int = BASE_SEED) -> dict:
             # keep a clear disc around the sensor
             if (abs(x) - hx) < 9.0 and (abs(y) - hy) < 9.0:
                 continue
-            boxes.append([x - hx, y - hy, 0.0, x + hx, y + hy, h])
+            boxes.append([x - hx, y - hy, GROUND_Z, x + hx, y + hy, GROUND_Z + h])
     n_buildings = len(boxes)
     pc = np.arange(-72.0, 73.0, 36.0)
     for cx in pc:
@@ -58,7 +60,7 @@ def make_scene(seed: int = BASE_SEED) -> dict:
             x, y = cx + jx, cy + jy
             if np.hypot(x, y) < 6.0:
                 x += 8.0
-            boxes.append([x - 0.3, y - 0.3, 0.0, x + 0.3, y + 0.3, 6.0])
+            boxes.append([x - 0.3, y - 0.3, GROUND_Z, x + 0.3, y + 0.3, GROUND_Z + 6.0])
     return {"boxes": np.asarray(boxes, dtype=np.float64), "n_buildings": n_buildings}
 
 
@@ -70,7 +72,7 @@ def _ray_cast(scene: dict, o: np.ndarray, d: np.ndarray) -> np.ndarray:
     # ground
     dz = d[:, 2]
     with np.errstate(divide="ignore", invalid="ignore"):
-        tg = np.where(dz < -1e-12, -o[2] / dz, np.inf)
+        tg = np.where(dz < -1e-12, (GROUND_Z - o[2]) / dz, np.inf)
     t_best = np.minimum(t_best, np.where(tg > 0, tg, np.inf))
     # boxes: slab method, chunked over rays
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -173,7 +175,7 @@ def sample_map(scene: dict, n: int, rng: np.random.Generator, noise: float = 0.0
         k = min(x.size, n_ground - filled)
         out[filled:filled + k, 0] = x[:k]
         out[filled:filled + k, 1] = y[:k]
-        out[filled:filled + k, 2] = rng.normal(0.0, noise, k)
+        out[filled:filled + k, 2] = GROUND_Z + rng.normal(0.0, noise, k)
         filled += k
     # walls (rejection on the horizontal radius so that reduced-size configs keep the full-size density)
     O = np.stack([r[0] for r in rects]); U = np.stack([r[1] for r in rects])
