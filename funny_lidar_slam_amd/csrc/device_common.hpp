@@ -34,6 +34,16 @@ struct DevGrid {
     unsigned n_pts;
 };
 
+// Dense voxel window (optional, iVox path): a plain 3-D array of {begin, count} over the bounding box of the
+// occupied voxel keys, x fastest.  One aligned 8-byte load per probe, no hashing, and -- unlike the hash
+// table, which scatters neighbouring voxels over the whole table -- neighbouring voxels share cache lines,
+// so the per-XCD L2 (4 MiB) holds the slice of the map its queries touch.
+struct DenseWindow {
+    const uint2* cells;  // nullptr: window not built (extent too large) -> hash table path
+    int ox, oy, oz;      // voxel key of cell (0,0,0)
+    int nx, ny, nz;
+};
+
 struct GnState {
     double T[16];  // current pose, column-major 4x4 (world <- body)
     double last_rot, last_pos;
@@ -45,10 +55,26 @@ struct GnState {
     int converged;       // ICP: has_converge_;  NDT: 0 if min_effective check failed
     int n_valid, n_valid2;
     int pad;
+    long long dbg[16];  // cycle stamps of the solve kernel phases (diagnostics, written only with -DFLS_TIMING)
     double log_T[kMaxIter][16];
     double log_res[kMaxIter];
     int log_nv[kMaxIter];
 };
+
+// Result mailbox in host-mapped pinned memory: the Gauss-Newton tail writes the few words a Match returns
+// (pose, counters) straight to the host and publishes them with one system-scope release store of `seq`
+// = match_id << 9 | done << 8 | iterations.  The host spins on that word instead of paying a blocking
+// hipStreamSynchronize (~25 us wake-up) plus a device-to-host copy kernel per Match.
+struct Mailbox {
+    double T[16];
+    double sum_res, sum_res2;
+    double last_dx[6];
+    int iter, done, converged, n_valid, n_valid2;
+    unsigned seq;
+};
+
+// initial pose handed to the first iteration's kernels as a launch argument (no host-to-device copy)
+struct Pose16 { double m[16]; };
 
 struct TrafficCounters {
     unsigned long long probes, hits, cand;
@@ -57,6 +83,11 @@ struct TrafficCounters {
 __host__ __device__ __forceinline__ unsigned long long pack_key(int x, int y, int z) {
     return ((unsigned long long)((unsigned)x & 0x1FFFFFu) << 42) | ((unsigned long long)((unsigned)y & 0x1FFFFFu) << 21) |
            (unsigned long long)((unsigned)z & 0x1FFFFFu);
+}
+__host__ __device__ __forceinline__ void unpack_key(unsigned long long k, int& x, int& y, int& z) {
+    x = (int)((unsigned)(k >> 42) << 11) >> 11;  // sign-extend the 21-bit fields
+    y = (int)((unsigned)((k >> 21) & 0x1FFFFFu) << 11) >> 11;
+    z = (int)((unsigned)(k & 0x1FFFFFu) << 11) >> 11;
 }
 __host__ __device__ __forceinline__ unsigned hash_key(unsigned long long k) {
     k ^= k >> 33;

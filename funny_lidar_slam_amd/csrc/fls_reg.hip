@@ -141,6 +141,7 @@ fls_status fls_get_fitness_score(fls_handle h, float max_range, float* score) {
 
 int fls_get_iteration_log(fls_handle h, double* T_iters, int32_t* n_valid, double* sum_res, int cap) {
     if (!h || !h->h_state.p) return 0;
+    if (guarded([&]() -> fls_status { FLS_HIP(hipSetDevice(h->device)); h->refresh_log(); return FLS_OK; }) != FLS_OK) return 0;
     const GnState& s = *h->h_state.p;
     const int n = std::min(cap, h->log_n);
     for (int i = 0; i < n; ++i) {
@@ -182,6 +183,13 @@ fls_status fls_get_kernel_time(fls_handle h, double* ms_total, int64_t* launches
     h->prof_ms = 0.0;
     h->prof_launches = 0;
     h->prof_point_iters = 0;
+    return FLS_OK;
+}
+
+fls_status fls_get_debug_stamps(fls_handle h, int64_t out[16]) {
+    if (!h || !out || !h->h_state.p) return FLS_ERR_INVALID;
+    (void)guarded([&]() -> fls_status { FLS_HIP(hipSetDevice(h->device)); h->refresh_log(); return FLS_OK; });
+    for (int i = 0; i < 16; ++i) out[i] = h->h_state.p->dbg[i];
     return FLS_OK;
 }
 

@@ -15,6 +15,7 @@
 #include "host_util.hpp"
 #include <unordered_map>
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <limits>
 
@@ -159,10 +160,59 @@ struct GridImage {
     }
     DevGrid dev() const { return DevGrid{d_table.p, d_pts.p, mask, unsigned(pts.size())}; }
 
+    // dense window (see device_common.hpp DenseWindow)
+    std::vector<uint2> cells;
+    DevBuf<uint2> d_cells;
+    int win_o[3] = {0, 0, 0}, win_n[3] = {0, 0, 0};
+    bool have_window = false;
+    static constexpr size_t kMaxWindowCells = size_t(48) << 20;  // 48 Mi cells = 384 MiB of {begin,count}
+    DenseWindow window() const {
+        return have_window ? DenseWindow{d_cells.p, win_o[0], win_o[1], win_o[2], win_n[0], win_n[1], win_n[2]}
+                           : DenseWindow{nullptr, 0, 0, 0, 0, 0, 0};
+    }
+
     void build_from_ivox(const HostIvox& m, hipStream_t s) {
+        // voxels in window order (z, y, x): spatially adjacent voxels get adjacent point buckets
+        struct Ref { int x, y, z; const HostIvox::Voxel* v; };
+        std::vector<Ref> refs;
+        refs.reserve(m.n_alive);
+        int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+        for (const auto& v : m.pool) {
+            if (!v.alive) continue;
+            Ref r;
+            unpack_key(v.key, r.x, r.y, r.z);
+            r.v = &v;
+            refs.push_back(r);
+            mn[0] = std::min(mn[0], r.x); mx[0] = std::max(mx[0], r.x);
+            mn[1] = std::min(mn[1], r.y); mx[1] = std::max(mx[1], r.y);
+            mn[2] = std::min(mn[2], r.z); mx[2] = std::max(mx[2], r.z);
+        }
+        std::sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) {
+            if (a.z != b.z) return a.z < b.z;
+            if (a.y != b.y) return a.y < b.y;
+            return a.x < b.x;
+        });
         begin_build(m.n_alive, m.n_points);
-        for (const auto& v : m.pool)
-            if (v.alive) insert_bucket(v.key, v.pts.data(), v.pts.size());
+        have_window = false;
+        size_t ncell = 0;
+        if (!refs.empty()) {
+            for (int a = 0; a < 3; ++a) { win_o[a] = mn[a] - 1; win_n[a] = mx[a] - mn[a] + 3; }  // one empty cell of margin
+            ncell = size_t(win_n[0]) * size_t(win_n[1]) * size_t(win_n[2]);
+            have_window = ncell <= kMaxWindowCells;
+        }
+        if (have_window) cells.assign(ncell, make_uint2(0u, 0u));
+        for (const Ref& r : refs) {
+            const unsigned beg = unsigned(pts.size());
+            insert_bucket(r.v->key, r.v->pts.data(), r.v->pts.size());
+            if (have_window) {
+                const size_t idx = (size_t(r.z - win_o[2]) * win_n[1] + size_t(r.y - win_o[1])) * win_n[0] + size_t(r.x - win_o[0]);
+                cells[idx] = make_uint2(beg, unsigned(r.v->pts.size()));
+            }
+        }
+        if (have_window) {
+            d_cells.reserve(cells.size());
+            FLS_HIP(hipMemcpyAsync(d_cells.p, cells.data(), cells.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
+        }
         upload(s);
     }
 };

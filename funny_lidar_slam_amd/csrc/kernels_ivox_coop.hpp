@@ -1,0 +1,339 @@
+// kernels_ivox_coop.hpp -- the production iVox point-to-plane path, split for the machine:
+//
+//   ivox_knn_kernel<G>   G lanes cooperate on ONE source point: the 19 voxel probes are dealt round-robin
+//                        to the G lanes (all first-slot hash loads of a wave are in flight together), every
+//                        lane scans the points of the voxels it hit into a private top-5 held as 64-bit
+//                        keys {float-bits(d2) : map slot}, and the G private lists are merged by five
+//                        rounds of a DPP/shuffle group-min.  Few registers -> 8 waves/SIMD, G x more waves
+//                        than points/64: the dependent gathers (table -> voxel points) are hidden by
+//                        thread-level parallelism instead of being serialised in one lane (the first,
+//                        fused kernel spent 117 us per launch that way).
+//                        Output: nearest_points_[i] (<=5 float4 {x,y,z,id}) + count; untouched when no
+//                        candidate exists (ivox_map.cpp:21-23 quirk).
+//   p2plane_fit_solve_kernel  one lane per source point: 5x3 column-pivoted Householder plane fit, gates,
+//                        Jacobian (FP64), the Q1 stale-slot rule, DPP wave reduction of the 6x6 system; the last
+//                        workgroup to finish also runs the Gauss-Newton tail (solve, pose update, stop rule).
+//
+// (An earlier single-kernel variant with one lane per point ran 117 us per launch: it serialised ~60
+// dependent gathers per lane.)  Exact-tie rule of the selection: lower map slot wins (the reference's
+// order under exact float ties is libstdc++-introselect-defined; parity tests count such queries).
+#pragma once
+#include "kernels_p2plane.hpp"
+
+namespace fls {
+
+// NEARBY18 offsets (ivox_map.cpp:50-54) packed 2 bits per entry (value + 1), entry k at bits [2k, 2k+1]:
+// a per-lane probe index needs no table load.
+//   dx: 0,-1,1,0,0,0,0,1,-1,1,-1,1,-1,1,-1,0,0,0,0
+//   dy: 0,0,0,1,-1,0,0,1,1,-1,-1,0,0,0,0,1,-1,1,-1
+//   dz: 0,0,0,0,0,-1,1,0,0,0,0,1,1,-1,-1,1,1,-1,-1
+__device__ __forceinline__ void nearby18(const int k, int& dx, int& dy, int& dz) {
+    constexpr unsigned long long DX = 0x1548889561ull, DY = 0x895429495ull, DZ = 0x282956155ull;
+    dx = (int)((DX >> (2 * k)) & 3ull) - 1;
+    dy = (int)((DY >> (2 * k)) & 3ull) - 1;
+    dz = (int)((DZ >> (2 * k)) & 3ull) - 1;
+}
+
+// Butterfly exchange partners without LDS: lane^1 and lane^2 are quad permutes, the third pairing uses
+// row_half_mirror (lane i <-> 7-i inside each group of 8) -- any perfect pairing works for a min / sum.
+template <int STEP>
+__device__ __forceinline__ unsigned dpp_pair_u32(const unsigned v) {
+    static_assert(STEP >= 0 && STEP <= 3, "");
+    if (STEP == 0) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    if (STEP == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    if (STEP == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);                 // row_mirror (16 lanes)
+}
+template <int G>
+__device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v) {
+#define FLS_MIN_STEP(S)                                                                               \
+    {                                                                                                 \
+        const unsigned lo = dpp_pair_u32<S>((unsigned)(v & 0xffffffffull));                          \
+        const unsigned hi = dpp_pair_u32<S>((unsigned)(v >> 32));                                    \
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;                            \
+        v = o < v ? o : v;                                                                            \
+    }
+    FLS_MIN_STEP(0)
+    if (G >= 4) FLS_MIN_STEP(1)
+    if (G >= 8) FLS_MIN_STEP(2)
+    if (G >= 16) FLS_MIN_STEP(3)
+#undef FLS_MIN_STEP
+    if (G == 32) {
+        const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), 16, 64);
+        const unsigned hi = __shfl_xor((unsigned)(v >> 32), 16, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ int group_sum_i32(int v) {
+    v += (int)dpp_pair_u32<0>((unsigned)v);
+    if (G >= 4) v += (int)dpp_pair_u32<1>((unsigned)v);
+    if (G >= 8) v += (int)dpp_pair_u32<2>((unsigned)v);
+    if (G >= 16) v += (int)dpp_pair_u32<3>((unsigned)v);
+    if (G == 32) v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
+__device__ __forceinline__ void top5_insert_key(unsigned long long (&t)[5], const unsigned long long key) {
+    if (key < t[4]) {
+        t[4] = key;
+#pragma unroll
+        for (int j = 4; j > 0; --j) {
+            if (t[j] < t[j - 1]) { const unsigned long long x = t[j]; t[j] = t[j - 1]; t[j - 1] = x; }
+        }
+    }
+}
+
+template <int G, bool COUNT, bool DENSE>
+__global__ void __launch_bounds__(256)
+ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                const GnState* __restrict__ st, const int first, const Pose16 T0, const DevGrid grid, const DenseWindow win,
+                const float inv_res, float4* __restrict__ nn_pts /* [n][5] */, unsigned char* __restrict__ nn_cnt,
+                unsigned char* __restrict__ flag, TrafficCounters* __restrict__ tc) {
+    static_assert(G == 4 || G == 8, "group size");
+    constexpr int QPB = 256 / G;       // queries per workgroup
+    constexpr int R = (19 + G - 1) / G;  // probe rounds per lane
+    // XCD-aware block order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with
+    // its own 4 MiB L2.  Re-map so that XCD x walks ONE contiguous eighth of the (ring-major, hence spatially
+    // coherent) scan: every L2 then caches its own slice of the map instead of all of it.  Affects speed only.
+    // (the grid is launched rounded up to a multiple of 8 so that the re-map is a bijection)
+    const int nb = (n + QPB - 1) / QPB, per = gridDim.x >> 3;
+    const int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int sub = threadIdx.x % G;
+    const int q = lb * QPB + threadIdx.x / G;
+    const bool active = lb < nb && q < n;
+    // issue the state / source loads before looking at the stop flag: one memory round trip instead of three.
+    // The first iteration of a Match takes the initial pose from the launch arguments and ignores the
+    // (stale) device state; it also clears the per-point valid flags (std::fill once per Match, Q1).
+    const int done = first ? 0 : st->done;
+    double T[12];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) T[c * 3 + r] = first ? T0.m[c * 4 + r] : st->T[c * 4 + r];
+    const float px = active ? sx[q] : 0.f, py = active ? sy[q] : 0.f, pz = active ? sz[q] : 0.f;
+    if (done) return;
+    if (first && active && sub == 0) flag[q] = 0;
+    const double x = px, y = py, z = pz;
+    const float ptx = (float)(((T[0] * x + T[3] * y) + T[6] * z) + T[9]);
+    const float pty = (float)(((T[1] * x + T[4] * y) + T[7] * z) + T[10]);
+    const float ptz = (float)(((T[2] * x + T[5] * y) + T[8] * z) + T[11]);
+    const float fx = roundf(ptx * inv_res), fy = roundf(pty * inv_res), fz = roundf(ptz * inv_res);
+    const bool in_range = active && fabsf(fx) < (float)kKeyLimit && fabsf(fy) < (float)kKeyLimit && fabsf(fz) < (float)kKeyLimit;
+    const int kx = in_range ? (int)fx : 0, ky = in_range ? (int)fy : 0, kz = in_range ? (int)fz : 0;
+
+    // phase 1: this lane's probes (k = sub, sub+G, ...): issue every first-slot load before resolving any.
+    // Written as explicit per-round scalars (no indexed arrays) so that nothing lands in scratch.
+    unsigned long long t5[5] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
+    int ncand = 0;
+    unsigned long long c_hits = 0, c_cand = 0, c_probes = 0;
+    auto probe_key = [&](const int r, bool& pv) -> unsigned long long {
+        const int k = sub + G * r;
+        pv = in_range && k < 19;
+        int ox, oy, oz;
+        nearby18(k < 19 ? k : 0, ox, oy, oz);
+        return pack_key(kx + ox, ky + oy, kz + oz);
+    };
+    auto first_load = [&](const bool pv, const unsigned long long key, unsigned& h) -> HashEntry {
+        h = hash_key(key) & grid.mask;
+        return pv ? grid.table[h] : HashEntry{kEmptyKey, 0u, 0u};
+    };
+    // resolve a probe (linear probing on collision) to its voxel's point range; count = 0 on a miss
+    auto resolve = [&](const bool pv, const unsigned long long key, unsigned h, HashEntry ek, unsigned& beg, unsigned& cnt) {
+        while (pv && ek.key != key && ek.key != kEmptyKey) {
+            h = (h + 1) & grid.mask;
+            ek = grid.table[h];
+        }
+        const bool hit = pv && ek.key == key;
+        beg = hit ? ek.begin : 0u;
+        cnt = hit ? ek.count : 0u;
+        if (COUNT && pv) { c_probes++; if (hit) { c_hits++; c_cand += ek.count; } }
+    };
+    unsigned b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+    if (DENSE) {
+        // dense window: one 8-byte load per probe, addresses of neighbouring voxels are neighbours
+        auto cell = [&](const int r, unsigned& beg, unsigned& cnt) {
+            const int k = sub + G * r;
+            int ox, oy, oz;
+            nearby18(k < 19 ? k : 0, ox, oy, oz);
+            const int cx = kx + ox - win.ox, cy = ky + oy - win.oy, cz = kz + oz - win.oz;
+            const bool ok = in_range && k < 19 && (unsigned)cx < (unsigned)win.nx && (unsigned)cy < (unsigned)win.ny && (unsigned)cz < (unsigned)win.nz;
+            const uint2 e = ok ? win.cells[((size_t)cz * win.ny + cy) * win.nx + cx] : make_uint2(0u, 0u);
+            beg = e.x;
+            cnt = e.y;
+            if (COUNT && in_range && k < 19) { c_probes++; if (e.y) { c_hits++; c_cand += e.y; } }
+        };
+        cell(0, b0, c0);
+        if (R > 1) cell(1, b1, c1);
+        if (R > 2) cell(2, b2, c2);
+        if (R > 3) cell(3, b3, c3);
+        if (R > 4) cell(4, b4, c4);
+    } else {
+        bool pv0 = false, pv1 = false, pv2 = false, pv3 = false, pv4 = false;
+        unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0;
+        unsigned h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
+        HashEntry e0{kEmptyKey, 0u, 0u}, e1 = e0, e2 = e0, e3 = e0, e4 = e0;
+        k0 = probe_key(0, pv0); e0 = first_load(pv0, k0, h0);
+        if (R > 1) { k1 = probe_key(1, pv1); e1 = first_load(pv1, k1, h1); }
+        if (R > 2) { k2 = probe_key(2, pv2); e2 = first_load(pv2, k2, h2); }
+        if (R > 3) { k3 = probe_key(3, pv3); e3 = first_load(pv3, k3, h3); }
+        if (R > 4) { k4 = probe_key(4, pv4); e4 = first_load(pv4, k4, h4); }
+        resolve(pv0, k0, h0, e0, b0, c0);
+        if (R > 1) resolve(pv1, k1, h1, e1, b1, c1);
+        if (R > 2) resolve(pv2, k2, h2, e2, b2, c2);
+        if (R > 3) resolve(pv3, k3, h3, e3, b3, c3);
+        if (R > 4) resolve(pv4, k4, h4, e4, b4, c4);
+    }
+    // scan this lane's <= R voxels, 4 point loads in flight per trip (the dependent-load latency is paid
+    // once per four candidates; the tail of a voxel re-reads its last point, masked out)
+    auto consider = [&](const float4 p, const unsigned s, const bool ok) {
+        const float dx = p.x - ptx, dy = p.y - pty, dz = p.z - ptz;
+        const float d2 = dx * dx + (dy * dy + dz * dz);  // Eigen Vector3f::squaredNorm order
+        if (ok && d2 < 25.0f) {  // max_range 5.0 squared (never binds at 0.5 m voxels)
+            ++ncand;
+            top5_insert_key(t5, ((unsigned long long)__float_as_uint(d2) << 32) | s);
+        }
+    };
+    // one flattened loop over this lane's <= R voxels: trip count = ceil(lane total / 4), not the sum of
+    // per-voxel maxima
+    const unsigned tot = c0 + c1 + c2 + c3 + c4;
+    auto slot_of = [&](unsigned idx) -> unsigned {
+        if (idx < c0) return b0 + idx;
+        idx -= c0;
+        if (R > 1) { if (idx < c1) return b1 + idx; idx -= c1; }
+        if (R > 2) { if (idx < c2) return b2 + idx; idx -= c2; }
+        if (R > 3) { if (idx < c3) return b3 + idx; idx -= c3; }
+        return b4 + idx;
+    };
+    for (unsigned j = 0; j < tot; j += 4) {
+        const unsigned last = tot - 1;
+        const unsigned i1 = j + 1, i2 = j + 2, i3 = j + 3;
+        const unsigned s0 = slot_of(j), s1 = slot_of(i1 < last ? i1 : last), s2 = slot_of(i2 < last ? i2 : last),
+                       s3 = slot_of(i3 < last ? i3 : last);
+        const float4 p0 = grid.pts[s0], p1 = grid.pts[s1], p2 = grid.pts[s2], p3 = grid.pts[s3];
+        consider(p0, s0, true);
+        consider(p1, s1, i1 <= last);
+        consider(p2, s2, i2 <= last);
+        consider(p3, s3, i3 <= last);
+    }
+    // phase 2: merge the G private lists: five rounds of group-min + pop
+    const int total = group_sum_i32<G>(ncand);
+    if (total > 0) {  // uniform within the group
+        const int cnt = total < 5 ? total : 5;
+        unsigned long long mine = ~0ull;  // the j-th smallest key lands in lane sub == j
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const unsigned long long m = group_min_u64<G>(t5[0]);
+            if (t5[0] == m && m != ~0ull) {  // keys are unique (slot in the low word): exactly one lane pops
+                t5[0] = t5[1]; t5[1] = t5[2]; t5[2] = t5[3]; t5[3] = t5[4]; t5[4] = ~0ull;
+            }
+            if (G >= 8) { if (sub == j) mine = m; }
+            else { if (sub == 0) { /* G == 4: lane 0 writes all five */
+                    if (active) {
+                        const float4 v = (m != ~0ull) ? grid.pts[(unsigned)(m & 0xffffffffull)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+                        nn_pts[(size_t)q * 5 + j] = v;
+                    }
+                } }
+        }
+        if (G >= 8 && sub < 5 && active) {
+            const float4 v = (mine != ~0ull) ? grid.pts[(unsigned)(mine & 0xffffffffull)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            nn_pts[(size_t)q * 5 + sub] = v;
+        }
+        if (sub == 0 && active) nn_cnt[q] = (unsigned char)cnt;
+    }
+    if (COUNT) {
+        const double p = wave_sum((double)c_probes), hsum = wave_sum((double)c_hits), c = wave_sum((double)c_cand);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&tc->probes, (unsigned long long)p);
+            atomicAdd(&tc->hits, (unsigned long long)hsum);
+            atomicAdd(&tc->cand, (unsigned long long)c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// p2plane_fit_solve_kernel: fit + residual + block reduction (one lane per source point, reading what
+// ivox_knn_kernel left behind), and the LAST workgroup to finish runs the Gauss-Newton
+// tail (reduce the block partials, 6x6 solve, pose update, stop rule) -- one launch per iteration fewer.
+// Cross-workgroup hand-off follows the agent-scope release / acquire recipe: every workgroup writes its
+// partial row with plain stores, __syncthreads, lane 0 issues fence(release, agent) + s_waitcnt vmcnt(0)
+// and takes a ticket with a device-scope atomic; the workgroup that draws the last ticket does ONE
+// fence(acquire, agent), __syncthreads, then reads all rows with plain loads.  `ticket` is reset by that
+// workgroup, so it is zero at every launch.  No placement / dispatch-order assumption, no spinning.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFitThreads = 512;
+__global__ void __launch_bounds__(kFitThreads)
+p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                         GnState* __restrict__ st, const int first, const Pose16 T0, const float4* __restrict__ nn_pts,
+                         const unsigned char* __restrict__ nn_cnt, double* __restrict__ Jst /* [7][n] */, unsigned char* __restrict__ flag,
+                         double* __restrict__ partials, unsigned* __restrict__ ticket, Mailbox* __restrict__ mb, const unsigned match_id,
+                         const double plane_thres, const double rot_thr, const double pos_thr) {
+    const int i = blockIdx.x * kFitThreads + threadIdx.x;
+    const int done = first ? 0 : st->done;
+    double T44[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T44[k] = first ? T0.m[k] : st->T[k];
+    const double last_rot = first ? 0.0 : st->last_rot, last_pos = first ? 0.0 : st->last_pos;
+    const int it = first ? 0 : st->iter;
+    if (done) return;
+    __shared__ LoamTailSmem sm;
+    __shared__ double wsum[kFitThreads / 64][32];
+    __shared__ unsigned s_ticket;
+    bool contrib = false;
+    double J[6] = {0, 0, 0, 0, 0, 0}, res = 0.0;
+    if (i < n) {
+        const int cnt = nn_cnt[i];
+        bool valid_now = false;
+        if (cnt == 5) {
+            float4 nn[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) nn[j] = nn_pts[(size_t)i * 5 + j];
+            const float px = sx[i], py = sy[i], pz = sz[i];
+            const double x = px, y = py, z = pz;
+            const float ptx = (float)(((T44[0] * x + T44[4] * y) + T44[8] * z) + T44[12]);
+            const float pty = (float)(((T44[1] * x + T44[5] * y) + T44[9] * z) + T44[13]);
+            const float ptz = (float)(((T44[2] * x + T44[6] * y) + T44[10] * z) + T44[14]);
+            valid_now = plane_residual_dev(nn, px, py, pz, ptx, pty, ptz, T44, plane_thres, J, res);
+        }
+        if (valid_now) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) Jst[(size_t)a * n + i] = J[a];
+            Jst[(size_t)6 * n + i] = res;
+            flag[i] = 1;
+            contrib = true;
+        } else if (flag[i]) {  // Q1: stale contribution of an earlier iteration
+#pragma unroll
+            for (int a = 0; a < 6; ++a) J[a] = Jst[(size_t)a * n + i];
+            res = Jst[(size_t)6 * n + i];
+            contrib = true;
+        }
+    }
+    // wave sums -> LDS -> one row per workgroup (fixed order: wave 0 + wave 1 + ...)
+    reduce_rank1_and_store(contrib, J, res, &wsum[threadIdx.x >> 6][0]);
+    __syncthreads();
+    if (threadIdx.x < 29) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kFitThreads / 64; ++w) v += wsum[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    // ---- last workgroup: Gauss-Newton tail ----
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    __syncthreads();
+    loam_tail<kFitThreads>(st, sm, nullptr, 0, partials, (int)gridDim.x, rot_thr, pos_thr, T44, last_rot, last_pos, it, mb, match_id);
+}
+
+}  // namespace fls

@@ -234,11 +234,11 @@ icp_p2p_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const
     const int lane = threadIdx.x & 63;
     double* row = partials + (size_t)blockIdx.x * kPartialStride;
 #pragma unroll
-    for (int k = 0; k < 21; ++k) { const double v = wave_sum(Hc[k]); if (lane == 0) row[k] = v; }
+    for (int k = 0; k < 21; ++k) { const double v = wave_sum_dpp(Hc[k]); if (lane == 63) row[k] = v; }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { const double v = wave_sum(Bc[k]); if (lane == 0) row[21 + k] = v; }
-    const double sr = wave_sum(res), sc = wave_sum(contrib ? 1.0 : 0.0);
-    if (lane == 0) { row[27] = sr; row[28] = sc; }
+    for (int k = 0; k < 6; ++k) { const double v = wave_sum_dpp(Bc[k]); if (lane == 63) row[21 + k] = v; }
+    const double sr = wave_sum_dpp(res), sc = wave_sum_dpp(contrib ? 1.0 : 0.0);
+    if (lane == 63) { row[27] = sr; row[28] = sc; }
     if (COUNT) count_traffic(tc, c_p, c_h, c_c);
 }
 
@@ -503,11 +503,11 @@ ndt_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const flo
     const int lane = threadIdx.x & 63;
     double* row = partials + (size_t)blockIdx.x * kPartialStride;
 #pragma unroll
-    for (int k = 0; k < 21; ++k) { const double v = wave_sum(Hc[k]); if (lane == 0) row[k] = v; }
+    for (int k = 0; k < 21; ++k) { const double v = wave_sum_dpp(Hc[k]); if (lane == 63) row[k] = v; }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { const double v = wave_sum(Bc[k]); if (lane == 0) row[21 + k] = v; }
-    const double sr = wave_sum(res), sc = wave_sum(cnt);
-    if (lane == 0) { row[27] = sr; row[28] = sc; }
+    for (int k = 0; k < 6; ++k) { const double v = wave_sum_dpp(Bc[k]); if (lane == 63) row[21 + k] = v; }
+    const double sr = wave_sum_dpp(res), sc = wave_sum_dpp(cnt);
+    if (lane == 63) { row[27] = sr; row[28] = sc; }
     if (COUNT) count_traffic(tc, c_p, c_h, c_c);
 }
 
@@ -518,53 +518,64 @@ ndt_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const flo
 __global__ void __launch_bounds__(1024)
 gn_solve_lu_kernel(GnState* __restrict__ st, const double* __restrict__ partials, const int nrows, const int mode,
                    const double rot_thr, const double pos_thr, const int min_effective) {
-    if (st->done) return;
+    const int done = st->done;
+    double Tl[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Tl[q] = st->T[q];
+    const int it = st->iter;
+    if (done) return;
     __shared__ double red[32][33];
     __shared__ double tot[32];
     __shared__ double Hs[36], inv[36], gs[6], xs[6];
     __shared__ int tr[6];
-    reduce_partials(partials, nrows, tot, red);
-    if (threadIdx.x == 0) {
-        int k = 0;
-        for (int a = 0; a < 6; ++a)
-            for (int b = a; b < 6; ++b) { Hs[a + b * 6] = tot[k]; Hs[b + a * 6] = tot[k]; ++k; }
-        for (int a = 0; a < 6; ++a) gs[a] = tot[21 + a];
-        for (int q = 0; q < 36; ++q) st->H[q] = Hs[q];
-        for (int q = 0; q < 6; ++q) st->g[q] = gs[q];
-        const int it = st->iter;
-        const int effective = (int)tot[28];
+    reduce_partials<kSolveThreads>(partials, nrows, tot, red);
+    if (threadIdx.x >= 64) return;  // wave 0 only
+    const int lane = threadIdx.x;
+    if (lane < 36) {
+        const int i = lane % 6, j = lane / 6;
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        const int k = a * 6 - (a * (a - 1)) / 2 + (b - a);
+        Hs[lane] = tot[k];
+        st->H[lane] = tot[k];
+    }
+    if (lane < 6) { gs[lane] = tot[21 + lane]; st->g[lane] = tot[21 + lane]; }
+    __builtin_amdgcn_wave_barrier();
+    const int effective = (int)tot[28];
+    const double sres = tot[27];
+    const bool early_fail = (mode == 1 && effective < min_effective);  // incremental_ndt.h:306-309: T = pose; return false
+    double det = 1.0;
+    if (!early_fail) det = lu6_solve_wave(Hs, inv, gs, xs, tr);
+    if (lane == 0) {
         st->n_valid = effective;
-        st->sum_res = tot[27];
-        bool log_now = true;
-        if (mode == 1 && effective < min_effective) {  // incremental_ndt.h:306-309: T = pose; return false
+        st->sum_res = sres;
+        if (early_fail) {
             st->done = 1;
             st->converged = 0;
+        } else if (mode == 0 && det == 0.0) {
+            // icp_optimized.h:129-131: skip the update, keep iterating
         } else {
-            const double det = lu6_inverse_det(Hs, inv, tr);
-            if (mode == 0 && det == 0.0) {
-                // icp_optimized.h:129-131: skip the update, keep iterating
-            } else {
-                for (int a = 0; a < 6; ++a) { double s = 0.0; for (int q = 0; q < 6; ++q) s += inv[a + q * 6] * gs[q]; xs[a] = s; }
-                const double* dth = (mode == 0) ? xs + 3 : xs;
-                const double* dt = (mode == 0) ? xs : xs + 3;
-                double Rd[9], R[9], Rn[9];
-                if (mode == 0) { st->T[12] += dt[0]; st->T[13] += dt[1]; st->T[14] += dt[2]; }
-                so3_exp_dev(dth, Rd);
-                for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) R[i + j * 3] = st->T[i + j * 4];
-                mat3_mul_dev(R, Rd, Rn);  // right-multiplicative
-                for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) st->T[i + j * 4] = Rn[i + j * 3];
-                if (mode == 1) { st->T[12] += dt[0]; st->T[13] += dt[1]; st->T[14] += dt[2]; }
-                for (int q = 0; q < 6; ++q) st->last_dx[q] = xs[q];
-                if (norm3d(dth) < rot_thr && norm3d(dt) < pos_thr) {
-                    st->done = 1;
-                    st->converged = 1;
-                }
+            double dx[6];
+            for (int q = 0; q < 6; ++q) dx[q] = xs[q];
+            const double* dth = (mode == 0) ? dx + 3 : dx;
+            const double* dt = (mode == 0) ? dx : dx + 3;
+            double Rd[9], R[9], Rn[9];
+            if (mode == 0) { Tl[12] += dt[0]; Tl[13] += dt[1]; Tl[14] += dt[2]; }
+            so3_exp_dev(dth, Rd);
+            for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) R[i + j * 3] = Tl[i + j * 4];
+            mat3_mul_dev(R, Rd, Rn);  // right-multiplicative
+            for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) Tl[i + j * 4] = Rn[i + j * 3];
+            if (mode == 1) { Tl[12] += dt[0]; Tl[13] += dt[1]; Tl[14] += dt[2]; }
+            for (int q = 0; q < 16; ++q) st->T[q] = Tl[q];
+            for (int q = 0; q < 6; ++q) st->last_dx[q] = dx[q];
+            if (norm3d(dth) < rot_thr && norm3d(dt) < pos_thr) {
+                st->done = 1;
+                st->converged = 1;
             }
         }
-        if (log_now && it < kMaxIter) {
-            for (int q = 0; q < 16; ++q) st->log_T[it][q] = st->T[q];
+        if (it < kMaxIter) {
+            for (int q = 0; q < 16; ++q) st->log_T[it][q] = Tl[q];
             st->log_nv[it] = effective;
-            st->log_res[it] = tot[27];
+            st->log_res[it] = sres;
         }
         st->iter = it + 1;
     }

@@ -10,6 +10,7 @@
 #include "matcher_base.hpp"
 #include "kernels_p2plane.hpp"
 #include "kernels_knn.hpp"
+#include "kernels_ivox_coop.hpp"
 #include "fitness_host.hpp"
 
 namespace fls {
@@ -18,6 +19,10 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     HostIvox ivox;
     GridImage image;
     bool image_dirty = true;
+    int expect_iters = 4;  // chunk size of the next Match = iterations the previous one needed
+    DevBuf<unsigned> d_ticket;
+    bool use_dense = true; // dense voxel window instead of the hash table when the map extent allows (FLS_IVOX_DENSE=0 disables)
+    int variant = 4;       // lanes cooperating on one query in ivox_knn_kernel: 4 or 8 (FLS_IVOX_VARIANT)
     bool is_first = true;  // the reference's function-static flag (:62), per handle here
     const double filter_size_map_min = 0.5;  // :351
 
@@ -41,6 +46,10 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (unset_d(p.point_to_planar_thres) || unset_d(p.position_converge_thres) || unset_d(p.rotation_converge_thres))
             return FLS_ERR_INVALID;  // CHECK_NE(..., max()) at :45-48
         init_common();
+        if (const char* e = std::getenv("FLS_IVOX_VARIANT")) { const int v = std::atoi(e); if (v == 4 || v == 8) variant = v; }
+        if (const char* e = std::getenv("FLS_IVOX_DENSE")) use_dense = std::atoi(e) != 0;
+        d_ticket.reserve(1);
+        FLS_HIP(hipMemsetAsync(d_ticket.p, 0, sizeof(unsigned), stream));
         ivox.resolution = 0.5f;       // InitIVox :53-58
         ivox.inv_resolution = 1.0f / 0.5f;
         ivox.capacity = 1000000;
@@ -136,9 +145,19 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         return FLS_OK;
     }
 
+    template <int G>
+    void launch_knn(const size_t n, const int first, const Pose16& T0, const DevGrid& g, const DenseWindow& win) {
+        const dim3 grid(unsigned((((n * G + 255) / 256) + 7) / 8 * 8));  // multiple of 8: XCD re-map is a bijection
+#define FLS_KNN(C, D)                                                                                                                \
+    hipLaunchKernelGGL((ivox_knn_kernel<G, C, D>), grid, dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, first, T0, g, \
+                       win, ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p)
+        if (win.cells) { if (count_traffic) FLS_KNN(true, true); else FLS_KNN(false, true); }
+        else { if (count_traffic) FLS_KNN(true, false); else FLS_KNN(false, false); }
+#undef FLS_KNN
+    }
+
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
         const size_t n = scan.n;
-        const int nblk = int((n + 63) / 64);
         number_planar_point = n;
         stats = fls_stats{};
         stats.n_source = int(n);
@@ -147,7 +166,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             // empty planar cloud: H = g = 0 -> dx = 0 -> stop rule fires in iteration 0, n_valid = 0 < 50 -> false (:201-203)
             stats.iterations = 1; stats.converged = 0;
             if (out) *out = stats;
-            log_n = 0;
+            log_n = 0; log_stale = false;
             return FLS_NOT_CONVERGED;
         }
         refresh_image();
@@ -157,40 +176,62 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (n > nn_n) FLS_HIP(hipMemsetAsync(d_nn_cnt.p + nn_n, 0, n - nn_n, stream));
         nn_n = n;
         d_J.reserve(7 * n);
-        d_flag.reserve(n);
-        FLS_HIP(hipMemsetAsync(d_flag.p, 0, n, stream));  // std::fill(flags, false) once per Match (:156, Q1)
-        d_partials_b.reserve(size_t(nblk) * kPartialStride);
-        push_state(T);
+        d_flag.reserve(n);  // cleared by the first iteration's kNN kernel (std::fill(flags, false) once per Match, :156, Q1)
+        const int nwg = int((n + kFitThreads - 1) / kFitThreads);
+        d_partials_b.reserve(size_t(nwg) * kPartialStride);
+        if (count_traffic) FLS_HIP(hipMemsetAsync(d_tc.p, 0, sizeof(TrafficCounters), stream));
         const int iters = int(p.max_iterations);
         if (profiling) ensure_events(iters);
         const DevGrid g = image.dev();
-        for (int it = 0; it < iters; ++it) {
-            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
-            if (count_traffic)
-                hipLaunchKernelGGL(p2plane_ivox_kernel<true>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),
-                                   d_state.p, g, ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,
-                                   p.point_to_planar_thres, d_tc.p);
-            else
-                hipLaunchKernelGGL(p2plane_ivox_kernel<false>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),
-                                   d_state.p, g, ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,
-                                   p.point_to_planar_thres, d_tc.p);
-            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
-            hipLaunchKernelGGL(gn_solve_loam_kernel, dim3(1), dim3(1024), 0, stream, d_state.p, (const double*)nullptr, 0,
-                               (const double*)d_partials_b.p, nblk, p.rotation_converge_thres, p.position_converge_thres);
+        const DenseWindow win = use_dense ? image.window() : DenseWindow{nullptr, 0, 0, 0, 0, 0, 0};
+        Pose16 T0;
+        std::memcpy(T0.m, T, sizeof(T0.m));
+        match_id = (match_id + 1) & 0x7fffffu;
+        // Iterations are enqueued in chunks sized by the previous Match (steady-state SLAM needs about the same
+        // number every scan); the device decides convergence, kernels of a converged Match exit at once, and the
+        // host learns the outcome from the mailbox without a blocking synchronisation.
+        int launched = 0;
+        unsigned word = 0;
+        int chunk = std::max(1, std::min(iters, expect_iters));
+        for (;;) {
+            const int end = std::min(iters, launched + chunk);
+            for (int it = launched; it < end; ++it) {
+                const int first = it == 0 ? 1 : 0;
+                if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
+                if (variant == 4) launch_knn<4>(n, first, T0, g, win); else launch_knn<8>(n, first, T0, g, win);
+                if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
+                hipLaunchKernelGGL(p2plane_fit_solve_kernel, dim3(nwg), dim3(kFitThreads), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),
+                                   d_state.p, first, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p,
+                                   d_partials_b.p, d_ticket.p, mb_dev, match_id, p.point_to_planar_thres, p.rotation_converge_thres,
+                                   p.position_converge_thres);
+            }
+            launched = end;
+            FLS_HIP(hipGetLastError());
+            word = wait_mailbox(launched);
+            if (((word >> 8) & 1u) || launched >= iters) break;
+            chunk = 2;
         }
-        FLS_HIP(hipGetLastError());
-        pull_state(n);
-        const GnState& s = *h_state.p;
-        std::memcpy(T, s.T, sizeof(double) * 16);
-        std::memcpy(T_, s.T, sizeof(T_));
-        std::memcpy(final_T, s.T, sizeof(final_T));
+        const Mailbox& mb = *mb_host;
+        const int used = int(word & 0xffu);
+        expect_iters = std::max(2, used);
+        log_stale = true;
+        log_n = std::min(used, kMaxIter);
+        account_profile(used, n);
+        if (count_traffic) {
+            FLS_HIP(hipMemcpyAsync(h_tc.p, d_tc.p, sizeof(TrafficCounters), hipMemcpyDeviceToHost, stream));
+            FLS_HIP(hipStreamSynchronize(stream));
+            last_tc = *h_tc.p;
+        }
+        std::memcpy(T, mb.T, sizeof(double) * 16);
+        std::memcpy(T_, mb.T, sizeof(T_));
+        std::memcpy(final_T, mb.T, sizeof(final_T));
         have_final = true;
         bool has_converge = true;
-        if (s.n_valid < 50) has_converge = false;  // :201-203
-        stats.iterations = s.iter;
-        stats.n_valid = s.n_valid;
-        stats.sum_res = s.sum_res;
-        std::memcpy(stats.last_dx, s.last_dx, sizeof(stats.last_dx));
+        if (mb.n_valid < 50) has_converge = false;  // :201-203
+        stats.iterations = used;
+        stats.n_valid = mb.n_valid;
+        stats.sum_res = mb.sum_res;
+        std::memcpy(stats.last_dx, mb.last_dx, sizeof(stats.last_dx));
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
         if (has_converge && !p.is_localization_mode && update_map) {  // :205-206

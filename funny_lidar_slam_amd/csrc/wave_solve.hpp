@@ -1,0 +1,270 @@
+// wave_solve.hpp -- wavefront-cooperative pieces of the Gauss-Newton tail (gfx950, wave64):
+//
+//   wave_sum_dpp          64-lane FP64 sum with DPP row shifts / row broadcasts (no LDS round trips):
+//                         row_shr 1,2,4,8 -> row_bcast15 -> row_bcast31; total lands in lane 63.
+//                         Fixed tree => bit-reproducible.  Replaces the ds_bpermute shuffle chain that
+//                         cost ~20k cycles per wave for the 29 sums of the normal equations.
+//   fullpiv_qr_solve6_wave  Eigen FullPivHouseholderQR<6x6>::solve semantics (pivot order, rank rule,
+//                         zero fill) executed by ONE wave: lane l < 36 owns element (l % 6, l / 6) of the
+//                         LDS-resident matrix; pivot search, row/column swaps and the Householder update of
+//                         all trailing columns happen in parallel; the rhs lives in lanes 0..5 and moves
+//                         by v_readlane.  Same arithmetic expressions, same summation order as
+//                         linalg_dev.hpp::fullpiv_qr_solve6 (and therefore as the CPU path) -- only the
+//                         single-thread LDS latency chain (~29 us per iteration) is gone.
+//   lu6_solve_wave        PartialPivLU<6x6>: determinant, explicit inverse, inverse * b for ICP / NDT.
+#pragma once
+#include "linalg_dev.hpp"
+
+namespace fls {
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(const double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi2, lo2);
+}
+// after the call lane 63 holds the sum over all 64 lanes (other lanes hold partial prefix sums)
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3
+    return v;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max(const double v) {  // operands are >= -1: a zero fill never wins wrongly
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(__double2loint(-1.0), lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(__double2hiint(-1.0), hi, CTRL, ROW_MASK, 0xf, false);
+    const double o = __hiloint2double(hi2, lo2);
+    return o > v ? o : v;
+}
+// maximum over the 64 lanes, valid in lane 63 (same tree as wave_sum_dpp)
+__device__ __forceinline__ double wave_max_dpp(double v) {
+    v = dpp_max<0x111, 0xf>(v);
+    v = dpp_max<0x112, 0xf>(v);
+    v = dpp_max<0x114, 0xf>(v);
+    v = dpp_max<0x118, 0xf>(v);
+    v = dpp_max<0x142, 0xa>(v);
+    v = dpp_max<0x143, 0xc>(v);
+    return v;
+}
+
+__device__ __forceinline__ double readlane_f64(const double v, const int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// M: LDS, 36 doubles column-major, holds H on entry (destroyed).  g_in: rhs (uniform pointer, 6 doubles).
+// Result x[6] is returned in lanes 0..5 (value of lane i = x[i]) and written to xs (LDS, 6 doubles).
+// Must be called by all 64 lanes of exactly one wave.
+// ---------------------------------------------------------------------------------------------
+__device__ inline void fullpiv_qr_solve6_wave(double* M, const double* g_in, double* xs, double* hcoef /*LDS 6*/,
+                                              int* rows_tr /*LDS 6*/, int* cols_tr /*LDS 6*/) {
+    const int lane = threadIdx.x & 63;
+    const int l = lane < 36 ? lane : 35;
+    const int i = l % 6, j = l / 6;
+    const double precision = FLS_DBL_EPS * 6.0;
+    double biggest = 0.0, maxpivot = 0.0;
+    int nonzero_pivots = 6;
+    for (int k = 0; k < 6; ++k) {
+        // 1. pivot: largest |entry| of the bottom-right corner, first in column-major order on ties
+        const double a = (lane < 36 && i >= k && j >= k) ? fabs(M[l]) : -1.0;
+        const double mx = readlane_f64(wave_max_dpp(a), 63);
+        const unsigned long long eq = __ballot(a == mx);
+        const int piv = __ffsll((long long)eq) - 1;
+        const int rb = piv % 6, cb = piv / 6;
+        if (k == 0) biggest = mx;
+        if (fabs(mx) <= fabs(biggest) * precision) {  // isMuchSmallerThan: the rest of the corner is negligible
+            nonzero_pivots = k;
+            if (lane >= k && lane < 6) { rows_tr[lane] = lane; cols_tr[lane] = lane; hcoef[lane] = 0.0; }
+            break;
+        }
+        if (lane == 0) { rows_tr[k] = rb; cols_tr[k] = cb; }
+        // 2. row swap (columns >= k only) then column swap (all rows), as one gather
+        const int jp = (j == k) ? cb : (j == cb ? k : j);
+        const int ip = (jp >= k) ? ((i == k) ? rb : (i == rb ? k : i)) : i;
+        const double moved = M[ip + 6 * jp];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 36) M[l] = moved;
+        __builtin_amdgcn_wave_barrier();
+        // 3. one batch of LDS reads: column k (uniform addresses -> broadcast) and this lane's own column j.
+        //    Everything below works on registers with loops unrolled over r = 0..5 and predicated on r > k,
+        //    i.e. one LDS round trip per step instead of one per term of the sums.
+        double ck[6], cj[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { ck[r] = M[r + 6 * k]; cj[r] = M[r + 6 * j]; }
+        double c0 = 0.0, tail = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if (r == k) c0 = ck[r];
+            if (r > k) tail += ck[r] * ck[r];
+        }
+        double tau, beta, den = 1.0;
+        const bool trivial = (k == 5) || tail <= FLS_DBL_MIN;
+        if (trivial) { tau = 0.0; beta = c0; }
+        else {
+            beta = sqrt(c0 * c0 + tail);
+            if (c0 >= 0.0) beta = -beta;
+            den = c0 - beta;
+            tau = (beta - c0) / beta;
+        }
+        // essential part ess[r] = ck[r] / den (r > k): every lane needs all of them for its tmp -> computed
+        // redundantly (5 divisions in flight, independent) rather than via another LDS round trip
+        double ess[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ess[r] = (r > k && !trivial) ? ck[r] / den : 0.0;
+        // 4. new value of this lane's element
+        double mine = 0.0, ess_i = 0.0, cjk = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if (r == i) { mine = cj[r]; ess_i = ess[r]; }
+            if (r == k) cjk = cj[r];
+        }
+        if (j == k) {
+            if (i == k) mine = beta;
+            else if (i > k) mine = ess_i;  // (0 when trivial)
+        } else if (j > k && i >= k && tau != 0.0) {
+            double tmp = 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                if (r > k) tmp += ess[r] * cj[r];
+            tmp += cjk;
+            if (i == k) mine -= tau * tmp;
+            else mine -= (tau * ess_i) * tmp;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 36 && j >= k) M[l] = mine;
+        if (lane == 0) hcoef[k] = tau;
+        __builtin_amdgcn_wave_barrier();
+        if (fabs(beta) > maxpivot) maxpivot = fabs(beta);
+    }
+    // rank(): pivots above eps * 6 * |maxpivot|
+    const double premult = fabs(maxpivot) * (FLS_DBL_EPS * 6.0);
+    int rank = 0;
+    for (int q = 0; q < nonzero_pivots; ++q) rank += (fabs(M[q + 6 * q]) > premult) ? 1 : 0;
+    // column permutation: identity, then transposition (k, cols_tr[k]) for k = 0..5   (uniform loop)
+    int perm_of_lane = lane;  // lanes 0..5: perm[lane]
+    for (int k = 0; k < 6; ++k) {
+        const int ct = cols_tr[k];
+        const int pk = __builtin_amdgcn_readlane(perm_of_lane, k), pc = __builtin_amdgcn_readlane(perm_of_lane, ct);
+        if (lane == k) perm_of_lane = pc;
+        if (lane == ct) perm_of_lane = pk;
+        if (k == ct && lane == k) perm_of_lane = pk;
+    }
+    // c = Q^T g on lanes 0..5
+    double c = lane < 6 ? g_in[lane] : 0.0;
+    for (int k = 0; k < rank; ++k) {
+        const int rt = rows_tr[k];
+        const double ck = readlane_f64(c, k), crt = readlane_f64(c, rt);
+        if (lane == k) c = crt;
+        if (lane == rt) c = ck;
+        if (k == rt && lane == k) c = ck;
+        const double tau = hcoef[k];
+        if (k < 5 && tau != 0.0) {
+            double tmp = 0.0;
+            for (int r = k + 1; r < 6; ++r) tmp += M[r + 6 * k] * readlane_f64(c, r);
+            tmp += readlane_f64(c, k);
+            if (lane == k) c -= tau * tmp;
+            else if (lane > k && lane < 6) c -= (tau * M[lane + 6 * k]) * tmp;
+        } else if (k == 5) {
+            if (lane == 5) c *= (1.0 - tau);  // rows == 1 case of applyHouseholderOnTheLeft
+        }
+    }
+    // back substitution on the leading rank x rank triangle (column oriented)
+    for (int q = rank - 1; q >= 0; --q) {
+        const double cq = readlane_f64(c, q) / M[q + 6 * q];
+        if (lane == q) c = cq;
+        else if (lane < q) c -= cq * M[lane + 6 * q];
+    }
+    // x[perm[q]] = c[q] for q < rank, 0 elsewhere
+    if (lane < 6) xs[lane] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rank) xs[perm_of_lane] = c;
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+// PartialPivLU<6x6> by one wave.  M: LDS 36 (H on entry, LU on exit), inv: LDS 36 (out), b: 6 doubles.
+// Returns the determinant (uniform); xs[6] (LDS) = inverse * b, summed in column order like the CPU path.
+// ---------------------------------------------------------------------------------------------
+__device__ inline double lu6_solve_wave(double* M, double* inv, const double* b, double* xs, int* row_tr /*LDS 6*/) {
+    const int lane = threadIdx.x & 63;
+    const int l = lane < 36 ? lane : 35;
+    const int i = l % 6, j = l / 6;
+    int ntr = 0;
+    for (int k = 0; k < 6; ++k) {
+        // partial pivot in column k, first maximum wins
+        int rb = k;
+        double bc = fabs(M[k + 6 * k]);
+        for (int r = k + 1; r < 6; ++r) { const double v = fabs(M[r + 6 * k]); if (v > bc) { bc = v; rb = r; } }
+        if (lane == 0) row_tr[k] = rb;
+        if (bc != 0.0 && rb != k) {
+            const int ip = (i == k) ? rb : (i == rb ? k : i);
+            const double moved = M[ip + 6 * j];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 36) M[l] = moved;
+            __builtin_amdgcn_wave_barrier();
+            ++ntr;
+        }
+        double mine = M[l];
+        const double pivot = M[k + 6 * k];
+        if (bc != 0.0 && j == k && i > k) mine = mine / pivot;
+        // trailing update uses the scaled column: lu(i,j) -= lu(i,k) * lu(k,j)
+        if (j > k && i > k) {
+            const double lik = (bc != 0.0) ? M[i + 6 * k] / pivot : M[i + 6 * k];
+            mine -= lik * M[k + 6 * j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 36) M[l] = mine;
+        __builtin_amdgcn_wave_barrier();
+    }
+    double det = M[0];
+    for (int q = 1; q < 6; ++q) det *= M[q + 6 * q];
+    det = (ntr & 1) ? -det : det;
+    // inverse: lanes 0..5 each solve one column of P * I
+    if (lane < 6) {
+        double c[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) c[r] = (r == lane) ? 1.0 : 0.0;
+        // apply the row transpositions to the identity column e_lane: rows swap k <-> row_tr[k] in order
+        for (int k = 0; k < 6; ++k) {
+            const int rt = row_tr[k];
+            if (rt != k) {
+                double a = 0.0, bb = 0.0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { if (r == k) a = c[r]; if (r == rt) bb = c[r]; }
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { if (r == k) c[r] = bb; else if (r == rt) c[r] = a; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int r = q + 1; r < 6; ++r) c[r] -= c[q] * M[r + 6 * q];
+#pragma unroll
+        for (int q = 5; q >= 0; --q) {
+            c[q] /= M[q + 6 * q];
+#pragma unroll
+            for (int r = 0; r < q; ++r) c[r] -= c[q] * M[r + 6 * q];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) inv[r + 6 * lane] = c[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 6) {
+        double s = 0.0;
+        for (int q = 0; q < 6; ++q) s += inv[lane + 6 * q] * b[q];
+        xs[lane] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return det;
+}
+
+}  // namespace fls

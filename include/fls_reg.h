@@ -160,6 +160,9 @@ fls_status fls_get_kernel_time(fls_handle h, double* ms_total, int64_t* launches
 /* traffic counters of the last Match run with flag bit 1 set */
 fls_status fls_get_traffic_counters(fls_handle h, uint64_t* probes, uint64_t* hit_voxels, uint64_t* cand_points);
 
+/* shader-clock stamps of the solve kernel's phases of the last iteration (only filled by -DFLS_TIMING builds) */
+fls_status fls_get_debug_stamps(fls_handle h, int64_t out[16]);
+
 const char* fls_status_string(int status);
 int fls_abi_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => every compute call fails with FLS_ERR_DEVICE) */

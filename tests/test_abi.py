@@ -80,3 +80,31 @@ def test_product_does_not_reference_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def _build_adapter(tmp_path):
+    import subprocess
+    exe = os.path.join(str(tmp_path), "adapter_smoke")
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "tests", "stubs"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "stubs", "adapter_smoke.cpp"), "-o", exe, "-L" + os.path.dirname(_lib.LIB_PATH), "-lfls_reg",
+           "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_cpp_adapter_compiles_and_links(built, tmp_path):
+    """include/fls_hip_registration.h (RegistrationInterface on top of the C ABI) builds with plain g++
+    against stand-in reference headers and links to libfls_reg.so."""
+    import subprocess
+    exe = _build_adapter(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "adapter compiled" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_adapter_runs_on_gpu(built, tmp_path):
+    import subprocess
+    exe = _build_adapter(tmp_path)
+    out = subprocess.run([exe, "run"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ok=1" in out.stdout
