@@ -116,10 +116,13 @@ def main():
     cluster = reg.PointcloudCluster(planar_cloud_=cfg["scan"])
     m.UploadScan(cluster)  # inputs resident in HBM before the timed region
 
+    T_work = np.empty((4, 4))
+    T_init = cfg["T_init"]
+
     def step():
-        T = cfg["T_init"].copy()
-        ok = m.MatchResident(T, update_map=False)
-        return ok, T
+        T_work[...] = T_init  # every step registers from the same initial guess (identity)
+        ok = m.MatchResident(T_work, update_map=False)
+        return ok, T_work
 
     for _ in range(args.warmup):
         step()
@@ -146,8 +149,10 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        poses = [torch.zeros(16, dtype=torch.float64, device="cuda") for _ in range(world)]
-        dist.all_gather(poses, torch.from_numpy(T.reshape(-1).copy()).cuda())
+        from funny_lidar_slam_amd import batch
+        row = batch.pack_result(T, ok, m.stats.iterations, m.stats.n_valid, m.stats.sum_res)
+        table = batch.gather_results(row[None, :], world, batch.RESULT_WIDTH, device="cuda")  # one job per rank per step
+        assert table.shape == (world, batch.RESULT_WIDTH)
 
     if rank == 0:
         total_scans = args.steps * n_gpus

@@ -1,0 +1,63 @@
+"""Sharding of independent scan-to-map registration jobs over the GPUs of one node.
+
+BASELINE.json configs[4]: a batch of independent 64x1800 scan-to-map jobs sharded over 8 MI355X.
+One registration is single-GPU; independent jobs partition with NO data-path
+collective: every rank owns a contiguous block of job ids (deterministic, static), runs them on its own
+GPU against a replica of the map, and the results are gathered once at the end (RCCL all_gather when the
+process group is nccl, gloo in the CPU tests).  Per-job state is per handle (reference quirk Q12).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence, Tuple
+
+import numpy as np
+
+
+def partition(n_jobs: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """[begin, end) of the block of job ids owned by `rank` (block partition, sizes differ by <= 1)."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad world_size / rank")
+    base, extra = divmod(n_jobs, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def run_block(worker: Callable[[int], np.ndarray], begin: int, end: int) -> np.ndarray:
+    """Run jobs [begin, end) with `worker(job_id) -> flat float64 result vector`; rows = jobs."""
+    rows = [np.asarray(worker(j), dtype=np.float64).reshape(-1) for j in range(begin, end)]
+    return np.stack(rows) if rows else np.zeros((0, 0))
+
+
+def gather_results(local: np.ndarray, n_jobs: int, width: int, device=None) -> np.ndarray:
+    """All ranks end up with the (n_jobs, width) table, rows ordered by job id.
+
+    Uses torch.distributed (nccl == RCCL on ROCm, gloo on CPU).  Blocks are padded to the largest block so
+    that one fixed-size all_gather suffices (the payload is tiny: 20 doubles per job)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        return np.asarray(local, dtype=np.float64).reshape(n_jobs, width)
+    sizes = [partition(n_jobs, world, r) for r in range(world)]
+    cap = max(e - b for b, e in sizes)
+    buf = torch.zeros((cap, width), dtype=torch.float64, device=device)
+    b, e = sizes[rank]
+    if e > b:
+        buf[: e - b] = torch.from_numpy(np.asarray(local, dtype=np.float64).reshape(e - b, width)).to(buf.device)
+    out = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    table = np.zeros((n_jobs, width))
+    for r, (rb, re_) in enumerate(sizes):
+        if re_ > rb:
+            table[rb:re_] = out[r][: re_ - rb].cpu().numpy()
+    return table
+
+
+def pack_result(T: np.ndarray, ok: bool, iterations: int, n_valid: int, sum_res: float) -> np.ndarray:
+    """Job result row: 16 pose doubles (row-major 4x4) + [ok, iterations, n_valid, sum_res]."""
+    return np.concatenate([np.asarray(T, dtype=np.float64).reshape(16), [float(ok), float(iterations), float(n_valid), float(sum_res)]])
+
+
+RESULT_WIDTH = 20

@@ -281,6 +281,9 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
     __shared__ LoamTailSmem sm;
     __shared__ double wsum[kFitThreads / 64][32];
     __shared__ unsigned s_ticket;
+#ifdef FLS_TIMING
+    const long long t_begin = (long long)__builtin_readcyclecounter();
+#endif
     bool contrib = false;
     double J[6] = {0, 0, 0, 0, 0, 0}, res = 0.0;
     if (i < n) {
@@ -328,6 +331,10 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
     __syncthreads();
     if (s_ticket != gridDim.x - 1) return;
     // ---- last workgroup: Gauss-Newton tail ----
+#ifdef FLS_TIMING
+    if (threadIdx.x == 0) st->dbg[0] = t_begin;
+#endif
+    FLS_STAMP(1);
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch

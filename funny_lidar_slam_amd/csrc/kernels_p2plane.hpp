@@ -124,6 +124,12 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
     __syncthreads();
 }
 
+#ifdef FLS_TIMING
+#define FLS_STAMP(k) do { if (threadIdx.x == 0) st->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define FLS_STAMP(k) do { } while (0)
+#endif
+
 // shared memory of the LOAM-family Gauss-Newton tail
 struct LoamTailSmem {
     double red[32][33];
@@ -146,8 +152,10 @@ __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem
                                           const unsigned match_id = 0u) {
     if (nrows_a > 0) reduce_partials<NT>(partials_a, nrows_a, sm.tot_a, sm.red);
     else { if (threadIdx.x < 32) sm.tot_a[threadIdx.x] = 0.0; __syncthreads(); }
+    FLS_STAMP(2);
     reduce_partials<NT>(partials_b, nrows_b, sm.tot_b, sm.red);
     if (threadIdx.x >= 64) return;  // wave 0 only from here on
+    FLS_STAMP(3);
     const int lane = threadIdx.x;
     if (lane < 36) {
         const int i = lane % 6, j = lane / 6;
@@ -159,7 +167,12 @@ __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem
     }
     if (lane < 6) { const double v = sm.tot_a[21 + lane] + sm.tot_b[21 + lane]; sm.gs[lane] = v; st->g[lane] = v; }
     __builtin_amdgcn_wave_barrier();
+#ifdef FLS_TIMING
+    fullpiv_qr_solve6_wave(sm.Hs, sm.gs, sm.xs, sm.hc, sm.tr, sm.ctr, st->dbg);
+#else
     fullpiv_qr_solve6_wave(sm.Hs, sm.gs, sm.xs, sm.hc, sm.tr, sm.ctr);
+#endif
+    FLS_STAMP(4);
     if (lane == 0) {
         double dx[6];
         for (int q = 0; q < 6; ++q) dx[q] = sm.xs[q];
@@ -206,6 +219,7 @@ __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem
             __hip_atomic_store(&mb->seq, (match_id << 9) | ((unsigned)stop << 8) | (unsigned)(it + 1), __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        FLS_STAMP(5);
     }
 }
 

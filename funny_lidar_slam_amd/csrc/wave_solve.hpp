@@ -62,11 +62,12 @@ __device__ __forceinline__ double readlane_f64(const double v, const int lane) {
 
 // ---------------------------------------------------------------------------------------------
 // M: LDS, 36 doubles column-major, holds H on entry (destroyed).  g_in: rhs (uniform pointer, 6 doubles).
-// Result x[6] is returned in lanes 0..5 (value of lane i = x[i]) and written to xs (LDS, 6 doubles).
+// Result x[6] is written to xs (LDS, 6 doubles).
 // Must be called by all 64 lanes of exactly one wave.
 // ---------------------------------------------------------------------------------------------
 __device__ inline void fullpiv_qr_solve6_wave(double* M, const double* g_in, double* xs, double* hcoef /*LDS 6*/,
-                                              int* rows_tr /*LDS 6*/, int* cols_tr /*LDS 6*/) {
+                                              int* rows_tr /*LDS 6*/, int* cols_tr /*LDS 6*/, long long* dbg = nullptr) {
+#define QR_STAMP(q) do { if (dbg && (threadIdx.x & 63) == 0) dbg[q] = (long long)__builtin_readcyclecounter(); } while (0)
     const int lane = threadIdx.x & 63;
     const int l = lane < 36 ? lane : 35;
     const int i = l % 6, j = l / 6;
@@ -77,6 +78,7 @@ __device__ inline void fullpiv_qr_solve6_wave(double* M, const double* g_in, dou
         // 1. pivot: largest |entry| of the bottom-right corner, first in column-major order on ties
         const double a = (lane < 36 && i >= k && j >= k) ? fabs(M[l]) : -1.0;
         const double mx = readlane_f64(wave_max_dpp(a), 63);
+        if (k == 0) QR_STAMP(6);
         const unsigned long long eq = __ballot(a == mx);
         const int piv = __ffsll((long long)eq) - 1;
         const int rb = piv % 6, cb = piv / 6;
@@ -94,12 +96,14 @@ __device__ inline void fullpiv_qr_solve6_wave(double* M, const double* g_in, dou
         __builtin_amdgcn_wave_barrier();
         if (lane < 36) M[l] = moved;
         __builtin_amdgcn_wave_barrier();
+        if (k == 0) QR_STAMP(7);
         // 3. one batch of LDS reads: column k (uniform addresses -> broadcast) and this lane's own column j.
         //    Everything below works on registers with loops unrolled over r = 0..5 and predicated on r > k,
         //    i.e. one LDS round trip per step instead of one per term of the sums.
         double ck[6], cj[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) { ck[r] = M[r + 6 * k]; cj[r] = M[r + 6 * j]; }
+        if (k == 0) QR_STAMP(8);
         double c0 = 0.0, tail = 0.0;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -115,6 +119,7 @@ __device__ inline void fullpiv_qr_solve6_wave(double* M, const double* g_in, dou
             den = c0 - beta;
             tau = (beta - c0) / beta;
         }
+        if (k == 0) QR_STAMP(9);
         // essential part ess[r] = ck[r] / den (r > k): every lane needs all of them for its tmp -> computed
         // redundantly (5 divisions in flight, independent) rather than via another LDS round trip
         double ess[6];
@@ -139,55 +144,83 @@ __device__ inline void fullpiv_qr_solve6_wave(double* M, const double* g_in, dou
             if (i == k) mine -= tau * tmp;
             else mine -= (tau * ess_i) * tmp;
         }
+        if (k == 0) QR_STAMP(10);
         __builtin_amdgcn_wave_barrier();
         if (lane < 36 && j >= k) M[l] = mine;
         if (lane == 0) hcoef[k] = tau;
         __builtin_amdgcn_wave_barrier();
         if (fabs(beta) > maxpivot) maxpivot = fabs(beta);
     }
+    QR_STAMP(11);
+    // ---- solve phase: uniform work, done redundantly by every lane on registers (no cross-lane traffic, one
+    // batch of broadcast LDS reads).  Loops are fully unrolled; run-time pivot indices become predicated swaps.
+    __builtin_amdgcn_wave_barrier();
+    double A[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) A[q] = M[q];
+    double hcf[6];
+    int rtr[6], ctr[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { hcf[q] = hcoef[q]; rtr[q] = rows_tr[q]; ctr[q] = cols_tr[q]; }
     // rank(): pivots above eps * 6 * |maxpivot|
     const double premult = fabs(maxpivot) * (FLS_DBL_EPS * 6.0);
     int rank = 0;
-    for (int q = 0; q < nonzero_pivots; ++q) rank += (fabs(M[q + 6 * q]) > premult) ? 1 : 0;
-    // column permutation: identity, then transposition (k, cols_tr[k]) for k = 0..5   (uniform loop)
-    int perm_of_lane = lane;  // lanes 0..5: perm[lane]
+#pragma unroll
+    for (int q = 0; q < 6; ++q) rank += (q < nonzero_pivots && fabs(A[q + 6 * q]) > premult) ? 1 : 0;
+    // column permutation: identity, then transposition (k, cols_tr[k]) for k = 0..5
+    int perm[6] = {0, 1, 2, 3, 4, 5};
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const int ct = cols_tr[k];
-        const int pk = __builtin_amdgcn_readlane(perm_of_lane, k), pc = __builtin_amdgcn_readlane(perm_of_lane, ct);
-        if (lane == k) perm_of_lane = pc;
-        if (lane == ct) perm_of_lane = pk;
-        if (k == ct && lane == k) perm_of_lane = pk;
+#pragma unroll
+        for (int m = k + 1; m < 6; ++m)  // cols_tr[k] >= k always
+            if (ctr[k] == m) { const int t = perm[k]; perm[k] = perm[m]; perm[m] = t; }
     }
-    // c = Q^T g on lanes 0..5
-    double c = lane < 6 ? g_in[lane] : 0.0;
-    for (int k = 0; k < rank; ++k) {
-        const int rt = rows_tr[k];
-        const double ck = readlane_f64(c, k), crt = readlane_f64(c, rt);
-        if (lane == k) c = crt;
-        if (lane == rt) c = ck;
-        if (k == rt && lane == k) c = ck;
-        const double tau = hcoef[k];
-        if (k < 5 && tau != 0.0) {
-            double tmp = 0.0;
-            for (int r = k + 1; r < 6; ++r) tmp += M[r + 6 * k] * readlane_f64(c, r);
-            tmp += readlane_f64(c, k);
-            if (lane == k) c -= tau * tmp;
-            else if (lane > k && lane < 6) c -= (tau * M[lane + 6 * k]) * tmp;
-        } else if (k == 5) {
-            if (lane == 5) c *= (1.0 - tau);  // rows == 1 case of applyHouseholderOnTheLeft
+    // c = Q^T g
+    double c[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) c[q] = g_in[q];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (k < rank) {
+#pragma unroll
+            for (int m = k + 1; m < 6; ++m)  // rows_tr[k] >= k always
+                if (rtr[k] == m) { const double t = c[k]; c[k] = c[m]; c[m] = t; }
+            const double tau = hcf[k];
+            if (k == 5) c[5] *= (1.0 - tau);  // rows == 1 case of applyHouseholderOnTheLeft
+            else if (tau != 0.0) {
+                double tmp = 0.0;
+#pragma unroll
+                for (int r = k + 1; r < 6; ++r) tmp += A[r + 6 * k] * c[r];
+                tmp += c[k];
+                c[k] -= tau * tmp;
+#pragma unroll
+                for (int r = k + 1; r < 6; ++r) c[r] -= (tau * A[r + 6 * k]) * tmp;
+            }
         }
     }
     // back substitution on the leading rank x rank triangle (column oriented)
-    for (int q = rank - 1; q >= 0; --q) {
-        const double cq = readlane_f64(c, q) / M[q + 6 * q];
-        if (lane == q) c = cq;
-        else if (lane < q) c -= cq * M[lane + 6 * q];
+#pragma unroll
+    for (int q = 5; q >= 0; --q) {
+        if (q < rank) {
+            c[q] /= A[q + 6 * q];
+#pragma unroll
+            for (int r = 0; r < q; ++r) c[r] -= c[q] * A[r + 6 * q];
+        }
     }
     // x[perm[q]] = c[q] for q < rank, 0 elsewhere
-    if (lane < 6) xs[lane] = 0.0;
+    double x[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+            if (q < rank && perm[q] == m) x[m] = c[q];
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) xs[q] = x[q];
+    }
     __builtin_amdgcn_wave_barrier();
-    if (lane < rank) xs[perm_of_lane] = c;
-    __builtin_amdgcn_wave_barrier();
+    QR_STAMP(12);
+#undef QR_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------

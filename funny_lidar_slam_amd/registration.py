@@ -109,12 +109,19 @@ class RegistrationInterface:
             raise FlsError(rc, "fls_scan_upload")
 
     def MatchResident(self, T: np.ndarray, update_map: bool = False) -> bool:
-        Tf = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4).T).reshape(-1)
-        rc = _lib.lib().fls_match_resident(self._h, Tf.ctypes.data_as(C.POINTER(C.c_double)), 1 if update_map else 0,
-                                           C.byref(self.stats))
+        # hot in bench.py: one preallocated column-major pose buffer, no per-call ctypes object construction
+        buf = getattr(self, "_Tbuf", None)
+        if buf is None:
+            buf = self._Tbuf = np.zeros(16, dtype=np.float64)
+            self._Tptr = buf.ctypes.data_as(C.POINTER(C.c_double))
+            self._Tview = buf.reshape(4, 4)  # row r of the view = column r of the pose
+            self._stats_ref = C.byref(self.stats)
+            self._fn_resident = _lib.lib().fls_match_resident
+        self._Tview[...] = T.T
+        rc = self._fn_resident(self._h, self._Tptr, 1 if update_map else 0, self._stats_ref)
         if rc < 0:
             raise FlsError(rc, "fls_match_resident")
-        T[...] = Tf.reshape(4, 4).T
+        T[...] = self._Tview.T
         return rc == _lib.FLS_OK
 
     # -- introspection --------------------------------------------------------------------------
