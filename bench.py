@@ -170,7 +170,7 @@ def main():
                                    "(LoamPointToPlaneIVOX semantics, YAML config_nclt.yaml) into a 1e6-pt iVox map, 1 scan per GPU per step",
                        "scan_points": int(cfg["scan"].shape[0]), "map_points": int(cfg["map"].shape[0]),
                        "gn_iterations": int(iters), "converged": bool(ok), "pose_err_vs_gt_m_rad": [dt, dr]},
-            "roofline": {"bound": "hbm", "kernel": "p2plane_ivox_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "ivox_knn_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_us": 1e6 * avg_launch_s,
                          "launches_timed": int(launches)},

@@ -65,7 +65,7 @@ __device__ __forceinline__ double readlane_f64(const double v, const int lane) {
 // Result x[6] is written to xs (LDS, 6 doubles).
 // Must be called by all 64 lanes of exactly one wave.
 // ---------------------------------------------------------------------------------------------
-__device__ inline void fullpiv_qr_solve6_wave(double* M, const double* g_in, double* xs, double* hcoef /*LDS 6*/,
+__device__ __forceinline__ void fullpiv_qr_solve6_wave(double* M, const double* g_in, double* xs, double* hcoef /*LDS 6*/,
                                               int* rows_tr /*LDS 6*/, int* cols_tr /*LDS 6*/, long long* dbg = nullptr) {
 #define QR_STAMP(q) do { if (dbg && (threadIdx.x & 63) == 0) dbg[q] = (long long)__builtin_readcyclecounter(); } while (0)
     const int lane = threadIdx.x & 63;
@@ -74,9 +74,10 @@ __device__ inline void fullpiv_qr_solve6_wave(double* M, const double* g_in, dou
     const double precision = FLS_DBL_EPS * 6.0;
     double biggest = 0.0, maxpivot = 0.0;
     int nonzero_pivots = 6;
+    double cur = lane < 36 ? M[l] : 0.0;  // this lane's element, kept in a register across the steps
     for (int k = 0; k < 6; ++k) {
         // 1. pivot: largest |entry| of the bottom-right corner, first in column-major order on ties
-        const double a = (lane < 36 && i >= k && j >= k) ? fabs(M[l]) : -1.0;
+        const double a = (lane < 36 && i >= k && j >= k) ? fabs(cur) : -1.0;
         const double mx = readlane_f64(wave_max_dpp(a), 63);
         if (k == 0) QR_STAMP(6);
         const unsigned long long eq = __ballot(a == mx);
@@ -89,27 +90,27 @@ __device__ inline void fullpiv_qr_solve6_wave(double* M, const double* g_in, dou
             break;
         }
         if (lane == 0) { rows_tr[k] = rb; cols_tr[k] = cb; }
-        // 2. row swap (columns >= k only) then column swap (all rows), as one gather
+        // 2. the row swap (k <-> rb, columns >= k) and the column swap (k <-> cb, all rows) are not materialised:
+        //    the pivoted matrix N(r, c) = old(rowp(r, colp(c)), colp(c)) is read straight from the old one.
+        //    One batch of LDS reads: column k (uniform addresses -> broadcast) and this lane's own column j.
         const int jp = (j == k) ? cb : (j == cb ? k : j);
-        const int ip = (jp >= k) ? ((i == k) ? rb : (i == rb ? k : i)) : i;
-        const double moved = M[ip + 6 * jp];
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 36) M[l] = moved;
-        __builtin_amdgcn_wave_barrier();
-        if (k == 0) QR_STAMP(7);
-        // 3. one batch of LDS reads: column k (uniform addresses -> broadcast) and this lane's own column j.
-        //    Everything below works on registers with loops unrolled over r = 0..5 and predicated on r > k,
-        //    i.e. one LDS round trip per step instead of one per term of the sums.
         double ck[6], cj[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) { ck[r] = M[r + 6 * k]; cj[r] = M[r + 6 * j]; }
-        if (k == 0) QR_STAMP(8);
-        double c0 = 0.0, tail = 0.0;
+        for (int r = 0; r < 6; ++r) {
+            const int rp = (r == k) ? rb : (r == rb ? k : r);  // row partner (applies to columns >= k)
+            ck[r] = M[rp + 6 * cb];                            // column k of N comes from old column cb (>= k)
+            cj[r] = M[((jp >= k) ? rp : r) + 6 * jp];
+        }
+        if (k == 0) QR_STAMP(7);
+        double mine = 0.0, cjk = 0.0, c0 = 0.0, tail = 0.0;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            if (r == k) c0 = ck[r];
+            if (r == i) mine = cj[r];
+            if (r == k) { cjk = cj[r]; c0 = ck[r]; }
             if (r > k) tail += ck[r] * ck[r];
         }
+        if (k == 0) QR_STAMP(8);
+        // 3. Householder reflector of column k (rows k..5), computed redundantly by every lane
         double tau, beta, den = 1.0;
         const bool trivial = (k == 5) || tail <= FLS_DBL_MIN;
         if (trivial) { tau = 0.0; beta = c0; }
@@ -120,33 +121,29 @@ __device__ inline void fullpiv_qr_solve6_wave(double* M, const double* g_in, dou
             tau = (beta - c0) / beta;
         }
         if (k == 0) QR_STAMP(9);
-        // essential part ess[r] = ck[r] / den (r > k): every lane needs all of them for its tmp -> computed
-        // redundantly (5 divisions in flight, independent) rather than via another LDS round trip
+        // essential part: lane (r, k) divides once, everybody picks the values up with v_readlane (uniform index)
+        const double ess_own = (j == k && i > k && !trivial) ? mine / den : 0.0;
         double ess[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) ess[r] = (r > k && !trivial) ? ck[r] / den : 0.0;
+        for (int r = 0; r < 6; ++r) ess[r] = readlane_f64(ess_own, r + 6 * k);  // 0 for r <= k
         // 4. new value of this lane's element
-        double mine = 0.0, ess_i = 0.0, cjk = 0.0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            if (r == i) { mine = cj[r]; ess_i = ess[r]; }
-            if (r == k) cjk = cj[r];
-        }
         if (j == k) {
             if (i == k) mine = beta;
-            else if (i > k) mine = ess_i;  // (0 when trivial)
+            else if (i > k) mine = ess_own;
         } else if (j > k && i >= k && tau != 0.0) {
-            double tmp = 0.0;
+            double tmp = 0.0, ess_i = 0.0;
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+            for (int r = 0; r < 6; ++r) {
                 if (r > k) tmp += ess[r] * cj[r];
+                if (r == i) ess_i = ess[r];
+            }
             tmp += cjk;
             if (i == k) mine -= tau * tmp;
             else mine -= (tau * ess_i) * tmp;
         }
         if (k == 0) QR_STAMP(10);
         __builtin_amdgcn_wave_barrier();
-        if (lane < 36 && j >= k) M[l] = mine;
+        if (lane < 36 && j >= k) { M[l] = mine; cur = mine; }
         if (lane == 0) hcoef[k] = tau;
         __builtin_amdgcn_wave_barrier();
         if (fabs(beta) > maxpivot) maxpivot = fabs(beta);
@@ -227,7 +224,7 @@ __device__ inline void fullpiv_qr_solve6_wave(double* M, const double* g_in, dou
 // PartialPivLU<6x6> by one wave.  M: LDS 36 (H on entry, LU on exit), inv: LDS 36 (out), b: 6 doubles.
 // Returns the determinant (uniform); xs[6] (LDS) = inverse * b, summed in column order like the CPU path.
 // ---------------------------------------------------------------------------------------------
-__device__ inline double lu6_solve_wave(double* M, double* inv, const double* b, double* xs, int* row_tr /*LDS 6*/) {
+__device__ __forceinline__ double lu6_solve_wave(double* M, double* inv, const double* b, double* xs, int* row_tr /*LDS 6*/) {
     const int lane = threadIdx.x & 63;
     const int l = lane < 36 ? lane : 35;
     const int i = l % 6, j = l / 6;
