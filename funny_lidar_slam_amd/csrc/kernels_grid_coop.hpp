@@ -1,0 +1,318 @@
+// kernels_grid_coop.hpp -- cooperative exact k-NN on the uniform cell grid + the per-kind fit kernels of
+// the three kinds whose reference uses pcl::KdTreeFLANN (IcpOptimized, LoamFull, LoamPointToPlaneKdtree).
+//
+//   grid_knn_kernel<K, FLOAT_XFORM>   8 lanes cooperate on one source point: the 27 cells around the query are
+//                        dealt round-robin to the lanes (hash probes in flight together), each lane scans the
+//                        points of its cells 4 loads at a time into a private top-K of 64-bit keys
+//                        {float-bits(d2) : map index} (ties resolve to the lower map index, the rule the CPU
+//                        oracle fixes for FLANN's traversal-defined order), then K rounds of DPP group-min.
+//                        Exactness: see kernels_knn.hpp (cell >= sqrt(gate) => every point within the gate lies
+//                        in the 27 cells).  The un-gated kind falls back to the serial ring search when the
+//                        K-th neighbour is not yet certain after the 27 cells.
+//                        (The first version ran the whole ring search in one lane per point: 797 us per launch
+//                        on the 1e6-point LOAM map.)
+//   icp_fit_kernel       IcpOptimized per-point lambda            icp_optimized.h:87-108
+//   plane_fit_kernel     LoamFull::PlanarMatch / LoamPointToPlaneKdtree::PlanerMatch (after the k-NN)
+//                                                                 loam_full_kdtree.h:291-343, loam_point_to_plane_kdtree.h:219-271
+//   corner_fit_kernel    LoamFull::CornerMatch (after the k-NN)   loam_full_kdtree.h:227-271
+// Fit kernels: one lane per point, FP64, DPP wave reduction, one partial row per 256-thread workgroup; the
+// Gauss-Newton tail runs in gn_solve_loam_kernel / gn_solve_lu_kernel.
+#pragma once
+#include "kernels_knn.hpp"
+#include "kernels_ivox_coop.hpp"
+
+namespace fls {
+
+template <int K>
+__device__ __forceinline__ void topk_insert(unsigned long long (&t)[K], unsigned (&s)[K], const unsigned long long key, const unsigned slot) {
+    if (key < t[K - 1]) {
+        t[K - 1] = key;
+        s[K - 1] = slot;
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) {
+            if (t[j] < t[j - 1]) {
+                const unsigned long long x = t[j]; t[j] = t[j - 1]; t[j - 1] = x;
+                const unsigned y = s[j]; s[j] = s[j - 1]; s[j - 1] = y;
+            }
+        }
+    }
+}
+__device__ __forceinline__ unsigned group8_min_u32(unsigned v) {
+    unsigned o = dpp_pair_u32<0>(v); v = o < v ? o : v;
+    o = dpp_pair_u32<1>(v); v = o < v ? o : v;
+    o = dpp_pair_u32<2>(v); v = o < v ? o : v;
+    return v;
+}
+
+template <int K, bool FLOAT_XFORM>
+__global__ void __launch_bounds__(256)
+grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                const GnState* __restrict__ st, const int first, const Pose16 T0, const CellGridDev cg, const float gate,
+                float4* __restrict__ nn_pts /* [n][K] */, unsigned char* __restrict__ nn_cnt, float* __restrict__ kth_d2,
+                unsigned char* __restrict__ flag_to_clear /* may be null */) {
+    constexpr int G = 8, QPB = 256 / G;  // 27 cells over 8 lanes: 4 rounds
+    const int nb = (n + QPB - 1) / QPB, per = gridDim.x >> 3;
+    const int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order (grid is a multiple of 8)
+    const int sub = threadIdx.x % G;
+    const int q = lb * QPB + threadIdx.x / G;
+    const bool active = lb < nb && q < n;
+    const int done = first ? 0 : st->done;
+    double T[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T[k] = first ? T0.m[k] : st->T[k];
+    const float px = active ? sx[q] : 0.f, py = active ? sy[q] : 0.f, pz = active ? sz[q] : 0.f;
+    if (done) return;
+    if (first && flag_to_clear && active && sub == 0) flag_to_clear[q] = 0;
+    float qx, qy, qz;
+    if (FLOAT_XFORM) {
+        const RtFloat rt = load_rt_float(T);
+        xform_f(rt, px, py, pz, qx, qy, qz);
+    } else {
+        const double x = px, y = py, z = pz;
+        qx = (float)(((T[0] * x + T[4] * y) + T[8] * z) + T[12]);
+        qy = (float)(((T[1] * x + T[5] * y) + T[9] * z) + T[13]);
+        qz = (float)(((T[2] * x + T[6] * y) + T[10] * z) + T[14]);
+    }
+    const double fx = floor((double)qx * cg.inv_cell), fy = floor((double)qy * cg.inv_cell), fz = floor((double)qz * cg.inv_cell);
+    const bool in_range = active && fabs(fx) < (double)(kKeyLimit - 2) && fabs(fy) < (double)(kKeyLimit - 2) && fabs(fz) < (double)(kKeyLimit - 2);
+    const int cx = in_range ? (int)fx : 0, cy = in_range ? (int)fy : 0, cz = in_range ? (int)fz : 0;
+
+    // probes: cell k = sub + 8 r of the 3x3x3 block, all first-slot loads issued before any is resolved
+    // (explicit per-round scalars: indexed arrays would land in scratch)
+    auto probe_key = [&](const int r, bool& pv) -> unsigned long long {
+        const int k = sub + G * r;
+        pv = in_range && k < 27;
+        const int kk = k < 27 ? k : 0;
+        return pack_key(cx + (kk % 3 - 1), cy + ((kk / 3) % 3 - 1), cz + (kk / 9 - 1));
+    };
+    auto first_load = [&](const bool pv, const unsigned long long key, unsigned& h) -> HashEntry {
+        h = hash_key(key) & cg.g.mask;
+        return pv ? cg.g.table[h] : HashEntry{kEmptyKey, 0u, 0u};
+    };
+    auto resolve = [&](const bool pv, const unsigned long long key, unsigned h, HashEntry ek, unsigned& b, unsigned& c) {
+        while (pv && ek.key != key && ek.key != kEmptyKey) {
+            h = (h + 1) & cg.g.mask;
+            ek = cg.g.table[h];
+        }
+        const bool hit = pv && ek.key == key;
+        b = hit ? ek.begin : 0u;
+        c = hit ? ek.count : 0u;
+    };
+    bool pv0, pv1, pv2, pv3;
+    unsigned h0, h1, h2, h3;
+    const unsigned long long k0 = probe_key(0, pv0), k1 = probe_key(1, pv1), k2 = probe_key(2, pv2), k3 = probe_key(3, pv3);
+    const HashEntry e0 = first_load(pv0, k0, h0), e1 = first_load(pv1, k1, h1), e2 = first_load(pv2, k2, h2), e3 = first_load(pv3, k3, h3);
+    unsigned b0, b1, b2, b3, c0, c1, c2, c3;
+    resolve(pv0, k0, h0, e0, b0, c0);
+    resolve(pv1, k1, h1, e1, b1, c1);
+    resolve(pv2, k2, h2, e2, b2, c2);
+    resolve(pv3, k3, h3, e3, b3, c3);
+    // one flattened candidate loop over this lane's cells, 4 point loads in flight per trip
+    unsigned long long t[K];
+    unsigned sl[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { t[j] = ~0ull; sl[j] = 0u; }
+    int ncand = 0;
+    const unsigned tot = c0 + c1 + c2 + c3;
+    auto slot_of = [&](unsigned idx) -> unsigned {
+        if (idx < c0) return b0 + idx;
+        idx -= c0;
+        if (idx < c1) return b1 + idx;
+        idx -= c1;
+        if (idx < c2) return b2 + idx;
+        idx -= c2;
+        return b3 + idx;
+    };
+    auto consider = [&](const float4 p, const unsigned s, const bool ok) {
+        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;  // flann::L2_Simple<float>
+        if (ok && !(d2 != d2)) {
+            ++ncand;
+            topk_insert<K>(t, sl, ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p.w), s);
+        }
+    };
+    for (unsigned j = 0; j < tot; j += 4) {
+        const unsigned last = tot - 1;
+        const unsigned i1 = j + 1, i2 = j + 2, i3 = j + 3;
+        const unsigned s0 = slot_of(j), s1 = slot_of(i1 < last ? i1 : last), s2 = slot_of(i2 < last ? i2 : last),
+                       s3 = slot_of(i3 < last ? i3 : last);
+        const float4 p0 = cg.g.pts[s0], p1 = cg.g.pts[s1], p2 = cg.g.pts[s2], p3 = cg.g.pts[s3];
+        consider(p0, s0, true);
+        consider(p1, s1, i1 <= last);
+        consider(p2, s2, i2 <= last);
+        consider(p3, s3, i3 <= last);
+    }
+    // merge the 8 private lists: K rounds of group-min + pop; the j-th neighbour lands in lane sub == j
+    const int total = group_sum_i32<G>(ncand);
+    unsigned long long mine_key = ~0ull, last_key = ~0ull;
+    unsigned mine_slot = 0u;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const unsigned long long m = group_min_u64<G>(t[0]);
+        const bool owner = (t[0] == m) && (m != ~0ull);
+        const unsigned ms = group8_min_u32(owner ? sl[0] : 0xffffffffu);
+        if (owner) {
+#pragma unroll
+            for (int u = 0; u + 1 < K; ++u) { t[u] = t[u + 1]; sl[u] = sl[u + 1]; }
+            t[K - 1] = ~0ull;
+        }
+        if (sub == j) { mine_key = m; mine_slot = ms; }
+        last_key = m;
+    }
+    int found = total < K ? total : K;
+    float kth = (total >= K && last_key != ~0ull) ? __uint_as_float((unsigned)(last_key >> 32)) : INFINITY;
+    // un-gated search (LoamPointToPlaneKdtree): the 27 cells certify the result only if the K-th neighbour lies
+    // within one cell size; otherwise lane 0 of the group redoes the query with the serial ring search
+    const double rad2 = cg.cell * cg.cell * (1.0 - 1e-5);
+    const bool certain = (gate < INFINITY) || (found == K && (double)kth <= rad2);
+    if (!certain) {  // uniform within the group
+        if (sub == 0 && active) {
+            KnnResult<K> r;
+            unsigned long long a = 0, b = 0, c = 0;
+            knn_grid<K>(cg, qx, qy, qz, gate, r, a, b, c);
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                nn_pts[(size_t)q * K + j] = j < r.found ? cg.g.pts[r.slot[j]] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            nn_cnt[q] = (unsigned char)r.found;
+            kth_d2[q] = r.found == K ? r.d[K - 1] : INFINITY;
+        }
+        return;
+    }
+    if (sub < K && active)
+        nn_pts[(size_t)q * K + sub] = (mine_key != ~0ull) ? cg.g.pts[mine_slot] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    if (sub == 0 && active) { nn_cnt[q] = (unsigned char)found; kth_d2[q] = kth; }
+}
+
+// one partial row per 256-thread workgroup from the per-wave sums in LDS (fixed order)
+__device__ __forceinline__ void block_row_from_wave_sums(double (*wsum)[32], double* __restrict__ partials) {
+    __syncthreads();
+    if (threadIdx.x < 29) {
+        const double v = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+        partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// IcpOptimized: e = pt - q, J = [I | -R hat(p)], H = J^T J, B = -J^T e   (icp_optimized.h:87-108)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+icp_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+               const GnState* __restrict__ st, const int first, const Pose16 T0, const float4* __restrict__ nn_pts /* [n][1] */,
+               const unsigned char* __restrict__ nn_cnt, const float* __restrict__ kth_d2, const double max_corr /* squared */,
+               int* __restrict__ nn_id, unsigned char* __restrict__ eff, double* __restrict__ partials) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int done = first ? 0 : st->done;
+    double T[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T[k] = first ? T0.m[k] : st->T[k];
+    if (done) return;
+    __shared__ double wsum[4][32];
+    double Hc[21], Bc[6], res = 0.0;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) Hc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Bc[k] = 0.0;
+    bool contrib = false;
+    if (i < n) {
+        int id = -1;
+        if (nn_cnt[i] >= 1 && !((double)kth_d2[i] > max_corr)) {
+            const float4 m = nn_pts[i];
+            id = __float_as_int(m.w);
+            const RtFloat rt = load_rt_float(T);
+            const float px = sx[i], py = sy[i], pz = sz[i];
+            float qx, qy, qz;
+            xform_f(rt, px, py, pz, qx, qy, qz);
+            const double e0 = (double)qx - (double)m.x, e1 = (double)qy - (double)m.y, e2 = (double)qz - (double)m.z;
+            const double o0 = px, o1 = py, o2 = pz;
+            const double hat[9] = {0.0, o2, -o1, -o2, 0.0, o0, o1, -o0, 0.0};
+            double J[18];  // 3x6 column-major: [I | M],  M = -(R * SO3Hat(o)), zero terms kept in place
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    J[r + j * 3] = (r == j) ? 1.0 : 0.0;
+                    J[r + (j + 3) * 3] = -((T[r] * hat[0 + j * 3] + T[r + 4] * hat[1 + j * 3]) + T[r + 8] * hat[2 + j * 3]);
+                }
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) {
+                    Hc[k] = (J[0 + a * 3] * J[0 + b * 3] + J[1 + a * 3] * J[1 + b * 3]) + J[2 + a * 3] * J[2 + b * 3];
+                    ++k;
+                }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) Bc[a] = ((-J[0 + a * 3]) * e0 + (-J[1 + a * 3]) * e1) + (-J[2 + a * 3]) * e2;
+            res = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+            contrib = true;
+        }
+        nn_id[i] = id;  // ids are reported for accepted correspondences only
+        eff[i] = contrib ? 1 : 0;
+    }
+    const int lane = threadIdx.x & 63;
+    double* row = &wsum[threadIdx.x >> 6][0];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) { const double v = wave_sum_dpp(Hc[k]); if (lane == 63) row[k] = v; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const double v = wave_sum_dpp(Bc[k]); if (lane == 63) row[21 + k] = v; }
+    const double sr = wave_sum_dpp(res), sc = wave_sum_dpp(contrib ? 1.0 : 0.0);
+    if (lane == 63) { row[27] = sr; row[28] = sc; }
+    block_row_from_wave_sums(wsum, partials);
+}
+
+// ---------------------------------------------------------------------------------------------
+// point-to-plane / point-to-line on the 5 exact neighbours left by grid_knn_kernel<5>
+// LINE = false: plane (Appendix C.1), LINE = true: corner feature (Appendix C.2)
+// ---------------------------------------------------------------------------------------------
+template <bool LINE>
+__global__ void __launch_bounds__(256)
+feature_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                   const GnState* __restrict__ st, const int first, const Pose16 T0, const float4* __restrict__ nn_pts /* [n][5] */,
+                   const unsigned char* __restrict__ nn_cnt, const float* __restrict__ kth_d2, const float gate, const double thres,
+                   int* __restrict__ nn_id /* [n][5] */, unsigned char* __restrict__ cnt_out, double* __restrict__ Jst /* [7][n] */,
+                   unsigned char* __restrict__ flag, double* __restrict__ partials) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int done = first ? 0 : st->done;
+    double T44[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T44[k] = first ? T0.m[k] : st->T[k];
+    if (done) return;
+    __shared__ double wsum[4][32];
+    bool contrib = false;
+    double J[6] = {0, 0, 0, 0, 0, 0}, res = 0.0;
+    if (i < n) {
+        const bool accepted = nn_cnt[i] == 5 && !(kth_d2[i] > gate);
+        float4 nn[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) nn[j] = nn_pts[(size_t)i * 5 + j];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) nn_id[(size_t)i * 5 + j] = accepted ? __float_as_int(nn[j].w) : -1;  // gate-accepted sets only
+        cnt_out[i] = accepted ? 5 : 0;
+        bool valid_now = false;
+        if (accepted) {
+            const float px = sx[i], py = sy[i], pz = sz[i];
+            const double x = px, y = py, z = pz;
+            const float ptx = (float)(((T44[0] * x + T44[4] * y) + T44[8] * z) + T44[12]);
+            const float pty = (float)(((T44[1] * x + T44[5] * y) + T44[9] * z) + T44[13]);
+            const float ptz = (float)(((T44[2] * x + T44[6] * y) + T44[10] * z) + T44[14]);
+            if (LINE) valid_now = line_residual_dev(nn, px, py, pz, ptx, pty, ptz, T44, thres, J, res);
+            else valid_now = plane_residual_dev(nn, px, py, pz, ptx, pty, ptz, T44, thres, J, res);
+        }
+        if (valid_now) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) Jst[(size_t)a * n + i] = J[a];
+            Jst[(size_t)6 * n + i] = res;
+            flag[i] = 1;
+            contrib = true;
+        } else if (flag[i]) {  // Q1 stale slot
+#pragma unroll
+            for (int a = 0; a < 6; ++a) J[a] = Jst[(size_t)a * n + i];
+            res = Jst[(size_t)6 * n + i];
+            contrib = true;
+        }
+    }
+    reduce_rank1_and_store(contrib, J, res, &wsum[threadIdx.x >> 6][0]);
+    block_row_from_wave_sums(wsum, partials);
+}
+
+}  // namespace fls

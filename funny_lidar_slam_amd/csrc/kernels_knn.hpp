@@ -12,11 +12,8 @@
 // Distances are FLANN L2_Simple<float>: ((dx*dx) + dy*dy) + dz*dz; ties resolve to the lower map
 // index (FLANN's order among equal distances is traversal-defined; the oracle fixes the same rule).
 //
-// Kernels (one lane = one source point, one wave per workgroup, shuffle-only reductions):
-//   icp_p2p_kernel        IcpOptimized::Match per-point lambda            icp_optimized.h:79-109
-//   plane_knn_kernel      LoamFull::PlanarMatch / LoamPointToPlaneKdtree::PlanerMatch
-//                                                                         loam_full_kdtree.h:275-345, loam_point_to_plane_kdtree.h:204-272
-//   corner_knn_kernel     LoamFull::CornerMatch                           loam_full_kdtree.h:211-273
+// This header: the serial ring search (fallback of the cooperative kernel in kernels_grid_coop.hpp, and the
+// fitness loops), the LOAM point-to-line residual, and
 //   ndt_kernel            IncrementalNDT::Match per-point lambda          incremental_ndt.h:252-285
 //   nn_dist_kernel        GetFitnessScore loops                           icp_optimized.h:191-215 etc.
 //   gn_solve_lu_kernel    H.inverse()*B + right-multiplicative update     icp_optimized.h:129-148, incremental_ndt.h:306-322
@@ -168,135 +165,6 @@ nn_dist_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// IcpOptimized per-point stage.  nn_id[i] = nearest map index (or -1), eff[i] = effect_pts
-// ---------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(64)
-icp_p2p_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
-               const GnState* __restrict__ st, const CellGridDev cg, const double max_corr /* squared */,
-               int* __restrict__ nn_id, unsigned char* __restrict__ eff, double* __restrict__ partials,
-               TrafficCounters* __restrict__ tc) {
-    if (st->done) return;
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    double Hc[21], Bc[6], res = 0.0;
-#pragma unroll
-    for (int k = 0; k < 21; ++k) Hc[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Bc[k] = 0.0;
-    bool contrib = false;
-    unsigned long long c_p = 0, c_h = 0, c_c = 0;
-    if (i < n) {
-        const RtFloat rt = load_rt_float(st->T);
-        const float px = sx[i], py = sy[i], pz = sz[i];
-        float qx, qy, qz;
-        xform_f(rt, px, py, pz, qx, qy, qz);
-        KnnResult<1> r;
-        knn_grid<1>(cg, qx, qy, qz, (float)max_corr, r, c_p, c_h, c_c);
-        int id = -1;
-        if (r.found) {
-            if (!((double)r.d[0] > max_corr)) {
-                id = r.id[0];  // ids are reported for accepted correspondences only
-                const float4 m = cg.g.pts[r.slot[0]];
-                const double e0 = (double)qx - (double)m.x, e1 = (double)qy - (double)m.y, e2 = (double)qz - (double)m.z;
-                const double o0 = px, o1 = py, o2 = pz;
-                // M = -(R * SO3Hat(o)), zero terms kept in place (they are exact)
-                double R[9];
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) R[q + j * 3] = st->T[q + j * 4];
-                const double hat[9] = {0.0, o2, -o1, -o2, 0.0, o0, o1, -o0, 0.0};
-                double J[18];  // 3x6 column-major: [I | M]
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        J[q + j * 3] = (q == j) ? 1.0 : 0.0;
-                        J[q + (j + 3) * 3] = -((R[q] * hat[0 + j * 3] + R[q + 3] * hat[1 + j * 3]) + R[q + 6] * hat[2 + j * 3]);
-                    }
-                int k = 0;
-#pragma unroll
-                for (int a = 0; a < 6; ++a)
-#pragma unroll
-                    for (int b = a; b < 6; ++b) {
-                        Hc[k] = (J[0 + a * 3] * J[0 + b * 3] + J[1 + a * 3] * J[1 + b * 3]) + J[2 + a * 3] * J[2 + b * 3];
-                        ++k;
-                    }
-#pragma unroll
-                for (int a = 0; a < 6; ++a) Bc[a] = ((-J[0 + a * 3]) * e0 + (-J[1 + a * 3]) * e1) + (-J[2 + a * 3]) * e2;
-                res = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
-                contrib = true;
-            }
-        }
-        nn_id[i] = id;
-        eff[i] = contrib ? 1 : 0;
-    }
-    const int lane = threadIdx.x & 63;
-    double* row = partials + (size_t)blockIdx.x * kPartialStride;
-#pragma unroll
-    for (int k = 0; k < 21; ++k) { const double v = wave_sum_dpp(Hc[k]); if (lane == 63) row[k] = v; }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { const double v = wave_sum_dpp(Bc[k]); if (lane == 63) row[21 + k] = v; }
-    const double sr = wave_sum_dpp(res), sc = wave_sum_dpp(contrib ? 1.0 : 0.0);
-    if (lane == 63) { row[27] = sr; row[28] = sc; }
-    if (COUNT) count_traffic(tc, c_p, c_h, c_c);
-}
-
-// ---------------------------------------------------------------------------------------------
-// point-to-plane on the exact 5-NN (LoamFull planar set / LoamPointToPlaneKdtree)
-// gate = point_search_thres (squared) for LoamFull, INFINITY for LoamPointToPlaneKdtree
-// ---------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(64)
-plane_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
-                 const GnState* __restrict__ st, const CellGridDev cg, const float gate, const double plane_thres,
-                 int* __restrict__ nn_id /* [n][5] */, unsigned char* __restrict__ nn_cnt, double* __restrict__ Jst /* [7][n] */,
-                 unsigned char* __restrict__ flag, double* __restrict__ partials, TrafficCounters* __restrict__ tc) {
-    if (st->done) return;
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    double T44[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) T44[k] = st->T[k];
-    bool contrib = false;
-    double J[6] = {0, 0, 0, 0, 0, 0}, res = 0.0;
-    unsigned long long c_p = 0, c_h = 0, c_c = 0;
-    if (i < n) {
-        const float px = sx[i], py = sy[i], pz = sz[i];
-        const double x = px, y = py, z = pz;
-        const float ptx = (float)(((T44[0] * x + T44[4] * y) + T44[8] * z) + T44[12]);
-        const float pty = (float)(((T44[1] * x + T44[5] * y) + T44[9] * z) + T44[13]);
-        const float ptz = (float)(((T44[2] * x + T44[6] * y) + T44[10] * z) + T44[14]);
-        KnnResult<5> r;
-        knn_grid<5>(cg, ptx, pty, ptz, gate, r, c_p, c_h, c_c);
-        const bool accepted = r.found == 5 && !(r.d[4] > gate);
-#pragma unroll
-        for (int j = 0; j < 5; ++j) nn_id[(size_t)i * 5 + j] = accepted ? r.id[j] : -1;
-        nn_cnt[i] = accepted ? 5 : 0;
-        bool valid_now = false;
-        if (accepted) {
-            float4 nn[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) nn[j] = cg.g.pts[r.slot[j]];
-            valid_now = plane_residual_dev(nn, px, py, pz, ptx, pty, ptz, T44, plane_thres, J, res);
-        }
-        if (valid_now) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a) Jst[(size_t)a * n + i] = J[a];
-            Jst[(size_t)6 * n + i] = res;
-            flag[i] = 1;
-            contrib = true;
-        } else if (flag[i]) {  // Q1 stale slot
-#pragma unroll
-            for (int a = 0; a < 6; ++a) J[a] = Jst[(size_t)a * n + i];
-            res = Jst[(size_t)6 * n + i];
-            contrib = true;
-        }
-    }
-    reduce_rank1_and_store(contrib, J, res, partials + (size_t)blockIdx.x * kPartialStride);
-    if (COUNT) count_traffic(tc, c_p, c_h, c_c);
-}
-
-// ---------------------------------------------------------------------------------------------
 // point-to-line on the exact 5-NN of the corner map (Appendix C.2)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool line_residual_dev(const float4 (&nn)[5], const float spx, const float spy, const float spz,
@@ -352,56 +220,6 @@ __device__ __forceinline__ bool line_residual_dev(const float4 (&nn)[5], const f
     return true;
 }
 
-template <bool COUNT>
-__global__ void __launch_bounds__(64)
-corner_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
-                  const GnState* __restrict__ st, const CellGridDev cg, const float gate, const double line_ratio,
-                  int* __restrict__ nn_id, unsigned char* __restrict__ nn_cnt, double* __restrict__ Jst, unsigned char* __restrict__ flag,
-                  double* __restrict__ partials, TrafficCounters* __restrict__ tc) {
-    if (st->done) return;
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    double T44[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) T44[k] = st->T[k];
-    bool contrib = false;
-    double J[6] = {0, 0, 0, 0, 0, 0}, res = 0.0;
-    unsigned long long c_p = 0, c_h = 0, c_c = 0;
-    if (i < n) {
-        const float px = sx[i], py = sy[i], pz = sz[i];
-        const double x = px, y = py, z = pz;
-        const float ptx = (float)(((T44[0] * x + T44[4] * y) + T44[8] * z) + T44[12]);
-        const float pty = (float)(((T44[1] * x + T44[5] * y) + T44[9] * z) + T44[13]);
-        const float ptz = (float)(((T44[2] * x + T44[6] * y) + T44[10] * z) + T44[14]);
-        KnnResult<5> r;
-        knn_grid<5>(cg, ptx, pty, ptz, gate, r, c_p, c_h, c_c);
-        const bool accepted = r.found == 5 && !(r.d[4] > gate);
-#pragma unroll
-        for (int j = 0; j < 5; ++j) nn_id[(size_t)i * 5 + j] = accepted ? r.id[j] : -1;
-        nn_cnt[i] = accepted ? 5 : 0;
-        bool valid_now = false;
-        if (accepted) {
-            float4 nn[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) nn[j] = cg.g.pts[r.slot[j]];
-            valid_now = line_residual_dev(nn, px, py, pz, ptx, pty, ptz, T44, line_ratio, J, res);
-        }
-        if (valid_now) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a) Jst[(size_t)a * n + i] = J[a];
-            Jst[(size_t)6 * n + i] = res;
-            flag[i] = 1;
-            contrib = true;
-        } else if (flag[i]) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a) J[a] = Jst[(size_t)a * n + i];
-            res = Jst[(size_t)6 * n + i];
-            contrib = true;
-        }
-    }
-    reduce_rank1_and_store(contrib, J, res, partials + (size_t)blockIdx.x * kPartialStride);
-    if (COUNT) count_traffic(tc, c_p, c_h, c_c);
-}
-
 // ---------------------------------------------------------------------------------------------
 // IncrementalNDT per-point stage.  Voxel table: key -> voxel slot v (entry.begin), with
 // mu[v][3], info[v][9] (column-major), vid[v] (creation id); only estimated voxels are in the table.
@@ -418,9 +236,14 @@ struct NdtGridDev {
 template <bool COUNT>
 __global__ void __launch_bounds__(64)
 ndt_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
-           const GnState* __restrict__ st, const NdtGridDev ng, const double outlier_thr, int* __restrict__ hit_vid /* [n][7] */,
-           unsigned char* __restrict__ eff7 /* [n][7] */, double* __restrict__ partials, TrafficCounters* __restrict__ tc) {
-    if (st->done) return;
+           const GnState* __restrict__ st, const int first, const Pose16 T0, const NdtGridDev ng, const double outlier_thr,
+           int* __restrict__ hit_vid /* [n][7] */, unsigned char* __restrict__ eff7 /* [n][7] */, double* __restrict__ partials,
+           TrafficCounters* __restrict__ tc) {
+    const int done = first ? 0 : st->done;
+    double P[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) P[k] = first ? T0.m[k] : st->T[k];
+    if (done) return;
     const int i = blockIdx.x * 64 + threadIdx.x;
     double Hc[21], Bc[6], res = 0.0, cnt = 0.0;
 #pragma unroll
@@ -429,9 +252,6 @@ ndt_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const flo
     for (int k = 0; k < 6; ++k) Bc[k] = 0.0;
     unsigned long long c_p = 0, c_h = 0, c_c = 0;
     if (i < n) {
-        double P[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) P[k] = st->T[k];
         const double p0 = sx[i], p1 = sy[i], p2 = sz[i];
         const double q0 = ((P[0] * p0 + P[4] * p1) + P[8] * p2) + P[12];
         const double q1 = ((P[1] * p0 + P[5] * p1) + P[9] * p2) + P[13];
@@ -516,13 +336,14 @@ ndt_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const flo
 // flag), mode 1 = IncrementalNDT (state [dtheta, dt], min_effective early-out).  Both right-multiply.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-gn_solve_lu_kernel(GnState* __restrict__ st, const double* __restrict__ partials, const int nrows, const int mode,
-                   const double rot_thr, const double pos_thr, const int min_effective) {
-    const int done = st->done;
+gn_solve_lu_kernel(GnState* __restrict__ st, const int first, const Pose16 T0, const double* __restrict__ partials, const int nrows,
+                   const int mode, const double rot_thr, const double pos_thr, const int min_effective, Mailbox* __restrict__ mb,
+                   const unsigned match_id) {
+    const int done = first ? 0 : st->done;
     double Tl[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) Tl[q] = st->T[q];
-    const int it = st->iter;
+    for (int q = 0; q < 16; ++q) Tl[q] = first ? T0.m[q] : st->T[q];
+    const int it = first ? 0 : st->iter;
     if (done) return;
     __shared__ double red[32][33];
     __shared__ double tot[32];
@@ -548,9 +369,10 @@ gn_solve_lu_kernel(GnState* __restrict__ st, const double* __restrict__ partials
     if (lane == 0) {
         st->n_valid = effective;
         st->sum_res = sres;
+        int stop = 0, conv = 0;
+        double dxo[6] = {0, 0, 0, 0, 0, 0};
         if (early_fail) {
-            st->done = 1;
-            st->converged = 0;
+            stop = 1;
         } else if (mode == 0 && det == 0.0) {
             // icp_optimized.h:129-131: skip the update, keep iterating
         } else {
@@ -565,19 +387,31 @@ gn_solve_lu_kernel(GnState* __restrict__ st, const double* __restrict__ partials
             mat3_mul_dev(R, Rd, Rn);  // right-multiplicative
             for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) Tl[i + j * 4] = Rn[i + j * 3];
             if (mode == 1) { Tl[12] += dt[0]; Tl[13] += dt[1]; Tl[14] += dt[2]; }
-            for (int q = 0; q < 16; ++q) st->T[q] = Tl[q];
-            for (int q = 0; q < 6; ++q) st->last_dx[q] = dx[q];
-            if (norm3d(dth) < rot_thr && norm3d(dt) < pos_thr) {
-                st->done = 1;
-                st->converged = 1;
-            }
+            for (int q = 0; q < 6; ++q) { st->last_dx[q] = dx[q]; dxo[q] = dx[q]; }
+            if (norm3d(dth) < rot_thr && norm3d(dt) < pos_thr) { stop = 1; conv = 1; }
         }
+        for (int q = 0; q < 16; ++q) st->T[q] = Tl[q];
+        st->done = stop;
+        st->converged = conv;
         if (it < kMaxIter) {
             for (int q = 0; q < 16; ++q) st->log_T[it][q] = Tl[q];
             st->log_nv[it] = effective;
             st->log_res[it] = sres;
         }
         st->iter = it + 1;
+        if (mb) {
+            for (int q = 0; q < 16; ++q) mb->T[q] = Tl[q];
+            for (int q = 0; q < 6; ++q) mb->last_dx[q] = dxo[q];
+            mb->sum_res = sres;
+            mb->sum_res2 = 0.0;
+            mb->iter = it + 1;
+            mb->done = stop;
+            mb->converged = conv;
+            mb->n_valid = effective;
+            mb->n_valid2 = 0;
+            __hip_atomic_store(&mb->seq, (match_id << 9) | ((unsigned)stop << 8) | (unsigned)(it + 1), __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

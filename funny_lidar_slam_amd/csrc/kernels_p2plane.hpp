@@ -224,18 +224,19 @@ __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem
 }
 
 __global__ void __launch_bounds__(kSolveThreads)
-gn_solve_loam_kernel(GnState* __restrict__ st, const double* __restrict__ partials_a, const int nrows_a,
-                     const double* __restrict__ partials_b, const int nrows_b, const double rot_thr, const double pos_thr) {
+gn_solve_loam_kernel(GnState* __restrict__ st, const int first, const Pose16 T0, const double* __restrict__ partials_a,
+                     const int nrows_a, const double* __restrict__ partials_b, const int nrows_b, const double rot_thr,
+                     const double pos_thr, Mailbox* __restrict__ mb, const unsigned match_id) {
     // every state word the tail needs is loaded up front (latency overlaps the partial reduction)
-    const int done = st->done;
+    const int done = first ? 0 : st->done;
     double Tl[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) Tl[q] = st->T[q];
-    const double last_rot = st->last_rot, last_pos = st->last_pos;
-    const int it = st->iter;
+    for (int q = 0; q < 16; ++q) Tl[q] = first ? T0.m[q] : st->T[q];
+    const double last_rot = first ? 0.0 : st->last_rot, last_pos = first ? 0.0 : st->last_pos;
+    const int it = first ? 0 : st->iter;
     if (done) return;
     __shared__ LoamTailSmem sm;
-    loam_tail<kSolveThreads>(st, sm, partials_a, nrows_a, partials_b, nrows_b, rot_thr, pos_thr, Tl, last_rot, last_pos, it);
+    loam_tail<kSolveThreads>(st, sm, partials_a, nrows_a, partials_b, nrows_b, rot_thr, pos_thr, Tl, last_rot, last_pos, it, mb, match_id);
 }
 
 }  // namespace fls

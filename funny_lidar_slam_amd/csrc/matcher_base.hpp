@@ -59,42 +59,12 @@ struct fls_matcher {
         std::memset(mb_host, 0, sizeof(fls::Mailbox));
         mb_host->seq = 0u;
         FLS_HIP(hipHostGetDevicePointer((void**)&mb_dev, mb_host, 0));
-        if (const char* e = std::getenv("FLS_GN_CHUNK")) {  // experiments: "first,next"
-            int a = 0, b = 0;
-            if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { chunk_first = a; chunk_next = b; }
-        }
     }
     void ensure_events(int iters) {
         while ((int)ev.size() < 2 * iters) {
             hipEvent_t e;
             FLS_HIP(hipEventCreate(&e));
             ev.push_back(e);
-        }
-    }
-    // reset the device Gauss-Newton state with the initial guess
-    void push_state(const double* T) {
-        fls::GnState* hs = h_state.p;
-        std::memset(hs, 0, offsetof(fls::GnState, log_T));
-        std::memcpy(hs->T, T, sizeof(double) * 16);
-        FLS_HIP(hipMemcpyAsync(d_state.p, hs, offsetof(fls::GnState, log_T), hipMemcpyHostToDevice, stream));
-        if (count_traffic) FLS_HIP(hipMemsetAsync(d_tc.p, 0, sizeof(fls::TrafficCounters), stream));
-    }
-    // Gauss-Newton launch loop.  Iterations are enqueued in chunks (first 4, then 3 at a time): the device
-    // decides convergence, kernels of an already converged Match exit at once, and the host only peeks at the
-    // `done` flag between chunks -- so a typical 3-5 iteration Match costs one synchronisation and at most a
-    // few microseconds of dead launches instead of (max_iterations - used) x 2 of them.
-    int chunk_first = 4, chunk_next = 3;
-    template <class F>
-    void run_gn_loop(int iters, F&& launch_iteration) {
-        int it = 0, chunk = std::min(iters, chunk_first);
-        while (it < iters) {
-            const int end = std::min(iters, it + chunk);
-            for (; it < end; ++it) launch_iteration(it);
-            if (it >= iters) break;
-            FLS_HIP(hipMemcpyAsync(h_state.p, d_state.p, offsetof(fls::GnState, log_T), hipMemcpyDeviceToHost, stream));
-            FLS_HIP(hipStreamSynchronize(stream));
-            if (h_state.p->done) break;
-            chunk = chunk_next;
         }
     }
     // Spin on the mailbox until the Gauss-Newton tail of iteration `target` (or an earlier one that hit the stop
@@ -137,23 +107,39 @@ struct fls_matcher {
         }
         prof_point_iters += uint64_t(iters) * points_per_iter;
     }
-    // read the state back (one synchronisation per Match) and account the profiled launches
-    void pull_state(size_t points_per_iter) {
-        FLS_HIP(hipMemcpyAsync(h_state.p, d_state.p, sizeof(fls::GnState), hipMemcpyDeviceToHost, stream));
-        if (count_traffic) FLS_HIP(hipMemcpyAsync(h_tc.p, d_tc.p, sizeof(fls::TrafficCounters), hipMemcpyDeviceToHost, stream));
-        FLS_HIP(hipStreamSynchronize(stream));
-        log_n = std::min(h_state.p->iter, fls::kMaxIter);
-        if (profiling) {
-            const int iters = h_state.p->iter;
-            for (int i = 0; i < iters && 2 * i + 1 < (int)ev.size(); ++i) {
-                float ms = 0.f;
-                FLS_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
-                prof_ms += ms;
-                prof_launches += 1;
-            }
-            prof_point_iters += uint64_t(iters) * points_per_iter;
+    // Gauss-Newton launch loop shared by every kind.  Iterations are enqueued in chunks sized by the previous
+    // Match (steady-state SLAM needs about the same number every scan); the device decides convergence, kernels
+    // of a finished Match exit at once, and the host learns the outcome from the mailbox without a blocking
+    // synchronisation.  launch(it, first) enqueues one iteration; returns the published mailbox word.
+    int expect_iters = 4;
+    template <class F>
+    unsigned run_mailbox_loop(int iters, size_t points_per_iter, F&& launch) {
+        match_id = (match_id + 1) & 0x7fffffu;
+        if (profiling) ensure_events(iters);
+        if (count_traffic) FLS_HIP(hipMemsetAsync(d_tc.p, 0, sizeof(fls::TrafficCounters), stream));
+        int launched = 0;
+        unsigned word = 0;
+        int chunk = std::max(1, std::min(iters, expect_iters));
+        for (;;) {
+            const int end = std::min(iters, launched + chunk);
+            for (int it = launched; it < end; ++it) launch(it, it == 0 ? 1 : 0);
+            launched = end;
+            FLS_HIP(hipGetLastError());
+            word = wait_mailbox(launched);
+            if (((word >> 8) & 1u) || launched >= iters) break;
+            chunk = 2;
         }
-        if (count_traffic) last_tc = *h_tc.p;
+        const int used = int(word & 0xffu);
+        expect_iters = std::max(2, used);
+        log_stale = true;
+        log_n = std::min(used, fls::kMaxIter);
+        account_profile(used, points_per_iter);
+        if (count_traffic) {
+            FLS_HIP(hipMemcpyAsync(h_tc.p, d_tc.p, sizeof(fls::TrafficCounters), hipMemcpyDeviceToHost, stream));
+            FLS_HIP(hipStreamSynchronize(stream));
+            last_tc = *h_tc.p;
+        }
+        return word;
     }
 };
 

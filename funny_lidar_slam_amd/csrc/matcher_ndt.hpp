@@ -225,28 +225,25 @@ struct NdtMatcher final : fls_matcher {
         d_hit_vid.reserve(std::max<size_t>(n * 7, 1));
         d_eff7.reserve(std::max<size_t>(n * 7, 1));
         d_partials_b.reserve(size_t(std::max(nblk, 1)) * kPartialStride);
-        push_state(T);
-        const int iters = int(p.max_iterations);
-        if (profiling) ensure_events(iters);
         const NdtGridDev ng{d_table.p, mask, d_mu.p, d_info.p, d_vid.p, inv_voxel};
-        for (int it = 0; it < iters; ++it) {
+        Pose16 T0;
+        std::memcpy(T0.m, T, sizeof(T0.m));
+        const unsigned word = run_mailbox_loop(int(p.max_iterations), n, [&](int it, int first) {
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
             if (nblk > 0) {
                 if (count_traffic)
-                    hipLaunchKernelGGL(ndt_kernel<true>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, ng,
+                    hipLaunchKernelGGL(ndt_kernel<true>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, first, T0, ng,
                                        p.ndt_res_outlier_threshold, d_hit_vid.p, d_eff7.p, d_partials_b.p, d_tc.p);
                 else
-                    hipLaunchKernelGGL(ndt_kernel<false>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, ng,
+                    hipLaunchKernelGGL(ndt_kernel<false>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, first, T0, ng,
                                        p.ndt_res_outlier_threshold, d_hit_vid.p, d_eff7.p, d_partials_b.p, d_tc.p);
             }
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
-            hipLaunchKernelGGL(gn_solve_lu_kernel, dim3(1), dim3(1024), 0, stream, d_state.p, (const double*)d_partials_b.p, nblk, 1,
-                               p.rotation_converge_thres, p.position_converge_thres, p.ndt_min_effective_pts);
-        }
-        FLS_HIP(hipGetLastError());
-        pull_state(n);
-        const GnState& s = *h_state.p;
-        stats.iterations = s.iter;
+            hipLaunchKernelGGL(gn_solve_lu_kernel, dim3(1), dim3(kSolveThreads), 0, stream, d_state.p, first, T0, (const double*)d_partials_b.p, nblk, 1,
+                               p.rotation_converge_thres, p.position_converge_thres, p.ndt_min_effective_pts, mb_dev, match_id);
+        });
+        const Mailbox& s = *mb_host;
+        stats.iterations = int(word & 0xffu);
         stats.n_valid = s.n_valid;
         stats.sum_res = s.sum_res;
         std::memcpy(stats.last_dx, s.last_dx, sizeof(stats.last_dx));

@@ -19,7 +19,6 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     HostIvox ivox;
     GridImage image;
     bool image_dirty = true;
-    int expect_iters = 4;  // chunk size of the next Match = iterations the previous one needed
     DevBuf<unsigned> d_ticket;
     bool use_dense = true; // dense voxel window instead of the hash table when the map extent allows (FLS_IVOX_DENSE=0 disables)
     int variant = 4;       // lanes cooperating on one query in ivox_knn_kernel: 4 or 8 (FLS_IVOX_VARIANT)
@@ -179,49 +178,22 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         d_flag.reserve(n);  // cleared by the first iteration's kNN kernel (std::fill(flags, false) once per Match, :156, Q1)
         const int nwg = int((n + kFitThreads - 1) / kFitThreads);
         d_partials_b.reserve(size_t(nwg) * kPartialStride);
-        if (count_traffic) FLS_HIP(hipMemsetAsync(d_tc.p, 0, sizeof(TrafficCounters), stream));
         const int iters = int(p.max_iterations);
-        if (profiling) ensure_events(iters);
         const DevGrid g = image.dev();
         const DenseWindow win = use_dense ? image.window() : DenseWindow{nullptr, 0, 0, 0, 0, 0, 0};
         Pose16 T0;
         std::memcpy(T0.m, T, sizeof(T0.m));
-        match_id = (match_id + 1) & 0x7fffffu;
-        // Iterations are enqueued in chunks sized by the previous Match (steady-state SLAM needs about the same
-        // number every scan); the device decides convergence, kernels of a converged Match exit at once, and the
-        // host learns the outcome from the mailbox without a blocking synchronisation.
-        int launched = 0;
-        unsigned word = 0;
-        int chunk = std::max(1, std::min(iters, expect_iters));
-        for (;;) {
-            const int end = std::min(iters, launched + chunk);
-            for (int it = launched; it < end; ++it) {
-                const int first = it == 0 ? 1 : 0;
-                if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
-                if (variant == 4) launch_knn<4>(n, first, T0, g, win); else launch_knn<8>(n, first, T0, g, win);
-                if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
-                hipLaunchKernelGGL(p2plane_fit_solve_kernel, dim3(nwg), dim3(kFitThreads), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),
-                                   d_state.p, first, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p,
-                                   d_partials_b.p, d_ticket.p, mb_dev, match_id, p.point_to_planar_thres, p.rotation_converge_thres,
-                                   p.position_converge_thres);
-            }
-            launched = end;
-            FLS_HIP(hipGetLastError());
-            word = wait_mailbox(launched);
-            if (((word >> 8) & 1u) || launched >= iters) break;
-            chunk = 2;
-        }
+        const unsigned word = run_mailbox_loop(iters, n, [&](int it, int first) {
+            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
+            if (variant == 4) launch_knn<4>(n, first, T0, g, win); else launch_knn<8>(n, first, T0, g, win);
+            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
+            hipLaunchKernelGGL(p2plane_fit_solve_kernel, dim3(nwg), dim3(kFitThreads), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),
+                               d_state.p, first, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p,
+                               d_partials_b.p, d_ticket.p, mb_dev, match_id, p.point_to_planar_thres, p.rotation_converge_thres,
+                               p.position_converge_thres);
+        });
         const Mailbox& mb = *mb_host;
         const int used = int(word & 0xffu);
-        expect_iters = std::max(2, used);
-        log_stale = true;
-        log_n = std::min(used, kMaxIter);
-        account_profile(used, n);
-        if (count_traffic) {
-            FLS_HIP(hipMemcpyAsync(h_tc.p, d_tc.p, sizeof(TrafficCounters), hipMemcpyDeviceToHost, stream));
-            FLS_HIP(hipStreamSynchronize(stream));
-            last_tc = *h_tc.p;
-        }
         std::memcpy(T, mb.T, sizeof(double) * 16);
         std::memcpy(T_, mb.T, sizeof(T_));
         std::memcpy(final_T, mb.T, sizeof(final_T));

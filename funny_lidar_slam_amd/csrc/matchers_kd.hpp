@@ -8,6 +8,7 @@
 #include "matcher_base.hpp"
 #include "host_math.hpp"
 #include "kernels_knn.hpp"
+#include "kernels_grid_coop.hpp"
 #include "fitness_host.hpp"
 #include <deque>
 
@@ -29,7 +30,9 @@ struct IcpMatcher final : fls_matcher {
     double final_T[16]{};
     bool have_final = false;
     DevBuf<int> d_nn_id;
-    DevBuf<unsigned char> d_eff;
+    DevBuf<unsigned char> d_eff, d_nn_cnt;
+    DevBuf<float4> d_nn_pts;
+    DevBuf<float> d_kth;
 
     fls_status init() {
         if (unset_f(p.map_cloud_filter_size) || unset_f(p.source_cloud_filter_size) || unset_d(p.point_search_thres) ||
@@ -68,39 +71,39 @@ struct IcpMatcher final : fls_matcher {
         if (raw_n <= 10) return FLS_ERR_INVALID;  // CHECK_GT(ordered_cloud_.size(), 10u) :55
         if (!have_map) return FLS_ERR_STATE;
         const size_t n = scan.n;
-        const int nblk = int((n + 63) / 64);
+        const int nwg = int((n + 255) / 256);
         stats = fls_stats{};
         stats.n_source = int(n);
-        d_nn_id.reserve(n);
-        d_eff.reserve(n);
-        d_partials_b.reserve(size_t(nblk) * kPartialStride);
-        push_state(T);
-        const int iters = int(p.max_iterations);
-        if (profiling) ensure_events(iters);
+        d_nn_pts.reserve(std::max<size_t>(n, 1));
+        d_nn_cnt.reserve(std::max<size_t>(n, 1));
+        d_kth.reserve(std::max<size_t>(n, 1));
+        d_nn_id.reserve(std::max<size_t>(n, 1));
+        d_eff.reserve(std::max<size_t>(n, 1));
+        d_partials_b.reserve(size_t(std::max(nwg, 1)) * kPartialStride);
         const CellGridDev cg = cell_dev(grid);
-        for (int it = 0; it < iters; ++it) {
+        const dim3 knn_grid_dim(unsigned((((n * 8 + 255) / 256) + 7) / 8 * 8));
+        Pose16 T0;
+        std::memcpy(T0.m, T, sizeof(T0.m));
+        const unsigned word = run_mailbox_loop(int(p.max_iterations), n, [&](int it, int first) {
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
-            if (count_traffic)
-                hipLaunchKernelGGL(icp_p2p_kernel<true>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, cg,
-                                   p.point_search_thres, d_nn_id.p, d_eff.p, d_partials_b.p, d_tc.p);
-            else
-                hipLaunchKernelGGL(icp_p2p_kernel<false>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, cg,
-                                   p.point_search_thres, d_nn_id.p, d_eff.p, d_partials_b.p, d_tc.p);
+            hipLaunchKernelGGL((grid_knn_kernel<1, true>), knn_grid_dim, dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p,
+                               first, T0, cg, float(p.point_search_thres), d_nn_pts.p, d_nn_cnt.p, d_kth.p, (unsigned char*)nullptr);
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
-            hipLaunchKernelGGL(gn_solve_lu_kernel, dim3(1), dim3(1024), 0, stream, d_state.p, (const double*)d_partials_b.p, nblk, 0,
-                               p.rotation_converge_thres, p.position_converge_thres, 0);
-        }
-        FLS_HIP(hipGetLastError());
-        pull_state(n);
-        const GnState& s = *h_state.p;
-        std::memcpy(T, s.T, sizeof(double) * 16);
-        std::memcpy(final_T, s.T, sizeof(final_T));
+            hipLaunchKernelGGL(icp_fit_kernel, dim3(nwg), dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, first, T0,
+                               (const float4*)d_nn_pts.p, (const unsigned char*)d_nn_cnt.p, (const float*)d_kth.p, p.point_search_thres,
+                               d_nn_id.p, d_eff.p, d_partials_b.p);
+            hipLaunchKernelGGL(gn_solve_lu_kernel, dim3(1), dim3(kSolveThreads), 0, stream, d_state.p, first, T0, (const double*)d_partials_b.p,
+                               nwg, 0, p.rotation_converge_thres, p.position_converge_thres, 0, mb_dev, match_id);
+        });
+        const Mailbox& mb = *mb_host;
+        std::memcpy(T, mb.T, sizeof(double) * 16);
+        std::memcpy(final_T, mb.T, sizeof(final_T));
         have_final = true;
-        const bool has_converge = s.converged != 0;  // Q10: false after max iterations
-        stats.iterations = s.iter;
-        stats.n_valid = s.n_valid;
-        stats.sum_res = s.sum_res;
-        std::memcpy(stats.last_dx, s.last_dx, sizeof(stats.last_dx));
+        const bool has_converge = mb.converged != 0;  // Q10: false after max iterations
+        stats.iterations = int(word & 0xffu);
+        stats.n_valid = mb.n_valid;
+        stats.sum_res = mb.sum_res;
+        std::memcpy(stats.last_dx, mb.last_dx, sizeof(stats.last_dx));
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
         if (has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode && update_map) {  // :154-157
@@ -133,22 +136,35 @@ struct IcpMatcher final : fls_matcher {
 // per-feature-class device buffers of the LOAM kinds
 struct FeatureDev {
     DevScan scan;
-    DevBuf<int> nn_id;
-    DevBuf<unsigned char> nn_cnt, flag;
+    DevBuf<float4> nn_pts;           // [n][5] neighbours left by grid_knn_kernel<5>
+    DevBuf<unsigned char> nn_cnt, flag, cnt_out;
+    DevBuf<float> kth;               // d2 of the 5th neighbour
+    DevBuf<int> nn_id;               // [n][5] reported ids (gate-accepted sets only)
     DevBuf<double> J;
-    void prepare(hipStream_t s) {
+    void prepare() {
         const size_t n = std::max<size_t>(scan.n, 1);
-        nn_id.reserve(n * 5); nn_cnt.reserve(n); flag.reserve(n); J.reserve(7 * n);
-        FLS_HIP(hipMemsetAsync(flag.p, 0, n, s));  // flags cleared once per Match (Q1)
+        nn_pts.reserve(n * 5); nn_cnt.reserve(n); cnt_out.reserve(n); kth.reserve(n); nn_id.reserve(n * 5); flag.reserve(n); J.reserve(7 * n);
     }
     int fetch(hipStream_t s, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) {
         const size_t n = std::min(cap, scan.n);
         if (!n) return 0;
         FLS_HIP(hipMemcpyAsync(ids, nn_id.p, n * 5 * sizeof(int), hipMemcpyDeviceToHost, s));
-        FLS_HIP(hipMemcpyAsync(cnt, nn_cnt.p, n, hipMemcpyDeviceToHost, s));
+        FLS_HIP(hipMemcpyAsync(cnt, cnt_out.p, n, hipMemcpyDeviceToHost, s));
         FLS_HIP(hipMemcpyAsync(valid, flag.p, n, hipMemcpyDeviceToHost, s));
         FLS_HIP(hipStreamSynchronize(s));
         return int(n);
+    }
+    // grid_knn_kernel<5> (flags cleared by the first iteration: once per Match, Q1) + feature_fit_kernel<LINE>
+    template <bool LINE>
+    void launch(hipStream_t s, GnState* st, int first, const Pose16& T0, const CellGridDev& cg, float gate, double thres, double* partials) {
+        const size_t n = scan.n;
+        if (n == 0) return;
+        const dim3 knn_grid_dim(unsigned((((n * 8 + 255) / 256) + 7) / 8 * 8));
+        hipLaunchKernelGGL((grid_knn_kernel<5, false>), knn_grid_dim, dim3(256), 0, s, scan.x.p, scan.y.p, scan.z.p, int(n), st, first, T0, cg, gate,
+                           nn_pts.p, nn_cnt.p, kth.p, flag.p);
+        hipLaunchKernelGGL((feature_fit_kernel<LINE>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, scan.x.p, scan.y.p, scan.z.p, int(n), st,
+                           first, T0, (const float4*)nn_pts.p, (const unsigned char*)nn_cnt.p, (const float*)kth.p, gate, thres, nn_id.p,
+                           cnt_out.p, J.p, flag.p, partials);
     }
 };
 
@@ -200,61 +216,40 @@ struct LoamFullMatcher final : fls_matcher {
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
         if (!have_map) return FLS_ERR_STATE;
         const size_t np = planar.scan.n, nc = corner.scan.n;
-        const int nbp = int((np + 63) / 64), nbc = int((nc + 63) / 64);
+        const int nbp = int((np + 255) / 256), nbc = int((nc + 255) / 256);
         stats = fls_stats{};
         stats.n_source = int(np);
         stats.n_source_corner = int(nc);
-        planar.prepare(stream);
-        corner.prepare(stream);
+        planar.prepare();
+        corner.prepare();
         d_partials_a.reserve(size_t(std::max(nbc, 1)) * kPartialStride);
         d_partials_b.reserve(size_t(std::max(nbp, 1)) * kPartialStride);
-        push_state(T);
-        const int iters = int(p.max_iterations);
-        if (profiling) ensure_events(iters);
         const CellGridDev cgp = cell_dev(planar_grid), cgc = cell_dev(corner_grid);
         const float gate_f = float(p.point_search_thres);
-        for (int it = 0; it < iters; ++it) {
+        Pose16 T0;
+        std::memcpy(T0.m, T, sizeof(T0.m));
+        const unsigned word = run_mailbox_loop(int(p.max_iterations), np + nc, [&](int it, int first) {
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
-            if (nbc > 0) {
-                if (count_traffic)
-                    hipLaunchKernelGGL(corner_knn_kernel<true>, dim3(nbc), dim3(64), 0, stream, corner.scan.x.p, corner.scan.y.p, corner.scan.z.p,
-                                       int(nc), d_state.p, cgc, gate_f, p.line_ratio_thres, corner.nn_id.p, corner.nn_cnt.p, corner.J.p,
-                                       corner.flag.p, d_partials_a.p, d_tc.p);
-                else
-                    hipLaunchKernelGGL(corner_knn_kernel<false>, dim3(nbc), dim3(64), 0, stream, corner.scan.x.p, corner.scan.y.p, corner.scan.z.p,
-                                       int(nc), d_state.p, cgc, gate_f, p.line_ratio_thres, corner.nn_id.p, corner.nn_cnt.p, corner.J.p,
-                                       corner.flag.p, d_partials_a.p, d_tc.p);
-            }
-            if (nbp > 0) {
-                if (count_traffic)
-                    hipLaunchKernelGGL(plane_knn_kernel<true>, dim3(nbp), dim3(64), 0, stream, planar.scan.x.p, planar.scan.y.p, planar.scan.z.p,
-                                       int(np), d_state.p, cgp, gate_f, p.point_to_planar_thres, planar.nn_id.p, planar.nn_cnt.p, planar.J.p,
-                                       planar.flag.p, d_partials_b.p, d_tc.p);
-                else
-                    hipLaunchKernelGGL(plane_knn_kernel<false>, dim3(nbp), dim3(64), 0, stream, planar.scan.x.p, planar.scan.y.p, planar.scan.z.p,
-                                       int(np), d_state.p, cgp, gate_f, p.point_to_planar_thres, planar.nn_id.p, planar.nn_cnt.p, planar.J.p,
-                                       planar.flag.p, d_partials_b.p, d_tc.p);
-            }
+            corner.launch<true>(stream, d_state.p, first, T0, cgc, gate_f, p.line_ratio_thres, d_partials_a.p);
+            planar.launch<false>(stream, d_state.p, first, T0, cgp, gate_f, p.point_to_planar_thres, d_partials_b.p);
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
-            hipLaunchKernelGGL(gn_solve_loam_kernel, dim3(1), dim3(1024), 0, stream, d_state.p, (const double*)d_partials_a.p, nbc,
-                               (const double*)d_partials_b.p, nbp, p.rotation_converge_thres, p.position_converge_thres);
-        }
-        FLS_HIP(hipGetLastError());
-        pull_state(np + nc);
-        const GnState& s = *h_state.p;
-        std::memcpy(T, s.T, sizeof(double) * 16);
+            hipLaunchKernelGGL(gn_solve_loam_kernel, dim3(1), dim3(kSolveThreads), 0, stream, d_state.p, first, T0, (const double*)d_partials_a.p,
+                               nbc, (const double*)d_partials_b.p, nbp, p.rotation_converge_thres, p.position_converge_thres, mb_dev, match_id);
+        });
+        const Mailbox& mb = *mb_host;
+        std::memcpy(T, mb.T, sizeof(double) * 16);
         bool has_converge = true;
-        if (s.n_valid < 50) has_converge = false;  // number_valid_planar_ < 50 :181
-        stats.iterations = s.iter;
-        stats.n_valid = s.n_valid;
-        stats.n_valid_corner = s.n_valid2;
-        stats.sum_res = s.sum_res;
-        stats.sum_res_corner = s.sum_res2;
-        std::memcpy(stats.last_dx, s.last_dx, sizeof(stats.last_dx));
+        if (mb.n_valid < 50) has_converge = false;  // number_valid_planar_ < 50 :181
+        stats.iterations = int(word & 0xffu);
+        stats.n_valid = mb.n_valid;
+        stats.n_valid_corner = mb.n_valid2;
+        stats.sum_res = mb.sum_res;
+        stats.sum_res_corner = mb.sum_res2;
+        std::memcpy(stats.last_dx, mb.last_dx, sizeof(stats.last_dx));
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
-        if (has_converge && gate.need(s.T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && update_map) {  // :185-193 (no localization switch)
-            const fls_status arc = add_cloud_impl(hm::xform_cloud_d(planar.scan.host, s.T), hm::xform_cloud_d(corner.scan.host, s.T));
+        if (has_converge && gate.need(mb.T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && update_map) {  // :185-193 (no localization switch)
+            const fls_status arc = add_cloud_impl(hm::xform_cloud_d(planar.scan.host, mb.T), hm::xform_cloud_d(corner.scan.host, mb.T));
             if (arc != FLS_OK) rc = arc;
             stats.map_updated = 1;
         }
@@ -313,43 +308,31 @@ struct P2PlaneKdMatcher final : fls_matcher {
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
         if (!have_map) return FLS_ERR_STATE;
         const size_t n = planar.scan.n;
-        const int nblk = int((n + 63) / 64);
+        const int nblk = int((n + 255) / 256);
         stats = fls_stats{};
         stats.n_source = int(n);
-        planar.prepare(stream);
+        planar.prepare();
         d_partials_b.reserve(size_t(std::max(nblk, 1)) * kPartialStride);
-        push_state(T);
-        const int iters = int(p.max_iterations);
-        if (profiling) ensure_events(iters);
         const CellGridDev cg = cell_dev(grid);
-        for (int it = 0; it < iters; ++it) {
+        Pose16 T0;
+        std::memcpy(T0.m, T, sizeof(T0.m));
+        const unsigned word = run_mailbox_loop(int(p.max_iterations), n, [&](int it, int first) {
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
-            if (nblk > 0) {
-                if (count_traffic)
-                    hipLaunchKernelGGL(plane_knn_kernel<true>, dim3(nblk), dim3(64), 0, stream, planar.scan.x.p, planar.scan.y.p, planar.scan.z.p,
-                                       int(n), d_state.p, cg, INFINITY, p.point_to_planar_thres, planar.nn_id.p, planar.nn_cnt.p, planar.J.p,
-                                       planar.flag.p, d_partials_b.p, d_tc.p);
-                else
-                    hipLaunchKernelGGL(plane_knn_kernel<false>, dim3(nblk), dim3(64), 0, stream, planar.scan.x.p, planar.scan.y.p, planar.scan.z.p,
-                                       int(n), d_state.p, cg, INFINITY, p.point_to_planar_thres, planar.nn_id.p, planar.nn_cnt.p, planar.J.p,
-                                       planar.flag.p, d_partials_b.p, d_tc.p);
-            }
+            planar.launch<false>(stream, d_state.p, first, T0, cg, INFINITY, p.point_to_planar_thres, d_partials_b.p);  // un-gated (:219)
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
-            hipLaunchKernelGGL(gn_solve_loam_kernel, dim3(1), dim3(1024), 0, stream, d_state.p, (const double*)nullptr, 0,
-                               (const double*)d_partials_b.p, nblk, p.rotation_converge_thres, p.position_converge_thres);
-        }
-        FLS_HIP(hipGetLastError());
-        pull_state(n);
-        const GnState& s = *h_state.p;
-        std::memcpy(T, s.T, sizeof(double) * 16);
-        std::memcpy(final_T, s.T, sizeof(final_T));
+            hipLaunchKernelGGL(gn_solve_loam_kernel, dim3(1), dim3(kSolveThreads), 0, stream, d_state.p, first, T0, (const double*)nullptr, 0,
+                               (const double*)d_partials_b.p, nblk, p.rotation_converge_thres, p.position_converge_thres, mb_dev, match_id);
+        });
+        const Mailbox& mb = *mb_host;
+        std::memcpy(T, mb.T, sizeof(double) * 16);
+        std::memcpy(final_T, mb.T, sizeof(final_T));
         have_final = true;
         bool has_converge = true;
-        if (s.n_valid < 50) has_converge = false;
-        stats.iterations = s.iter;
-        stats.n_valid = s.n_valid;
-        stats.sum_res = s.sum_res;
-        std::memcpy(stats.last_dx, s.last_dx, sizeof(stats.last_dx));
+        if (mb.n_valid < 50) has_converge = false;
+        stats.iterations = int(word & 0xffu);
+        stats.n_valid = mb.n_valid;
+        stats.sum_res = mb.sum_res;
+        std::memcpy(stats.last_dx, mb.last_dx, sizeof(stats.last_dx));
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
         if (has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode && update_map) {  // :145-149
