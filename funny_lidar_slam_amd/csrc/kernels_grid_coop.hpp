@@ -23,6 +23,10 @@
 
 namespace fls {
 
+// the 27 cells of the 3x3x3 block (raster code = (dx+1) + 3 (dy+1) + 9 (dz+1)) ordered nearest-first:
+// centre, 6 faces, 12 edges, 8 corners
+__device__ const unsigned char kCellOrder[27] = {13, 4, 10, 12, 14, 16, 22, 1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25, 0, 2, 6, 8, 18, 20, 24, 26};
+
 template <int K>
 __device__ __forceinline__ void topk_insert(unsigned long long (&t)[K], unsigned (&s)[K], const unsigned long long key, const unsigned slot) {
     if (key < t[K - 1]) {
@@ -77,13 +81,14 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
     const bool in_range = active && fabs(fx) < (double)(kKeyLimit - 2) && fabs(fy) < (double)(kKeyLimit - 2) && fabs(fz) < (double)(kKeyLimit - 2);
     const int cx = in_range ? (int)fx : 0, cy = in_range ? (int)fy : 0, cz = in_range ? (int)fz : 0;
 
-    // probes: cell k = sub + 8 r of the 3x3x3 block, all first-slot loads issued before any is resolved
-    // (explicit per-round scalars: indexed arrays would land in scratch)
-    auto probe_key = [&](const int r, bool& pv) -> unsigned long long {
-        const int k = sub + G * r;
-        pv = in_range && k < 27;
-        const int kk = k < 27 ? k : 0;
-        return pack_key(cx + (kk % 3 - 1), cy + ((kk / 3) % 3 - 1), cz + (kk / 9 - 1));
+    // The 27 cells are visited nearest-first (centre, 6 faces, 12 edges, 8 corners): cell order[sub + 8 r] in
+    // round r.  Round 0 (centre + faces + one edge) is scanned first; it yields an upper bound B on the K-th
+    // neighbour distance (any lane holding K points certifies one), and the remaining 19 cells are probed and
+    // scanned only if their box can still contain something closer than B (or than the caller's gate).  The
+    // pruning is exact: a skipped cell's minimum distance exceeds B by a 1e-5 relative margin.
+    auto cell_of = [&](const int k, int& dx, int& dy, int& dz) {
+        const int code = kCellOrder[k < 27 ? k : 0];
+        dx = code % 3 - 1; dy = (code / 3) % 3 - 1; dz = code / 9 - 1;
     };
     auto first_load = [&](const bool pv, const unsigned long long key, unsigned& h) -> HashEntry {
         h = hash_key(key) & cg.g.mask;
@@ -98,31 +103,11 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
         b = hit ? ek.begin : 0u;
         c = hit ? ek.count : 0u;
     };
-    bool pv0, pv1, pv2, pv3;
-    unsigned h0, h1, h2, h3;
-    const unsigned long long k0 = probe_key(0, pv0), k1 = probe_key(1, pv1), k2 = probe_key(2, pv2), k3 = probe_key(3, pv3);
-    const HashEntry e0 = first_load(pv0, k0, h0), e1 = first_load(pv1, k1, h1), e2 = first_load(pv2, k2, h2), e3 = first_load(pv3, k3, h3);
-    unsigned b0, b1, b2, b3, c0, c1, c2, c3;
-    resolve(pv0, k0, h0, e0, b0, c0);
-    resolve(pv1, k1, h1, e1, b1, c1);
-    resolve(pv2, k2, h2, e2, b2, c2);
-    resolve(pv3, k3, h3, e3, b3, c3);
-    // one flattened candidate loop over this lane's cells, 4 point loads in flight per trip
     unsigned long long t[K];
     unsigned sl[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { t[j] = ~0ull; sl[j] = 0u; }
     int ncand = 0;
-    const unsigned tot = c0 + c1 + c2 + c3;
-    auto slot_of = [&](unsigned idx) -> unsigned {
-        if (idx < c0) return b0 + idx;
-        idx -= c0;
-        if (idx < c1) return b1 + idx;
-        idx -= c1;
-        if (idx < c2) return b2 + idx;
-        idx -= c2;
-        return b3 + idx;
-    };
     auto consider = [&](const float4 p, const unsigned s, const bool ok) {
         const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
         const float d2 = (dx * dx + dy * dy) + dz * dz;  // flann::L2_Simple<float>
@@ -130,6 +115,59 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
             ++ncand;
             topk_insert<K>(t, sl, ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p.w), s);
         }
+    };
+    // ---- round 0
+    {
+        int dx, dy, dz;
+        cell_of(sub, dx, dy, dz);
+        const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
+        unsigned h, b0, c0;
+        const HashEntry e0 = first_load(in_range, key, h);
+        resolve(in_range, key, h, e0, b0, c0);
+        const unsigned last = b0 + c0 - 1;  // only dereferenced when c0 > 0
+        for (unsigned s = b0; s < b0 + c0; s += 4) {
+            const unsigned s1 = s + 1 < last ? s + 1 : last, s2 = s + 2 < last ? s + 2 : last, s3 = s + 3 < last ? s + 3 : last;
+            const float4 p0 = cg.g.pts[s], p1 = cg.g.pts[s1], p2 = cg.g.pts[s2], p3 = cg.g.pts[s3];
+            consider(p0, s, true);
+            consider(p1, s1, s + 1 <= last);
+            consider(p2, s2, s + 2 <= last);
+            consider(p3, s3, s + 3 <= last);
+        }
+    }
+    // ---- bound after round 0 (non-negative floats order like their bit patterns)
+    const unsigned my_kth = (t[K - 1] != ~0ull) ? (unsigned)(t[K - 1] >> 32) : 0x7f800000u;
+    float bound = __uint_as_float(group8_min_u32(my_kth));
+    bound = gate < bound ? gate : bound;
+    // ---- rounds 1..3: probe + scan only the cells that can still matter
+    const double qdx = (double)qx, qdy = (double)qy, qdz = (double)qz;
+    auto plan = [&](const int r, bool& pv) -> unsigned long long {
+        const int k = sub + G * r;
+        int dx, dy, dz;
+        cell_of(k, dx, dy, dz);
+        // minimum distance from the query to the cell's box, per axis (0 when the query's own slab)
+        const double ax = dx > 0 ? (double)(cx + 1) * cg.cell - qdx : (dx < 0 ? qdx - (double)cx * cg.cell : 0.0);
+        const double ay = dy > 0 ? (double)(cy + 1) * cg.cell - qdy : (dy < 0 ? qdy - (double)cy * cg.cell : 0.0);
+        const double az = dz > 0 ? (double)(cz + 1) * cg.cell - qdz : (dz < 0 ? qdz - (double)cz * cg.cell : 0.0);
+        const double bx = ax > 0.0 ? ax : 0.0, by = ay > 0.0 ? ay : 0.0, bz = az > 0.0 ? az : 0.0;
+        const double dmin2 = ((bx * bx + by * by) + bz * bz) * (1.0 - 1e-5);
+        pv = in_range && k < 27 && !(dmin2 > (double)bound);
+        return pack_key(cx + dx, cy + dy, cz + dz);
+    };
+    bool pv1, pv2, pv3;
+    unsigned h1, h2, h3;
+    const unsigned long long k1 = plan(1, pv1), k2 = plan(2, pv2), k3 = plan(3, pv3);
+    const HashEntry e1 = first_load(pv1, k1, h1), e2 = first_load(pv2, k2, h2), e3 = first_load(pv3, k3, h3);
+    unsigned b1, b2, b3, c1, c2, c3;
+    resolve(pv1, k1, h1, e1, b1, c1);
+    resolve(pv2, k2, h2, e2, b2, c2);
+    resolve(pv3, k3, h3, e3, b3, c3);
+    const unsigned tot = c1 + c2 + c3;
+    auto slot_of = [&](unsigned idx) -> unsigned {
+        if (idx < c1) return b1 + idx;
+        idx -= c1;
+        if (idx < c2) return b2 + idx;
+        idx -= c2;
+        return b3 + idx;
     };
     for (unsigned j = 0; j < tot; j += 4) {
         const unsigned last = tot - 1;
