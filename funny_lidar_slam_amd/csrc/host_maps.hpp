@@ -45,7 +45,18 @@ public:
         std::vector<Pt4> pts;
         int prev = -1, next = -1;  // LRU list (head = most recently inserted-into)
         bool alive = false;
+        // device-image bookkeeping (GridImage): slot region [img_begin, img_begin + img_cap), img_cnt points mirrored
+        unsigned img_begin = 0, img_cap = 0, img_cnt = 0;
+        bool dirty = false;
     };
+    // journal of the changes since the device image was last synchronised
+    std::vector<int> touched;                       // voxel slots with new points (deduplicated through Voxel::dirty)
+    std::vector<unsigned long long> evicted_keys;   // voxels dropped by the LRU rule
+    void clear_journal() {
+        for (int v : touched) pool[v].dirty = false;
+        touched.clear();
+        evicted_keys.clear();
+    }
     float resolution = 0.5f, inv_resolution = 2.0f;
     size_t capacity = 1000000;
     std::vector<Voxel> pool;
@@ -56,7 +67,7 @@ public:
     int next_id = 0;
 
     void clear() {
-        pool.clear(); free_slots.clear(); index.clear();
+        pool.clear(); free_slots.clear(); index.clear(); touched.clear(); evicted_keys.clear();
         head = tail = -1; n_alive = n_points = 0; next_id = 0;
     }
     static bool key_of(float x, float y, float z, float inv, int& kx, int& ky, int& kz) {
@@ -83,6 +94,8 @@ public:
                 else { v = int(pool.size()); pool.emplace_back(); }
                 Voxel& vx = pool[v];
                 vx.key = key; vx.pts.clear(); vx.pts.push_back(p); vx.alive = true;
+                vx.img_begin = vx.img_cap = vx.img_cnt = 0;
+                if (!vx.dirty) { vx.dirty = true; touched.push_back(v); }
                 link_front(v);
                 index.emplace(key, v);
                 ++n_alive; ++n_points;
@@ -90,6 +103,7 @@ public:
             } else {
                 const int v = it->second;
                 pool[v].pts.push_back(p);
+                if (!pool[v].dirty) { pool[v].dirty = true; touched.push_back(v); }
                 ++n_points;
                 unlink(v);
                 link_front(v);
@@ -115,6 +129,7 @@ private:
         if (v < 0) return;
         unlink(v);
         index.erase(pool[v].key);
+        evicted_keys.push_back(pool[v].key);
         n_points -= pool[v].pts.size();
         pool[v].pts.clear(); pool[v].pts.shrink_to_fit();
         pool[v].alive = false;
@@ -132,6 +147,7 @@ struct GridImage {
     DevBuf<HashEntry> d_table;
     DevBuf<float4> d_pts;
     unsigned mask = 0;
+    size_t used = 0;  // slots in use on the device (iVox images: includes per-voxel slack); 0 for kd-kind grids
 
     static unsigned table_size_for(size_t n_keys) {
         size_t s = 1024;
@@ -158,7 +174,7 @@ struct GridImage {
         if (!pts.empty()) FLS_HIP(hipMemcpyAsync(d_pts.p, pts.data(), pts.size() * sizeof(Pt4), hipMemcpyHostToDevice, s));
         FLS_HIP(hipStreamSynchronize(s));
     }
-    DevGrid dev() const { return DevGrid{d_table.p, d_pts.p, mask, unsigned(pts.size())}; }
+    DevGrid dev() const { return DevGrid{d_table.p, d_pts.p, mask, unsigned(used ? used : pts.size())}; }
 
     // dense window (see device_common.hpp DenseWindow)
     std::vector<uint2> cells;
@@ -171,18 +187,47 @@ struct GridImage {
                            : DenseWindow{nullptr, 0, 0, 0, 0, 0, 0};
     }
 
-    void build_from_ivox(const HostIvox& m, hipStream_t s) {
+    // ---- incremental maintenance (iVox, dense-window images) ------------------------------------------
+    // Every voxel owns a slot region with slack (capacity = next power of two >= its count, >= 4).  An
+    // AddCloudToLocalMap that adds a few thousand points then costs one small host-to-device copy of
+    // {slot, point} / {cell, begin, count} records and one scatter kernel, instead of re-flattening and
+    // re-uploading the whole map (~125 ms for 1e6 points).  A full rebuild happens only when a voxel falls
+    // outside the window, the point array runs out of room, or more than half of it is garbage.
+    struct PtUpd { unsigned slot; float x, y, z; int id; };
+    struct CellUpd { unsigned long long idx; unsigned begin, count; };
+    std::vector<PtUpd> pt_upd;
+    std::vector<CellUpd> cell_upd;
+    DevBuf<PtUpd> d_pt_upd;
+    DevBuf<CellUpd> d_cell_upd;
+    size_t garbage = 0, n_pts_live = 0;
+    bool want_hash = true;  // build the hash table too (fallback / FLS_IVOX_DENSE=0)
+
+    static unsigned cap_for(size_t n) {
+        unsigned c = 4;
+        while (c < n) c <<= 1;
+        return c;
+    }
+    bool cell_index(int x, int y, int z, size_t& idx) const {
+        const long cx = long(x) - win_o[0], cy = long(y) - win_o[1], cz = long(z) - win_o[2];
+        if (cx < 0 || cy < 0 || cz < 0 || cx >= win_n[0] || cy >= win_n[1] || cz >= win_n[2]) return false;
+        idx = (size_t(cz) * win_n[1] + size_t(cy)) * win_n[0] + size_t(cx);
+        return true;
+    }
+
+    void build_from_ivox(HostIvox& m, hipStream_t s) {
         // voxels in window order (z, y, x): spatially adjacent voxels get adjacent point buckets
-        struct Ref { int x, y, z; const HostIvox::Voxel* v; };
+        struct Ref { int x, y, z; HostIvox::Voxel* v; };
         std::vector<Ref> refs;
         refs.reserve(m.n_alive);
         int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-        for (const auto& v : m.pool) {
+        size_t slots = 0;
+        for (auto& v : m.pool) {
             if (!v.alive) continue;
             Ref r;
             unpack_key(v.key, r.x, r.y, r.z);
             r.v = &v;
             refs.push_back(r);
+            slots += cap_for(v.pts.size());
             mn[0] = std::min(mn[0], r.x); mx[0] = std::max(mx[0], r.x);
             mn[1] = std::min(mn[1], r.y); mx[1] = std::max(mx[1], r.y);
             mn[2] = std::min(mn[2], r.z); mx[2] = std::max(mx[2], r.z);
@@ -192,28 +237,96 @@ struct GridImage {
             if (a.y != b.y) return a.y < b.y;
             return a.x < b.x;
         });
-        begin_build(m.n_alive, m.n_points);
         have_window = false;
         size_t ncell = 0;
         if (!refs.empty()) {
-            for (int a = 0; a < 3; ++a) { win_o[a] = mn[a] - 1; win_n[a] = mx[a] - mn[a] + 3; }  // one empty cell of margin
-            ncell = size_t(win_n[0]) * size_t(win_n[1]) * size_t(win_n[2]);
-            have_window = ncell <= kMaxWindowCells;
-        }
-        if (have_window) cells.assign(ncell, make_uint2(0u, 0u));
-        for (const Ref& r : refs) {
-            const unsigned beg = unsigned(pts.size());
-            insert_bucket(r.v->key, r.v->pts.data(), r.v->pts.size());
-            if (have_window) {
-                const size_t idx = (size_t(r.z - win_o[2]) * win_n[1] + size_t(r.y - win_o[1])) * win_n[0] + size_t(r.x - win_o[0]);
-                cells[idx] = make_uint2(beg, unsigned(r.v->pts.size()));
+            // margin for map growth: as much of (64, 64, 16) cells per side as the cell budget allows, at least 1
+            for (int shrink = 0; shrink < 8 && !have_window; ++shrink) {
+                const int mh = std::max(1, 64 >> shrink), mv = std::max(1, 16 >> shrink);
+                const int marg[3] = {mh, mh, mv};
+                for (int a = 0; a < 3; ++a) { win_o[a] = mn[a] - marg[a]; win_n[a] = mx[a] - mn[a] + 1 + 2 * marg[a]; }
+                ncell = size_t(win_n[0]) * size_t(win_n[1]) * size_t(win_n[2]);
+                have_window = ncell <= kMaxWindowCells;
             }
         }
+        const bool hash = want_hash || !have_window;
+        if (hash) begin_build(m.n_alive, slots);
+        else { table.clear(); mask = 0; pts.clear(); pts.reserve(slots); }
+        if (have_window) cells.assign(ncell, make_uint2(0u, 0u));
+        for (const Ref& r : refs) {
+            HostIvox::Voxel& v = *r.v;
+            const unsigned beg = unsigned(pts.size()), cap = cap_for(v.pts.size());
+            if (hash) {
+                unsigned h = hash_key(v.key) & mask;
+                while (table[h].key != kEmptyKey) h = (h + 1) & mask;
+                table[h] = HashEntry{v.key, beg, unsigned(v.pts.size())};
+            }
+            pts.insert(pts.end(), v.pts.begin(), v.pts.end());
+            pts.resize(size_t(beg) + cap, Pt4{0.f, 0.f, 0.f, -1});  // slack
+            v.img_begin = beg; v.img_cap = cap; v.img_cnt = unsigned(v.pts.size());
+            if (have_window) {
+                size_t idx;
+                cell_index(r.x, r.y, r.z, idx);
+                cells[idx] = make_uint2(beg, unsigned(v.pts.size()));
+            }
+        }
+        used = pts.size();
+        garbage = 0;
+        n_pts_live = m.n_points;
+        m.clear_journal();
         if (have_window) {
             d_cells.reserve(cells.size());
             FLS_HIP(hipMemcpyAsync(d_cells.p, cells.data(), cells.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
         }
-        upload(s);
+        if (hash) d_table.reserve(table.size());
+        d_pts.reserve(used + used / 2 + (size_t(1) << 16));  // room for growth without reallocation
+        if (hash) FLS_HIP(hipMemcpyAsync(d_table.p, table.data(), table.size() * sizeof(HashEntry), hipMemcpyHostToDevice, s));
+        if (used) FLS_HIP(hipMemcpyAsync(d_pts.p, pts.data(), used * sizeof(Pt4), hipMemcpyHostToDevice, s));
+        FLS_HIP(hipStreamSynchronize(s));
+        std::vector<uint2>().swap(cells);  // the device copy is authoritative from here on
+        std::vector<Pt4>().swap(pts);
+    }
+
+    // Collect the journal of `m` into update records.  Returns false when a full rebuild is required.
+    bool collect_incremental(HostIvox& m) {
+        if (!have_window || want_hash) return false;
+        pt_upd.clear();
+        cell_upd.clear();
+        for (unsigned long long key : m.evicted_keys) {
+            int x, y, z;
+            unpack_key(key, x, y, z);
+            size_t idx;
+            if (cell_index(x, y, z, idx)) cell_upd.push_back(CellUpd{idx, 0u, 0u});
+        }
+        size_t new_used = used, new_garbage = garbage;
+        for (int vi : m.touched) {
+            HostIvox::Voxel& v = m.pool[vi];
+            if (!v.alive) continue;  // created and evicted inside the same batch
+            int x, y, z;
+            unpack_key(v.key, x, y, z);
+            size_t idx;
+            if (!cell_index(x, y, z, idx)) return false;  // grew out of the window
+            const unsigned cnt = unsigned(v.pts.size());
+            unsigned from = v.img_cnt;
+            if (cnt > v.img_cap) {  // relocate the bucket to the end of the array, twice the room
+                const unsigned cap = cap_for(cnt);
+                if (new_used + cap > d_pts.cap) return false;
+                new_garbage += v.img_cap;
+                v.img_begin = unsigned(new_used);
+                v.img_cap = cap;
+                new_used += cap;
+                from = 0;
+            }
+            for (unsigned k = from; k < cnt; ++k) pt_upd.push_back(PtUpd{v.img_begin + k, v.pts[k].x, v.pts[k].y, v.pts[k].z, v.pts[k].id});
+            v.img_cnt = cnt;
+            cell_upd.push_back(CellUpd{idx, v.img_begin, cnt});
+        }
+        if (new_garbage * 2 > new_used && new_used > (size_t(1) << 20)) return false;  // compact
+        used = new_used;
+        garbage = new_garbage;
+        n_pts_live = m.n_points;
+        m.clear_journal();
+        return true;
     }
 };
 

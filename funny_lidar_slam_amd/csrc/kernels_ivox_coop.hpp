@@ -343,4 +343,66 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
     loam_tail<kFitThreads>(st, sm, nullptr, 0, partials, (int)gridDim.x, rot_thr, pos_thr, T44, last_rot, last_pos, it, mb, match_id);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Map maintenance on the device
+//   ivox_apply_updates_kernel   scatter {slot, point} and {cell, begin, count} records into the resident image
+//   ivox_add_decide_kernel      the per-point down-sampling decision of LoamPointToPlaneIVOX::AddCloudToLocalMap
+//                               (loam_point_to_plane_ivox.h:89-128) on the neighbour lists left by the last
+//                               PlanerMatch: code 0 = drop, 1 = points_to_add, 2 = point_no_need_downsample;
+//                               pw = pcl::transformPoint(p, T_) (double -> float)
+// ---------------------------------------------------------------------------------------------
+struct PtUpdDev { unsigned slot; float x, y, z; int id; };
+struct CellUpdDev { unsigned long long idx; unsigned begin, count; };
+
+__global__ void __launch_bounds__(256)
+ivox_apply_updates_kernel(const PtUpdDev* __restrict__ pu, const int npu, const CellUpdDev* __restrict__ cu, const int ncu,
+                          float4* __restrict__ pts, uint2* __restrict__ cells) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < npu) {
+        const PtUpdDev u = pu[i];
+        pts[u.slot] = make_float4(u.x, u.y, u.z, __int_as_float(u.id));
+    }
+    if (i < ncu) {
+        const CellUpdDev u = cu[i];
+        cells[u.idx] = make_uint2(u.begin, u.count);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ivox_add_decide_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                       const Pose16 Tw, const float4* __restrict__ nn_pts, const unsigned char* __restrict__ nn_cnt, const int nn_n,
+                       const double fs /* filter_size_map_min */, unsigned char* __restrict__ code, float4* __restrict__ pw_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double x = sx[i], y = sy[i], z = sz[i];
+    const float wx = (float)(((Tw.m[0] * x + Tw.m[4] * y) + Tw.m[8] * z) + Tw.m[12]);
+    const float wy = (float)(((Tw.m[1] * x + Tw.m[5] * y) + Tw.m[9] * z) + Tw.m[13]);
+    const float wz = (float)(((Tw.m[2] * x + Tw.m[6] * y) + Tw.m[10] * z) + Tw.m[14]);
+    pw_out[i] = make_float4(wx, wy, wz, 0.f);
+    const int cnt = i < nn_n ? nn_cnt[i] : 0;
+    unsigned char c = 1;  // no neighbours: add (:126)
+    if (cnt > 0) {
+        const double half = 0.5 * fs;
+        const double c0 = (floor((double)wx / fs) + 0.5) * fs, c1 = (floor((double)wy / fs) + 0.5) * fs, c2 = (floor((double)wz / fs) + 0.5) * fs;
+        const float4 n0 = nn_pts[(size_t)i * 5];
+        const double d0 = (double)n0.x - c0, d1 = (double)n0.y - c1, d2 = (double)n0.z - c2;
+        if (fabs(d0) > half && fabs(d1) > half && fabs(d2) > half) {
+            c = 2;  // :103-108
+        } else {
+            const double e0 = (double)wx - c0, e1 = (double)wy - c1, e2 = (double)wz - c2;
+            const double dist = (e0 * e0 + e1 * e1) + e2 * e2;
+            bool need_add = true;
+            if (cnt >= 5) {
+                for (int k = 0; k < 5 && need_add; ++k) {
+                    const float4 q = nn_pts[(size_t)i * 5 + k];
+                    const double f0 = (double)q.x - c0, f1 = (double)q.y - c1, f2 = (double)q.z - c2;
+                    if ((f0 * f0 + f1 * f1) + f2 * f2 < dist + 1.0e-6) need_add = false;
+                }
+            }
+            c = need_add ? 1 : 0;
+        }
+    }
+    code[i] = c;
+}
+
 }  // namespace fls

@@ -18,7 +18,13 @@ namespace fls {
 struct P2PlaneIvoxMatcher final : fls_matcher {
     HostIvox ivox;
     GridImage image;
-    bool image_dirty = true;
+    bool image_dirty = true, image_built = false;
+    size_t n_incremental = 0, n_full_rebuilds = 0;
+    PinnedBuf<char> upd_stage;
+    DevBuf<unsigned char> d_code;
+    DevBuf<float4> d_pw;
+    std::vector<unsigned char> h_code;
+    std::vector<Pt4> h_pw;
     DevBuf<unsigned> d_ticket;
     bool use_dense = true; // dense voxel window instead of the hash table when the map extent allows (FLS_IVOX_DENSE=0 disables)
     int variant = 4;       // lanes cooperating on one query in ivox_knn_kernel: 4 or 8 (FLS_IVOX_VARIANT)
@@ -52,11 +58,39 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         ivox.resolution = 0.5f;       // InitIVox :53-58
         ivox.inv_resolution = 1.0f / 0.5f;
         ivox.capacity = 1000000;
+        if (const char* e = std::getenv("FLS_IVOX_CAPACITY")) { const long c = std::atol(e); if (c > 1) ivox.capacity = size_t(c); }  // test hook (LRU eviction)
         return FLS_OK;
     }
 
+    // bring the device image up to date with `ivox`: scatter the journal when possible, else re-flatten
     void refresh_image() {
-        if (image_dirty) { image.build_from_ivox(ivox, stream); image_dirty = false; }
+        if (!image_dirty) return;
+        image.want_hash = !use_dense;
+        if (image_built && image.collect_incremental(ivox)) {
+            const size_t np = image.pt_upd.size(), nc = image.cell_upd.size();
+            if (np + nc) {
+                image.d_pt_upd.reserve(std::max<size_t>(np, 1));
+                image.d_cell_upd.reserve(std::max<size_t>(nc, 1));
+                upd_stage.reserve(np * sizeof(GridImage::PtUpd) + nc * sizeof(GridImage::CellUpd) + 16);
+                std::memcpy(upd_stage.p, image.pt_upd.data(), np * sizeof(GridImage::PtUpd));
+                char* cpos = upd_stage.p + np * sizeof(GridImage::PtUpd);
+                std::memcpy(cpos, image.cell_upd.data(), nc * sizeof(GridImage::CellUpd));
+                if (np) FLS_HIP(hipMemcpyAsync(image.d_pt_upd.p, upd_stage.p, np * sizeof(GridImage::PtUpd), hipMemcpyHostToDevice, stream));
+                if (nc) FLS_HIP(hipMemcpyAsync(image.d_cell_upd.p, cpos, nc * sizeof(GridImage::CellUpd), hipMemcpyHostToDevice, stream));
+                const size_t m = std::max(np, nc);
+                hipLaunchKernelGGL(ivox_apply_updates_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, stream,
+                                   (const PtUpdDev*)image.d_pt_upd.p, int(np), (const CellUpdDev*)image.d_cell_upd.p, int(nc), image.d_pts.p,
+                                   image.d_cells.p);
+                FLS_HIP(hipGetLastError());
+                FLS_HIP(hipStreamSynchronize(stream));  // the staging buffer is reused by the next update
+            }
+            ++n_incremental;
+        } else {
+            image.build_from_ivox(ivox, stream);
+            image_built = true;
+            ++n_full_rebuilds;
+        }
+        image_dirty = false;
     }
 
     // pcl::transformPoint with Affine3d(T_): double evaluation, float result
@@ -85,15 +119,44 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         return add_cloud_impl(cloud);
     }
 
-    fls_status add_cloud_impl(const std::vector<PtI>& planar_cloud) {
-        if (p.is_localization_mode) { is_first = true; ivox.clear(); }
+    fls_status add_cloud_impl(const std::vector<PtI>& planar_cloud, const bool from_resident_scan = false) {
+        if (p.is_localization_mode) { is_first = true; ivox.clear(); image_built = false; }
         fls_status rc = FLS_OK;
         if (is_first) {
             rc = ivox.add_points(planar_cloud.data(), planar_cloud.size());
             if (rc != FLS_OK) return rc;
             is_first = false;
+        } else if (from_resident_scan) {
+            // :79-131 on the device (the cloud is the scan just matched, still resident): decision code + world point
+            // per source point; the host only walks the codes to build the two insertion lists in index order.
+            std::vector<PtI> to_add, no_downsample;
+            const size_t n = std::min(number_planar_point, scan.n);
+            if (n) {
+                d_code.reserve(n);
+                d_pw.reserve(n);
+                h_code.resize(n);
+                h_pw.resize(n);
+                Pose16 Tw;
+                std::memcpy(Tw.m, T_, sizeof(Tw.m));
+                hipLaunchKernelGGL(ivox_add_decide_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p,
+                                   int(n), Tw, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, int(nn_n), filter_size_map_min,
+                                   d_code.p, d_pw.p);
+                FLS_HIP(hipGetLastError());
+                FLS_HIP(hipMemcpyAsync(h_code.data(), d_code.p, n, hipMemcpyDeviceToHost, stream));
+                FLS_HIP(hipMemcpyAsync(h_pw.data(), d_pw.p, n * sizeof(float4), hipMemcpyDeviceToHost, stream));
+                FLS_HIP(hipStreamSynchronize(stream));
+                for (size_t i = 0; i < n; ++i) {
+                    if (h_code[i] == 0) continue;
+                    const PtI pw{h_pw[i].x, h_pw[i].y, h_pw[i].z, scan.host[i].i};
+                    (h_code[i] == 1 ? to_add : no_downsample).push_back(pw);
+                }
+            }
+            rc = ivox.add_points(to_add.data(), to_add.size());
+            if (rc != FLS_OK) return rc;
+            rc = ivox.add_points(no_downsample.data(), no_downsample.size());
+            if (rc != FLS_OK) return rc;
         } else {
-            // :79-131  decisions use nearest_points_ of the LAST PlanerMatch and T_ (body-frame cloud expected)
+            // external non-first call with an arbitrary cloud: same rule on the host (:79-131)
             download_nn();
             std::vector<PtI> to_add, no_downsample;
             const double fs = filter_size_map_min, half = 0.5 * filter_size_map_min;
@@ -207,7 +270,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
         if (has_converge && !p.is_localization_mode && update_map) {  // :205-206
-            const fls_status arc = add_cloud_impl(scan.host);
+            const fls_status arc = add_cloud_impl(scan.host, /*from_resident_scan=*/true);
             if (arc != FLS_OK) rc = arc;
             stats.map_updated = 1;
         }
@@ -236,7 +299,12 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         }
         return int(n);
     }
-    size_t map_size(int) const override { return ivox.n_points; }
+    size_t map_size(int slot) const override {
+        if (slot == 100) return n_incremental;    // introspection: image updates applied as scatter lists
+        if (slot == 101) return n_full_rebuilds;  //                ... as full re-flatten + upload
+        if (slot == 102) return ivox.n_alive;     // occupied voxels
+        return ivox.n_points;
+    }
 };
 
 }  // namespace fls

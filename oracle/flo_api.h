@@ -93,6 +93,7 @@ int flo_get_counters(void* h, flo_counters* out);
 int flo_get_last_system(void* h, double* H36, double* g6);
 size_t flo_map_size(void* h, int slot); /* points (iVox / kd maps) or voxels (NDT) */
 size_t flo_map_voxels(void* h);
+void flo_set_ivox_capacity(void* h, size_t cap); /* test hook for the LRU eviction rule */
 /* dump of the map in insertion-id order: xyz (n x 3) */
 size_t flo_map_dump(void* h, int slot, float* xyz, size_t cap_points);
 /* NDT voxel dump: keys (n x 3 int32), mu (n x 3), info (n x 9 col-major), estimated (n) */

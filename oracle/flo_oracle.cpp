@@ -1034,6 +1034,10 @@ int flo_get_last_system(void* h, double* H36, double* g6) {
     return 0;
 }
 size_t flo_map_size(void* h, int slot) { return static_cast<MatcherBase*>(h)->MapSize(slot); }
+void flo_set_ivox_capacity(void* h, size_t cap) {  /* test hook: the reference hard-codes 1,000,000 (ivox_map.h:35) */
+    auto* m = dynamic_cast<P2PlaneIvox*>(static_cast<MatcherBase*>(h));
+    if (m) m->ivox->capacity_ = cap;
+}
 size_t flo_map_voxels(void* h) {
     auto* m = dynamic_cast<P2PlaneIvox*>(static_cast<MatcherBase*>(h));
     return m ? m->ivox->grids_map_.size() : 0;

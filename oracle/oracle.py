@@ -120,6 +120,8 @@ def lib():
         L.flo_map_size.argtypes = [C.c_void_p, C.c_int]
         L.flo_map_voxels.restype = C.c_size_t
         L.flo_map_voxels.argtypes = [C.c_void_p]
+        L.flo_set_ivox_capacity.restype = None
+        L.flo_set_ivox_capacity.argtypes = [C.c_void_p, C.c_size_t]
         L.flo_map_dump.restype = C.c_size_t
         L.flo_map_dump.argtypes = [C.c_void_p, C.c_int, fp, C.c_size_t]
         L.flo_ndt_dump.restype = C.c_size_t
@@ -239,6 +241,9 @@ class OracleMatcher:
 
     def map_voxels(self):
         return int(lib().flo_map_voxels(self._h))
+
+    def set_ivox_capacity(self, cap: int):
+        lib().flo_set_ivox_capacity(self._h, int(cap))
 
     def map_dump(self, slot=0):
         n = self.map_size(slot)

@@ -111,3 +111,50 @@ def test_pcl_layout_stride8_equals_packed():
         m.Match(reg.PointcloudCluster(planar_cloud_=f(cfg["scan"])), T, update_map=False)
         res.append(T.copy())
     assert np.array_equal(res[0], res[1])
+
+
+def _replay(n_scans, capacity=None, monkeypatch=None):
+    """Mapping-mode replay along a short trajectory: Match -> AddCloudToLocalMap rule -> next Match."""
+    scene = synth.make_scene()
+    rng = synth.rng_for(1, 11)
+    radius = 30.0
+    mp = synth.sample_map(scene, 60000, synth.rng_for(1, 0, 5), radius=radius)
+    lid = dict(synth.VELODYNE_64, n_az=60)
+    if capacity is not None:
+        monkeypatch.setenv("FLS_IVOX_CAPACITY", str(capacity))
+    m = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+    o = util.oracle_for("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+    if capacity is not None:
+        o.set_ivox_capacity(capacity)
+    m.AddCloudToLocalMap([mp])
+    o.AddCloudToLocalMap(mp)
+    assert m.map_size() == o.map_size() and m.map_size(102) == o.map_voxels()
+    Tgt = np.eye(4)
+    guess = np.eye(4)
+    for k in range(n_scans):
+        Tgt = Tgt @ synth.random_pose(rng, 1.0, 0.6)
+        scan = synth.cast_scan(scene, Tgt, rng=rng, max_range=radius + 8.0, **lid)  # sees beyond the mapped disc: the map grows
+        T = guess.copy()
+        ok = m.Match(reg.PointcloudCluster(planar_cloud_=scan), T, update_map=True)
+        ok_ref, T_ref = o.Match(scan, guess, update_map=True)
+        util.assert_same_registration(m, o, ok, T, ok_ref, T_ref, sets_only_tail=True, max_tie_rows=int(o.counters().tie_queries))
+        assert m.map_size() == o.map_size(), (k, m.map_size(), o.map_size())
+        assert m.map_size(102) == o.map_voxels()
+        guess = T_ref
+    return m, o
+
+
+def test_mapping_replay_incremental_image_updates():
+    """8 scans with map growth: the device image is maintained by scatter updates (no full re-flatten after the
+    first build) and every Match still agrees with the oracle bit-for-bit in its correspondences."""
+    m, o = _replay(8)
+    assert m.map_size(100) >= 7, "map updates should be incremental"
+    assert m.map_size(101) == 1, "only the initial build is a full flatten"
+    assert m.map_size() > 60000
+
+
+def test_mapping_replay_with_lru_eviction(monkeypatch):
+    """Small iVox capacity (test hook; the reference hard-codes 1e6 voxels): the LRU rule of ivox_map.cpp:133-136
+    evicts voxels during the replay; evicted cells must disappear from the device image."""
+    m, o = _replay(6, capacity=9000, monkeypatch=monkeypatch)
+    assert o.map_voxels() <= 9000
