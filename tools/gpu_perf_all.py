@@ -35,18 +35,21 @@ for cid, mode, y, loc in CASES:
     ms, nl, pi = m.kernel_time()
     # CPU oracle, best of a few thread counts
     best = None
-    for thr in (16, 64):
+    one_thread = None
+    for thr in (1, 16, 64):
         O.set_threads(thr)
         o = util.oracle_for(mode, y, loc); o.AddCloudToLocalMap(*maps)
         tt = []
         for _ in range(3):
             t = time.perf_counter(); ok_ref, T_ref = o.Match(cfg["scan"], np.eye(4), src1=corner, update_map=False); tt.append(time.perf_counter() - t)
+        if thr == 1:
+            one_thread = min(tt)
         if best is None or min(tt) < best[0]:
             best = (min(tt), thr, o.stats.iterations, o.stats.n_valid)
     dt, dr = synth.pose_error(T, T_ref)
     row = dict(config=cid, mode=mode, n_src=int(m.stats.n_source), n_src_corner=int(m.stats.n_source_corner), map=int(cfg["map"].shape[0]),
                iters=int(m.stats.iterations), ok=bool(ok), gpu_match_us=1e6 * float(np.median(ts)), gpu_scans_s=1.0 / float(np.median(ts)),
-               corr_kernel_avg_us=1e3 * ms / max(nl, 1), cpu_match_ms=1e3 * best[0], cpu_threads=best[1], cpu_scans_s=1.0 / best[0],
+               corr_kernel_avg_us=1e3 * ms / max(nl, 1), cpu_match_ms=1e3 * best[0], cpu_threads=best[1], cpu_scans_s=1.0 / best[0], cpu_1thr_scans_s=1.0 / one_thread,
                speedup=best[0] / float(np.median(ts)), pose_err_m=dt, pose_err_rad=dr, add_map_ms=1e3 * t_add)
     rows.append(row)
     print(json.dumps(row), flush=True)
