@@ -116,23 +116,32 @@ def main():
     cluster = reg.PointcloudCluster(planar_cloud_=cfg["scan"])
     m.UploadScan(cluster)  # inputs resident in HBM before the timed region
 
-    T_work = np.empty((4, 4))
-    T_init = cfg["T_init"]
+    run, T_work = m.resident_call(cfg["T_init"], update_map=False)  # every step registers from the same initial guess
 
     def step():
-        T_work[...] = T_init  # every step registers from the same initial guess (identity)
-        ok = m.MatchResident(T_work, update_map=False)
-        return ok, T_work
+        rc = run()
+        if rc < 0:
+            raise RuntimeError(f"fls_match_resident failed: {rc}")
+        return rc == 0, T_work
 
     for _ in range(args.warmup):
         step()
-    m.set_profiling(True)  # hipEvents around every correspondence launch of the timed region
+    # hipEvents bracket every correspondence-kernel launch of every EVENT_EVERY-th step of the timed region
+    # (each recorded event is a marker packet between two kernels: ~2-3 us; bracketing every step would cost
+    # ~10 % of `value`).  The events are settled after the region.
+    EVENT_EVERY = 4
+    m.kernel_time()  # reset the accumulators
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ok, T = step()
+    for k in range(args.steps):
+        if k % EVENT_EVERY == 0:
+            m.set_profiling(True)
+            ok, T = step()
+            m.set_profiling(False)
+        else:
+            ok, T = step()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()

@@ -167,16 +167,15 @@ size_t fls_map_size(fls_handle h, int slot) { return h ? h->map_size(slot) : 0; 
 
 fls_status fls_set_profiling(fls_handle h, int enable) {
     if (!h) return FLS_ERR_INVALID;
-    h->profiling = (enable & 1) != 0;
-    h->count_traffic = (enable & 2) != 0;
-    h->prof_ms = 0.0;
-    h->prof_launches = 0;
-    h->prof_point_iters = 0;
+    h->profiling = (enable & 1) != 0;       // accumulators are only reset by fls_get_kernel_time, so the flag can be
+    h->count_traffic = (enable & 2) != 0;   // toggled per Match (e.g. to bracket every n-th step of a timed region)
     return FLS_OK;
 }
 
 fls_status fls_get_kernel_time(fls_handle h, double* ms_total, int64_t* launches, uint64_t* point_iters) {
     if (!h) return FLS_ERR_INVALID;
+    const fls_status rc = guarded([&]() -> fls_status { FLS_HIP(hipSetDevice(h->device)); h->settle_events(); return FLS_OK; });
+    if (rc != FLS_OK) return rc;
     if (ms_total) *ms_total = h->prof_ms;
     if (launches) *launches = h->prof_launches;
     if (point_iters) *point_iters = h->prof_point_iters;

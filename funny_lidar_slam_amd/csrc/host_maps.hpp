@@ -321,6 +321,15 @@ struct GridImage {
             v.img_cnt = cnt;
             cell_upd.push_back(CellUpd{idx, v.img_begin, cnt});
         }
+        // a voxel evicted and re-created inside one batch yields two records for the same cell: the scatter kernel
+        // writes records in parallel, so keep only the LAST record per cell (stable sort, then unique from the back)
+        std::stable_sort(cell_upd.begin(), cell_upd.end(), [](const CellUpd& a, const CellUpd& b) { return a.idx < b.idx; });
+        size_t w = 0;
+        for (size_t r = 0; r < cell_upd.size(); ++r) {
+            if (r + 1 < cell_upd.size() && cell_upd[r + 1].idx == cell_upd[r].idx) continue;
+            cell_upd[w++] = cell_upd[r];
+        }
+        cell_upd.resize(w);
         if (new_garbage * 2 > new_used && new_used > (size_t(1) << 20)) return false;  // compact
         used = new_used;
         garbage = new_garbage;

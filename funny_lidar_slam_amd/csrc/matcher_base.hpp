@@ -20,7 +20,14 @@ struct fls_matcher {
     // profiling (fls_set_profiling)
     bool profiling = false;      // hipEvents around every correspondence launch
     bool count_traffic = false;  // run the <COUNT=true> kernel variants (device traffic counters)
-    std::vector<hipEvent_t> ev;  // 2 per possible iteration
+    // hipEvent pairs around the correspondence launches: a ring of kEvRing Matches so that nothing is resolved
+    // (hipEventSynchronize / ElapsedTime) on the timed path; fls_get_kernel_time settles the pending pairs
+    static constexpr int kEvRing = 64;
+    std::vector<hipEvent_t> ev_pool;   // kEvRing x 2 x kMaxIter, created lazily
+    hipEvent_t* ev = nullptr;          // the current Match's slice: ev[2 * it], ev[2 * it + 1]
+    int ev_slot = -1;
+    struct PendingEv { int slot, iters; };
+    std::vector<PendingEv> ev_pending;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
     uint64_t prof_point_iters = 0;
@@ -36,7 +43,7 @@ struct fls_matcher {
     unsigned match_id = 0;
 
     virtual ~fls_matcher() {
-        for (auto e : ev) (void)hipEventDestroy(e);
+        for (auto e : ev_pool) if (e) (void)hipEventDestroy(e);
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
         if (mb_host) (void)hipHostFree(mb_host);
     }
@@ -61,11 +68,26 @@ struct fls_matcher {
         FLS_HIP(hipHostGetDevicePointer((void**)&mb_dev, mb_host, 0));
     }
     void ensure_events(int iters) {
-        while ((int)ev.size() < 2 * iters) {
-            hipEvent_t e;
-            FLS_HIP(hipEventCreate(&e));
-            ev.push_back(e);
+        if (ev_pool.empty()) ev_pool.assign(size_t(kEvRing) * 2 * fls::kMaxIter, nullptr);
+        ev_slot = (ev_slot + 1) % kEvRing;
+        for (const PendingEv& pe : ev_pending)
+            if (pe.slot == ev_slot) { settle_events(); break; }  // the ring wrapped around
+        ev = ev_pool.data() + size_t(ev_slot) * 2 * fls::kMaxIter;
+        for (int i = 0; i < 2 * iters; ++i)
+            if (!ev[i]) FLS_HIP(hipEventCreate(&ev[i]));
+    }
+    void settle_events() {
+        for (const PendingEv& pe : ev_pending) {
+            hipEvent_t* e = ev_pool.data() + size_t(pe.slot) * 2 * fls::kMaxIter;
+            for (int i = 0; i < pe.iters; ++i) {
+                float ms = 0.f;
+                FLS_HIP(hipEventSynchronize(e[2 * i + 1]));
+                FLS_HIP(hipEventElapsedTime(&ms, e[2 * i], e[2 * i + 1]));
+                prof_ms += ms;
+                prof_launches += 1;
+            }
         }
+        ev_pending.clear();
     }
     // Spin on the mailbox until the Gauss-Newton tail of iteration `target` (or an earlier one that hit the stop
     // rule) has published its result.  Returns the published word.  Falls back to the stream state every
@@ -95,16 +117,10 @@ struct fls_matcher {
         log_n = std::min(h_state.p->iter, fls::kMaxIter);
         log_stale = false;
     }
-    // account the hipEvent-bracketed launches of the executed iterations
+    // remember the hipEvent-bracketed launches of the executed iterations (settled lazily)
     void account_profile(int iters, size_t points_per_iter) {
         if (!profiling) return;
-        for (int i = 0; i < iters && 2 * i + 1 < (int)ev.size(); ++i) {
-            float ms = 0.f;
-            FLS_HIP(hipEventSynchronize(ev[2 * i + 1]));
-            FLS_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
-            prof_ms += ms;
-            prof_launches += 1;
-        }
+        ev_pending.push_back(PendingEv{ev_slot, std::min(iters, fls::kMaxIter)});
         prof_point_iters += uint64_t(iters) * points_per_iter;
     }
     // Gauss-Newton launch loop shared by every kind.  Iterations are enqueued in chunks sized by the previous

@@ -124,6 +124,24 @@ class RegistrationInterface:
         T[...] = self._Tview.T
         return rc == _lib.FLS_OK
 
+    def resident_call(self, T_init: np.ndarray, update_map: bool = False):
+        """Pre-bound zero-overhead form of MatchResident for tight loops: returns (run, T_view) where run()
+        re-registers from T_init (copied into the column-major call buffer by memmove) and returns the status;
+        T_view is the (4,4) row-major-looking view of the result (transpose of the column-major buffer)."""
+        init = np.ascontiguousarray(np.asarray(T_init, dtype=np.float64).reshape(4, 4).T).reshape(-1).copy()
+        buf = np.zeros(16, dtype=np.float64)
+        ptr = buf.ctypes.data_as(C.POINTER(C.c_double))
+        fn, h, flag, st = _lib.lib().fls_match_resident, self._h, 1 if update_map else 0, C.byref(self.stats)
+        src, dst, nbytes = init.ctypes.data, buf.ctypes.data, 128
+        move = C.memmove
+
+        def run():
+            move(dst, src, nbytes)
+            return fn(h, ptr, flag, st)
+
+        self._keep = (init, buf)
+        return run, buf.reshape(4, 4).T
+
     # -- introspection --------------------------------------------------------------------------
     def iteration_log(self, cap: int = 64):
         T = np.zeros((cap, 16)); nv = np.zeros(cap, np.int32); sr = np.zeros(cap)
