@@ -8,7 +8,8 @@
 //                          dwordx4 load per candidate (gather, so AoS-of-16B beats SoA here)
 //   * Gauss-Newton state : one GnState block (pose, stop flags, per-iteration log), device resident
 //                          for the whole Match; the host reads it back once at the end
-//   * per-wave partials  : 32 doubles per wave (21 upper-H + 6 g + res + count + 3 spare)
+//   * workgroup partials : 32 doubles per workgroup (21 upper-H + 6 g + res + count + 3 spare)
+//   * result mailbox     : host-mapped pinned memory written by the last workgroup (Mailbox)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -96,28 +97,6 @@ __host__ __device__ __forceinline__ unsigned hash_key(unsigned long long k) {
     k *= 0xc4ceb9fe1a85ec53ULL;
     k ^= k >> 33;
     return (unsigned)k;
-}
-
-// fixed-order 64-lane sum (same tree every run -> bit-reproducible results)
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// running top-5 by (d2, arrival order): strict '<' keeps the earlier candidate on exact ties
-__device__ __forceinline__ void top5_insert(float (&d)[5], unsigned (&s)[5], float dc, unsigned sc) {
-    if (dc < d[4]) {
-        d[4] = dc;
-        s[4] = sc;
-#pragma unroll
-        for (int j = 4; j > 0; --j) {
-            if (d[j] < d[j - 1]) {
-                const float td = d[j]; d[j] = d[j - 1]; d[j - 1] = td;
-                const unsigned ts = s[j]; s[j] = s[j - 1]; s[j - 1] = ts;
-            }
-        }
-    }
 }
 
 }  // namespace fls

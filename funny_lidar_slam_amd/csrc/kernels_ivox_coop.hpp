@@ -244,7 +244,7 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
         if (sub == 0 && active) nn_cnt[q] = (unsigned char)cnt;
     }
     if (COUNT) {
-        const double p = wave_sum((double)c_probes), hsum = wave_sum((double)c_hits), c = wave_sum((double)c_cand);
+        const double p = wave_sum_u((double)c_probes), hsum = wave_sum_u((double)c_hits), c = wave_sum_u((double)c_cand);
         if ((threadIdx.x & 63) == 0) {
             atomicAdd(&tc->probes, (unsigned long long)p);
             atomicAdd(&tc->hits, (unsigned long long)hsum);

@@ -139,7 +139,7 @@ __device__ __forceinline__ void xform_f(const RtFloat& rt, const float x, const 
 }
 
 __device__ __forceinline__ void count_traffic(TrafficCounters* tc, unsigned long long p, unsigned long long h, unsigned long long c) {
-    const double sp = wave_sum((double)p), sh = wave_sum((double)h), sc = wave_sum((double)c);
+    const double sp = wave_sum_u((double)p), sh = wave_sum_u((double)h), sc = wave_sum_u((double)c);
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&tc->probes, (unsigned long long)sp);
         atomicAdd(&tc->hits, (unsigned long long)sh);

@@ -25,11 +25,6 @@
 
 namespace fls {
 
-// IVoxMap::GenerateNearbyGrids NEARBY18 order (ivox_map.cpp:50-54)
-__device__ constexpr signed char kNearby18[19][3] = {
-    {0, 0, 0},  {-1, 0, 0}, {1, 0, 0},  {0, 1, 0},  {0, -1, 0}, {0, 0, -1}, {0, 0, 1},  {1, 1, 0},  {-1, 1, 0}, {1, -1, 0},
-    {-1, -1, 0}, {1, 0, 1}, {-1, 0, 1}, {1, 0, -1}, {-1, 0, -1}, {0, 1, 1}, {0, -1, 1}, {0, 1, -1}, {0, -1, -1}};
-
 // Point-to-plane residual on 5 neighbours (Appendix C.1).  nn[0] must be the nearest neighbour.
 // Returns false wherever the reference lambda returns early.
 __device__ __forceinline__ bool plane_residual_dev(const float4 (&nn)[5], const float spx, const float spy, const float spz,

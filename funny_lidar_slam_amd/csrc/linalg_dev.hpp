@@ -7,11 +7,11 @@
 //                          loam_point_to_plane_ivox.h:283, loam_full_kdtree.h:303)
 //      sym_eig_svd3       singular values / V of a symmetric 3x3 by two-sided Jacobi
 //                         (JacobiSVD at loam_full_kdtree.h:244)
-//  * one-thread, LDS/global-resident (dynamic indexing allowed), used once per
-//    Gauss-Newton iteration by the solve kernel:
-//      fullpiv_qr_solve6  H.fullPivHouseholderQr().solve(g)   loam_point_to_plane_ivox.h:167
-//      lu6_inverse_det    H.determinant(), H.inverse()        icp_optimized.h:129,133, incremental_ndt.h:311
-//      so3_exp            include/common/math_function.h:74-89
+//  * helpers of the Gauss-Newton tail (one lane, once per iteration):
+//      so3_exp_dev        include/common/math_function.h:74-89
+//      mat3_mul_dev, norm3d
+//    (the 6x6 solvers -- fullPivHouseholderQr().solve, PartialPivLU inverse -- are wave-cooperative and live
+//     in wave_solve.hpp)
 // Compiled with -ffp-contract=off: no FMA contraction, so the arithmetic is the
 // same sequence of IEEE mul/add the CPU path performs.
 #pragma once
@@ -250,133 +250,8 @@ __device__ __forceinline__ void jacobi_svd3_v(const double (&A)[3][3], double (&
 }
 
 // ---------------------------------------------------------------------------------------------
-// one-thread solvers on memory-resident (LDS) column-major 6x6
+// small helpers of the Gauss-Newton tail (the 6x6 solvers themselves are wave-cooperative: wave_solve.hpp)
 // ---------------------------------------------------------------------------------------------
-__device__ inline void householder_make(double* x, int n, double& tau, double& beta) {
-    double tail = 0.0;
-    for (int i = 1; i < n; ++i) tail += x[i] * x[i];
-    const double c0 = x[0];
-    if (n == 1 || tail <= FLS_DBL_MIN) {
-        tau = 0.0;
-        beta = c0;
-        for (int i = 1; i < n; ++i) x[i] = 0.0;
-    } else {
-        beta = sqrt(c0 * c0 + tail);
-        if (c0 >= 0.0) beta = -beta;
-        const double den = c0 - beta;
-        for (int i = 1; i < n; ++i) x[i] = x[i] / den;
-        tau = (beta - c0) / beta;
-    }
-}
-__device__ inline void householder_apply_left(double* M, int rows, int cols, int ld, const double* ess, double tau) {
-    if (rows == 1) {
-        for (int j = 0; j < cols; ++j) M[j * ld] *= (1.0 - tau);
-        return;
-    }
-    if (tau == 0.0) return;
-    for (int j = 0; j < cols; ++j) {
-        double* col = M + j * ld;
-        double tmp = 0.0;
-        for (int i = 1; i < rows; ++i) tmp += ess[i - 1] * col[i];
-        tmp += col[0];
-        col[0] -= tau * tmp;
-        for (int i = 1; i < rows; ++i) col[i] -= (tau * ess[i - 1]) * tmp;
-    }
-}
-
-// qr: 36 doubles work space holding H on entry (destroyed); c: 6 doubles holding g on entry; x out.
-__device__ inline void fullpiv_qr_solve6(double* qr, double* c, double* x, double* hcoef, int* rows_tr, int* perm) {
-    const int N = 6;
-    const double precision = FLS_DBL_EPS * 6.0;
-    double biggest = 0.0, maxpivot = 0.0;
-    int nonzero_pivots = N;
-    for (int i = 0; i < N; ++i) perm[i] = i;
-    int cols_tr[6];
-    for (int k = 0; k < N; ++k) {
-        int rb = k, cb = k;
-        double bc = fabs(qr[k + k * N]);
-        for (int j = k; j < N; ++j)
-            for (int i = k; i < N; ++i) {
-                const double v = fabs(qr[i + j * N]);
-                if (v > bc) { bc = v; rb = i; cb = j; }
-            }
-        if (k == 0) biggest = bc;
-        if (fabs(bc) <= fabs(biggest) * precision) {
-            nonzero_pivots = k;
-            for (int i = k; i < N; ++i) { rows_tr[i] = i; cols_tr[i] = i; hcoef[i] = 0.0; }
-            break;
-        }
-        rows_tr[k] = rb;
-        cols_tr[k] = cb;
-        if (k != rb)
-            for (int j = k; j < N; ++j) { const double t = qr[k + j * N]; qr[k + j * N] = qr[rb + j * N]; qr[rb + j * N] = t; }
-        if (k != cb)
-            for (int i = 0; i < N; ++i) { const double t = qr[i + k * N]; qr[i + k * N] = qr[i + cb * N]; qr[i + cb * N] = t; }
-        double beta;
-        householder_make(qr + k + k * N, N - k, hcoef[k], beta);
-        qr[k + k * N] = beta;
-        if (fabs(beta) > maxpivot) maxpivot = fabs(beta);
-        if (k + 1 < N) householder_apply_left(qr + k + (k + 1) * N, N - k, N - k - 1, N, qr + (k + 1) + k * N, hcoef[k]);
-    }
-    for (int k = 0; k < N; ++k) { const int t = perm[k]; perm[k] = perm[cols_tr[k]]; perm[cols_tr[k]] = t; }
-    const double premult = fabs(maxpivot) * (FLS_DBL_EPS * 6.0);
-    int rank = 0;
-    for (int i = 0; i < nonzero_pivots; ++i) rank += (fabs(qr[i + i * N]) > premult) ? 1 : 0;
-    for (int i = 0; i < N; ++i) x[i] = 0.0;
-    if (rank == 0) return;
-    for (int k = 0; k < rank; ++k) {
-        const double t = c[k]; c[k] = c[rows_tr[k]]; c[rows_tr[k]] = t;
-        householder_apply_left(c + k, N - k, 1, N, qr + (k + 1) + k * N, hcoef[k]);
-    }
-    for (int i = rank - 1; i >= 0; --i) {
-        c[i] /= qr[i + i * N];
-        for (int r = 0; r < i; ++r) c[r] -= c[i] * qr[r + i * N];
-    }
-    for (int i = 0; i < rank; ++i) x[perm[i]] = c[i];
-}
-
-// lu: 36 doubles holding H on entry; inv: 36 doubles out; returns determinant.
-__device__ inline double lu6_inverse_det(double* lu, double* inv, int* row_tr) {
-    const int N = 6;
-    int ntr = 0;
-    for (int k = 0; k < N; ++k) {
-        int rb = k;
-        double bc = fabs(lu[k + k * N]);
-        for (int i = k + 1; i < N; ++i) {
-            const double v = fabs(lu[i + k * N]);
-            if (v > bc) { bc = v; rb = i; }
-        }
-        row_tr[k] = rb;
-        if (bc != 0.0) {
-            if (k != rb) {
-                for (int j = 0; j < N; ++j) { const double t = lu[k + j * N]; lu[k + j * N] = lu[rb + j * N]; lu[rb + j * N] = t; }
-                ++ntr;
-            }
-            for (int i = k + 1; i < N; ++i) lu[i + k * N] /= lu[k + k * N];
-        }
-        for (int j = k + 1; j < N; ++j)
-            for (int i = k + 1; i < N; ++i) lu[i + j * N] -= lu[i + k * N] * lu[k + j * N];
-    }
-    double det = lu[0];
-    for (int i = 1; i < N; ++i) det *= lu[i + i * N];
-    det = (ntr & 1) ? -det : det;
-    for (int j = 0; j < N; ++j)
-        for (int i = 0; i < N; ++i) inv[i + j * N] = (i == j) ? 1.0 : 0.0;
-    for (int k = 0; k < N; ++k)
-        if (row_tr[k] != k)
-            for (int j = 0; j < N; ++j) { const double t = inv[k + j * N]; inv[k + j * N] = inv[row_tr[k] + j * N]; inv[row_tr[k] + j * N] = t; }
-    for (int j = 0; j < N; ++j) {
-        double* c = inv + j * N;
-        for (int i = 0; i < N; ++i)
-            for (int r = i + 1; r < N; ++r) c[r] -= c[i] * lu[r + i * N];
-        for (int i = N - 1; i >= 0; --i) {
-            c[i] /= lu[i + i * N];
-            for (int r = 0; r < i; ++r) c[r] -= c[i] * lu[r + i * N];
-        }
-    }
-    return det;
-}
-
 __device__ inline double norm3d(const double* v) { return sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
 
 // SO3Exp (math_function.h:74-89): identity if |v| <= eps, else Rodrigues.  R 3x3 column-major.

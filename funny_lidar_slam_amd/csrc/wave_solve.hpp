@@ -9,8 +9,8 @@
 //                         LDS-resident matrix; pivot search, row/column swaps and the Householder update of
 //                         all trailing columns happen in parallel; the rhs lives in lanes 0..5 and moves
 //                         by v_readlane.  Same arithmetic expressions, same summation order as
-//                         linalg_dev.hpp::fullpiv_qr_solve6 (and therefore as the CPU path) -- only the
-//                         single-thread LDS latency chain (~29 us per iteration) is gone.
+//                         the scalar algorithm of the CPU path -- only the single-thread LDS latency chain
+//                         (~29 us per iteration in the first version) is gone.
 //   lu6_solve_wave        PartialPivLU<6x6>: determinant, explicit inverse, inverse * b for ICP / NDT.
 #pragma once
 #include "linalg_dev.hpp"
@@ -53,6 +53,9 @@ __device__ __forceinline__ double wave_max_dpp(double v) {
     v = dpp_max<0x143, 0xc>(v);
     return v;
 }
+
+// counters of the traffic-counting kernel variants: exact integers in doubles, total in every lane
+__device__ __forceinline__ double wave_sum_u(const double v) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wave_sum_dpp(v)), 63), __builtin_amdgcn_readlane(__double2loint(wave_sum_dpp(v)), 63)); }
 
 __device__ __forceinline__ double readlane_f64(const double v, const int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);

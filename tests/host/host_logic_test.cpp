@@ -1,0 +1,144 @@
+// Host-logic checks of the PRODUCT's C++ bookkeeping that need no GPU (compiled with hipcc, run on the CPU):
+//   * HostIvox insert / LRU-evict semantics vs a straightforward list+map model and vs the oracle's iVox
+//   * voxel_grid (PCL VoxelGrid semantics) vs the oracle's
+//   * GridImage::collect_incremental invariants (disjoint slot regions, unique cell records, eviction records)
+// No HIP runtime call is made: only host members are touched.
+#include "../../funny_lidar_slam_amd/csrc/host_maps.hpp"
+#include "../../oracle/flo_api.h"
+#include <cstdio>
+#include <list>
+#include <map>
+#include <random>
+#include <set>
+
+using namespace fls;
+
+#define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+static std::vector<PtI> random_cloud(std::mt19937& rng, size_t n, float extent) {
+    std::uniform_real_distribution<float> u(-extent, extent), w(-2.f, 2.f);
+    std::vector<PtI> c(n);
+    for (auto& p : c) { p.x = u(rng); p.y = u(rng); p.z = w(rng); p.i = u(rng); }
+    return c;
+}
+
+int main() {
+    std::mt19937 rng(12345);
+    // ---- 1. HostIvox vs a model with the reference's rule (ivox_map.cpp:122-143) -----------------------
+    {
+        HostIvox iv;
+        iv.capacity = 300;
+        std::list<std::pair<unsigned long long, std::vector<int>>> cache;  // front = most recent
+        std::map<unsigned long long, decltype(cache)::iterator> index;
+        int next_id = 0;
+        for (int round = 0; round < 6; ++round) {
+            const auto cloud = random_cloud(rng, 2000, 6.0f + round);
+            CHECK(iv.add_points(cloud.data(), cloud.size()) == FLS_OK);
+            for (const PtI& p : cloud) {
+                int kx, ky, kz;
+                HostIvox::key_of(p.x, p.y, p.z, iv.inv_resolution, kx, ky, kz);
+                const unsigned long long key = pack_key(kx, ky, kz);
+                auto it = index.find(key);
+                if (it == index.end()) {
+                    cache.push_front({key, {next_id++}});
+                    index[key] = cache.begin();
+                    if (index.size() >= iv.capacity) { index.erase(cache.back().first); cache.pop_back(); }
+                } else {
+                    it->second->second.push_back(next_id++);
+                    cache.splice(cache.begin(), cache, it->second);
+                    index[key] = cache.begin();
+                }
+            }
+            CHECK(iv.n_alive == index.size());
+            size_t pts = 0;
+            for (auto& kv : cache) pts += kv.second.size();
+            CHECK(iv.n_points == pts);
+            // LRU order and contents
+            int v = iv.head;
+            for (auto& kv : cache) {
+                CHECK(v >= 0 && iv.pool[v].alive && iv.pool[v].key == kv.first && iv.pool[v].pts.size() == kv.second.size());
+                for (size_t k = 0; k < kv.second.size(); ++k) CHECK(iv.pool[v].pts[k].id == kv.second[k]);
+                v = iv.pool[v].next;
+            }
+            CHECK(v == -1);
+        }
+        int x, y, z;
+        unpack_key(pack_key(-5, 1048000, -1048000), x, y, z);
+        CHECK(x == -5 && y == 1048000 && z == -1048000);
+        PtI far{6.0e5f, 0.f, 0.f, 0.f};  // 1.2e6 voxels out: beyond the 21-bit key range
+        CHECK(iv.add_points(&far, 1) == FLS_ERR_RANGE);
+    }
+    // ---- 2. HostIvox vs the oracle's iVox through its C API (sizes after inserts) -----------------------
+    {
+        flo_params p{};
+        p.struct_size = sizeof(p);
+        p.max_iterations = 1; p.point_to_planar_thres = 0.1; p.position_converge_thres = 0.005; p.rotation_converge_thres = 0.001;
+        void* o = flo_create(FLO_P2PLANE_IVOX, &p);
+        CHECK(o != nullptr);
+        flo_set_ivox_capacity(o, 500);
+        HostIvox iv;
+        iv.capacity = 500;
+        const auto cloud = random_cloud(rng, 20000, 9.0f);
+        std::vector<float> flat(cloud.size() * 4);
+        for (size_t i = 0; i < cloud.size(); ++i) { flat[4 * i] = cloud[i].x; flat[4 * i + 1] = cloud[i].y; flat[4 * i + 2] = cloud[i].z; flat[4 * i + 3] = cloud[i].i; }
+        flo_add_cloud(o, flat.data(), cloud.size(), nullptr, 0, 4);
+        CHECK(iv.add_points(cloud.data(), cloud.size()) == FLS_OK);
+        CHECK(iv.n_points == flo_map_size(o, 0));
+        CHECK(iv.n_alive == flo_map_voxels(o));
+        flo_destroy(o);
+    }
+    // ---- 3. voxel_grid vs the oracle -------------------------------------------------------------------
+    for (float leaf : {0.2f, 0.4f, 1.0f}) {
+        const auto cloud = random_cloud(rng, 30000, 15.0f);
+        std::vector<float> flat(cloud.size() * 4), out(cloud.size() * 4);
+        for (size_t i = 0; i < cloud.size(); ++i) { flat[4 * i] = cloud[i].x; flat[4 * i + 1] = cloud[i].y; flat[4 * i + 2] = cloud[i].z; flat[4 * i + 3] = cloud[i].i; }
+        const size_t m = flo_voxel_grid(flat.data(), cloud.size(), 4, leaf, out.data());
+        const auto vg = voxel_grid(cloud, leaf);
+        CHECK(vg.size() == m);
+        for (size_t i = 0; i < m; ++i)
+            CHECK(vg[i].x == out[4 * i] && vg[i].y == out[4 * i + 1] && vg[i].z == out[4 * i + 2] && vg[i].i == out[4 * i + 3]);
+    }
+    CHECK(voxel_grid(std::vector<PtI>(), 0.4f).empty());
+    // ---- 4. incremental image bookkeeping --------------------------------------------------------------
+    {
+        HostIvox iv;
+        iv.capacity = 400;
+        GridImage img;
+        img.want_hash = false;
+        img.have_window = true;
+        img.win_o[0] = img.win_o[1] = img.win_o[2] = -64;
+        img.win_n[0] = img.win_n[1] = img.win_n[2] = 128;
+        img.d_pts.cap = size_t(1) << 22;  // pretend the device array is large (never dereferenced here)
+        std::set<size_t> live_cells;
+        for (int round = 0; round < 8; ++round) {
+            const auto cloud = random_cloud(rng, 1500, 4.0f + 2.0f * round);
+            CHECK(iv.add_points(cloud.data(), cloud.size()) == FLS_OK);
+            CHECK(img.collect_incremental(iv));
+            CHECK(iv.touched.empty() && iv.evicted_keys.empty());
+            std::set<unsigned long long> seen_cells;
+            for (const auto& c : img.cell_upd) CHECK(seen_cells.insert(c.idx).second);  // unique per cell
+            std::set<unsigned> seen_slots;
+            for (const auto& u : img.pt_upd) CHECK(seen_slots.insert(u.slot).second);    // unique per slot
+            for (const auto& c : img.cell_upd) { if (c.count) live_cells.insert(c.idx); else live_cells.erase(c.idx); }
+            // regions of alive voxels are disjoint and hold exactly the voxel's points
+            std::vector<std::pair<unsigned, unsigned>> regions;
+            size_t alive = 0;
+            for (const auto& v : iv.pool) {
+                if (!v.alive) continue;
+                ++alive;
+                CHECK(v.img_cnt == v.pts.size() && v.img_cnt <= v.img_cap && v.img_begin + v.img_cap <= img.used);
+                regions.push_back({v.img_begin, v.img_begin + v.img_cap});
+            }
+            std::sort(regions.begin(), regions.end());
+            for (size_t i = 1; i < regions.size(); ++i) CHECK(regions[i - 1].second <= regions[i].first);
+            CHECK(live_cells.size() == alive);  // every alive voxel has a live cell, every evicted one was cleared
+        }
+        CHECK(GridImage::cap_for(0) == 4 && GridImage::cap_for(5) == 8 && GridImage::cap_for(8) == 8 && GridImage::cap_for(9) == 16);
+        // a point outside the window forces a full rebuild
+        PtI out{200.f, 0.f, 0.f, 0.f};
+        CHECK(iv.add_points(&out, 1) == FLS_OK);
+        CHECK(!img.collect_incremental(iv));
+    }
+    std::printf("host logic ok\n");
+    return 0;
+}

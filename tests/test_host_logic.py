@@ -1,0 +1,16 @@
+"""Product host logic (C++ in funny_lidar_slam_amd/csrc/host_maps.hpp) exercised on the CPU: compiled with hipcc,
+no GPU needed (no HIP runtime call is made).  See tests/host/host_logic_test.cpp for what is checked."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_bookkeeping(built, tmp_path):
+    exe = os.path.join(str(tmp_path), "host_logic_test")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result",
+           os.path.join(ROOT, "tests", "host", "host_logic_test.cpp"), "-o", exe, "-L" + os.path.join(ROOT, "oracle"), "-loracle",
+           "-Wl,-rpath," + os.path.join(ROOT, "oracle")]
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "host logic ok" in out.stdout, out.stdout + out.stderr
