@@ -86,6 +86,64 @@ __device__ __forceinline__ void top5_insert_key(unsigned long long (&t)[5], cons
     }
 }
 
+// Selection keys as IEEE doubles: the 64-bit key {float-bits(d2) + kKeyBias : map slot} read as a positive NORMAL
+// double orders exactly like the unsigned integer (sign 0, exponent field >= 1 thanks to the bias, never Inf/NaN
+// because d2 < 25), so a sorted insertion is nine full-rate v_min_f64 / v_max_f64 instead of five 64-bit
+// compares and twenty selects.  "No candidate" = high word kKeyNoneHi (largest finite exponent; any low word).
+constexpr unsigned kKeyBias = 0x00100000u, kKeyNoneHi = 0x7FEFFFFFu, kKeyValidLimit = 0x7FE00000u;
+__device__ __forceinline__ double kmin_f64(const double a, const double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double kmax_f64(const double a, const double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double make_dkey(const float d2, const unsigned slot, const bool ok) {
+    return __hiloint2double((int)(ok ? __float_as_uint(d2) + kKeyBias : kKeyNoneHi), (int)slot);
+}
+__device__ __forceinline__ bool dkey_valid(const double k) { return (unsigned)__double2hiint(k) < kKeyValidLimit; }
+__device__ __forceinline__ unsigned dkey_slot(const double k) { return (unsigned)__double2loint(k); }
+__device__ __forceinline__ void top5_insert_dkey(double (&t)[5], const double key) {
+    double x = kmin_f64(t[4], key);
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+        const double lo = kmin_f64(t[j], x), hi = kmax_f64(t[j], x);
+        t[j + 1] = hi;
+        x = lo;
+    }
+    t[0] = x;
+}
+template <int G>
+__device__ __forceinline__ double group_min_dkey(double v) {
+#define FLS_DMIN_STEP(S)                                                                              \
+    {                                                                                                 \
+        const unsigned lo = dpp_pair_u32<S>((unsigned)__double2loint(v));                             \
+        const unsigned hi = dpp_pair_u32<S>((unsigned)__double2hiint(v));                             \
+        v = kmin_f64(v, __hiloint2double((int)hi, (int)lo));                                          \
+    }
+    FLS_DMIN_STEP(0)
+    if (G >= 4) FLS_DMIN_STEP(1)
+    if (G >= 8) FLS_DMIN_STEP(2)
+#undef FLS_DMIN_STEP
+    return v;
+}
+
+// candidate index -> map slot as a compare / select chain on VALUES (written as a function of scalars: a lambda
+// capturing the offsets by reference made the compiler select between ADDRESSES and load through them)
+template <int R>
+__device__ __forceinline__ unsigned slot_select(const unsigned idx, const unsigned p1, const unsigned p2, const unsigned p3, const unsigned p4,
+                                                const unsigned o0, const unsigned o1, const unsigned o2, const unsigned o3, const unsigned o4) {
+    unsigned sel = R == 5 ? o4 : R == 4 ? o3 : R == 3 ? o2 : R == 2 ? o1 : o0;
+    if (R > 4) sel = idx < p4 ? o3 : sel;
+    if (R > 3) sel = idx < p3 ? o2 : sel;
+    if (R > 2) sel = idx < p2 ? o1 : sel;
+    if (R > 1) sel = idx < p1 ? o0 : sel;
+    return idx + sel;
+}
+
 template <int G, bool COUNT, bool DENSE>
 __global__ void __launch_bounds__(256)
 ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
@@ -126,8 +184,8 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
 
     // phase 1: this lane's probes (k = sub, sub+G, ...): issue every first-slot load before resolving any.
     // Written as explicit per-round scalars (no indexed arrays) so that nothing lands in scratch.
-    unsigned long long t5[5] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
-    int ncand = 0;
+    const double kNone = __hiloint2double((int)kKeyNoneHi, -1);
+    double t5[5] = {kNone, kNone, kNone, kNone, kNone};
     unsigned long long c_hits = 0, c_cand = 0, c_probes = 0;
     auto probe_key = [&](const int r, bool& pv) -> unsigned long long {
         const int k = sub + G * r;
@@ -191,22 +249,15 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
     auto consider = [&](const float4 p, const unsigned s, const bool ok) {
         const float dx = p.x - ptx, dy = p.y - pty, dz = p.z - ptz;
         const float d2 = dx * dx + (dy * dy + dz * dz);  // Eigen Vector3f::squaredNorm order
-        if (ok && d2 < 25.0f) {  // max_range 5.0 squared (never binds at 0.5 m voxels)
-            ++ncand;
-            top5_insert_key(t5, ((unsigned long long)__float_as_uint(d2) << 32) | s);
-        }
+        top5_insert_dkey(t5, make_dkey(d2, s, ok && d2 < 25.0f));  // max_range 5.0 squared (never binds at 0.5 m voxels)
     };
     // one flattened loop over this lane's <= R voxels: trip count = ceil(lane total / 4), not the sum of
     // per-voxel maxima
-    const unsigned tot = c0 + c1 + c2 + c3 + c4;
-    auto slot_of = [&](unsigned idx) -> unsigned {
-        if (idx < c0) return b0 + idx;
-        idx -= c0;
-        if (R > 1) { if (idx < c1) return b1 + idx; idx -= c1; }
-        if (R > 2) { if (idx < c2) return b2 + idx; idx -= c2; }
-        if (R > 3) { if (idx < c3) return b3 + idx; idx -= c3; }
-        return b4 + idx;
-    };
+    const unsigned p1 = c0, p2 = p1 + c1, p3 = p2 + c2, p4 = p3 + c3, tot = p4 + c4;
+    // candidate index -> map slot, branch-free: slot = idx + (begin - prefix) of the voxel the index falls in
+    // (unsigned wrap-around is intended)
+    const unsigned o0 = b0, o1 = b1 - p1, o2 = b2 - p2, o3 = b3 - p3, o4 = b4 - p4;
+    auto slot_of = [=](const unsigned idx) -> unsigned { return slot_select<R>(idx, p1, p2, p3, p4, o0, o1, o2, o3, o4); };
     for (unsigned j = 0; j < tot; j += 4) {
         const unsigned last = tot - 1;
         const unsigned i1 = j + 1, i2 = j + 2, i3 = j + 3;
@@ -218,29 +269,27 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
         consider(p2, s2, i2 <= last);
         consider(p3, s3, i3 <= last);
     }
-    // phase 2: merge the G private lists: five rounds of group-min + pop
-    const int total = group_sum_i32<G>(ncand);
-    if (total > 0) {  // uniform within the group
-        const int cnt = total < 5 ? total : 5;
-        unsigned long long mine = ~0ull;  // the j-th smallest key lands in lane sub == j
+    // phase 2: merge the G private lists: five rounds of group-min + pop (keys are unique -- the slot is the low
+    // word -- so exactly one lane pops per round); the neighbour count is the number of valid minima
+    const double m0 = group_min_dkey<G>(t5[0]);
+    if (dkey_valid(m0)) {  // uniform within the group: at least one candidate (else nothing is written, ivox_map.cpp:21-23)
+        int cnt = 0;
+        double mine = kNone;  // G == 8: the j-th smallest key lands in lane sub == j
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const unsigned long long m = group_min_u64<G>(t5[0]);
-            if (t5[0] == m && m != ~0ull) {  // keys are unique (slot in the low word): exactly one lane pops
-                t5[0] = t5[1]; t5[1] = t5[2]; t5[2] = t5[3]; t5[3] = t5[4]; t5[4] = ~0ull;
+            const double m = j == 0 ? m0 : group_min_dkey<G>(t5[0]);
+            const bool mv = dkey_valid(m);
+            cnt += mv ? 1 : 0;
+            if (mv && __double_as_longlong(t5[0]) == __double_as_longlong(m)) {
+                t5[0] = t5[1]; t5[1] = t5[2]; t5[2] = t5[3]; t5[3] = t5[4]; t5[4] = kNone;
             }
             if (G >= 8) { if (sub == j) mine = m; }
-            else { if (sub == 0) { /* G == 4: lane 0 writes all five */
-                    if (active) {
-                        const float4 v = (m != ~0ull) ? grid.pts[(unsigned)(m & 0xffffffffull)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-                        nn_pts[(size_t)q * 5 + j] = v;
-                    }
-                } }
+            else if (sub == 0 && active) {  // G == 4: lane 0 writes all five
+                nn_pts[(size_t)q * 5 + j] = mv ? grid.pts[dkey_slot(m)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            }
         }
-        if (G >= 8 && sub < 5 && active) {
-            const float4 v = (mine != ~0ull) ? grid.pts[(unsigned)(mine & 0xffffffffull)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-            nn_pts[(size_t)q * 5 + sub] = v;
-        }
+        if (G >= 8 && sub < 5 && active)
+            nn_pts[(size_t)q * 5 + sub] = dkey_valid(mine) ? grid.pts[dkey_slot(mine)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         if (sub == 0 && active) nn_cnt[q] = (unsigned char)cnt;
     }
     if (COUNT) {
