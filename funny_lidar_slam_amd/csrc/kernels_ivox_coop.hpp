@@ -144,10 +144,10 @@ __device__ __forceinline__ unsigned slot_select(const unsigned idx, const unsign
     return idx + sel;
 }
 
-template <int G, bool COUNT, bool DENSE>
+template <int G, bool COUNT, bool DENSE, bool FIRST>
 __global__ void __launch_bounds__(256)
 ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
-                const GnState* __restrict__ st, const int first, const Pose16 T0, const DevGrid grid, const DenseWindow win,
+                const GnState* __restrict__ st, const Pose16 T0, const DevGrid grid, const DenseWindow win,
                 const float inv_res, float4* __restrict__ nn_pts /* [n][5] */, unsigned char* __restrict__ nn_cnt,
                 unsigned char* __restrict__ flag, TrafficCounters* __restrict__ tc) {
     static_assert(G == 4 || G == 8, "group size");
@@ -162,18 +162,20 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
     const int sub = threadIdx.x % G;
     const int q = lb * QPB + threadIdx.x / G;
     const bool active = lb < nb && q < n;
-    // issue the state / source loads before looking at the stop flag: one memory round trip instead of three.
-    // The first iteration of a Match takes the initial pose from the launch arguments and ignores the
+    // issue the state / source loads before looking at the stop flag: one memory round trip instead of three
+    // (source loads are unconditional on a clamped index: a guarded load costs a branch and a wait each).
+    // The FIRST iteration of a Match takes the initial pose from the launch arguments and ignores the
     // (stale) device state; it also clears the per-point valid flags (std::fill once per Match, Q1).
-    const int done = first ? 0 : st->done;
+    const int done = FIRST ? 0 : st->done;
     double T[12];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) T[c * 3 + r] = first ? T0.m[c * 4 + r] : st->T[c * 4 + r];
-    const float px = active ? sx[q] : 0.f, py = active ? sy[q] : 0.f, pz = active ? sz[q] : 0.f;
+        for (int r = 0; r < 3; ++r) T[c * 3 + r] = FIRST ? T0.m[c * 4 + r] : st->T[c * 4 + r];
+    const int qq = active ? q : 0;
+    const float px = sx[qq], py = sy[qq], pz = sz[qq];
     if (done) return;
-    if (first && active && sub == 0) flag[q] = 0;
+    if (FIRST && active && sub == 0) flag[q] = 0;
     const double x = px, y = py, z = pz;
     const float ptx = (float)(((T[0] * x + T[3] * y) + T[6] * z) + T[9]);
     const float pty = (float)(((T[1] * x + T[4] * y) + T[7] * z) + T[10]);
@@ -218,10 +220,10 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
             nearby18(k < 19 ? k : 0, ox, oy, oz);
             const int cx = kx + ox - win.ox, cy = ky + oy - win.oy, cz = kz + oz - win.oz;
             const bool ok = in_range && k < 19 && (unsigned)cx < (unsigned)win.nx && (unsigned)cy < (unsigned)win.ny && (unsigned)cz < (unsigned)win.nz;
-            const uint2 e = ok ? win.cells[((size_t)cz * win.ny + cy) * win.nx + cx] : make_uint2(0u, 0u);
+            const uint2 e = win.cells[ok ? (unsigned)((cz * win.ny + cy) * win.nx + cx) : 0u];  // < 2^31 cells (host_maps.hpp)
             beg = e.x;
-            cnt = e.y;
-            if (COUNT && in_range && k < 19) { c_probes++; if (e.y) { c_hits++; c_cand += e.y; } }
+            cnt = ok ? e.y : 0u;
+            if (COUNT && in_range && k < 19) { c_probes++; if (cnt) { c_hits++; c_cand += cnt; } }
         };
         cell(0, b0, c0);
         if (R > 1) cell(1, b1, c1);
@@ -306,26 +308,37 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
 // p2plane_fit_solve_kernel: fit + residual + block reduction (one lane per source point, reading what
 // ivox_knn_kernel left behind), and the LAST workgroup to finish runs the Gauss-Newton
 // tail (reduce the block partials, 6x6 solve, pose update, stop rule) -- one launch per iteration fewer.
-// Cross-workgroup hand-off follows the agent-scope release / acquire recipe: every workgroup writes its
-// partial row with plain stores, __syncthreads, lane 0 issues fence(release, agent) + s_waitcnt vmcnt(0)
-// and takes a ticket with a device-scope atomic; the workgroup that draws the last ticket does ONE
-// fence(acquire, agent), __syncthreads, then reads all rows with plain loads.  `ticket` is reset by that
-// workgroup, so it is zero at every launch.  No placement / dispatch-order assumption, no spinning.
+// Cross-workgroup hand-off (placement independent, no spinning): every workgroup publishes its partial row with
+// write-through (sc1) relaxed agent-scope stores, the storing wave drains (s_waitcnt vmcnt(0)), __syncthreads, one
+// lane takes a ticket with an agent-scope atomic; the workgroup that draws the last ticket reads all rows with sc1
+// (relaxed agent-scope) loads.  No release fence: an agent-scope release writes back the XCD's whole L2, which
+// this kernel has just dirtied with 28 KB of Jacobian rows per workgroup (measured: 7 us on the critical path).
+// `ticket` is reset by the last workgroup, so it is zero at every launch.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFitThreads = 512;
+template <bool FIRST>
 __global__ void __launch_bounds__(kFitThreads)
 p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
-                         GnState* __restrict__ st, const int first, const Pose16 T0, const float4* __restrict__ nn_pts,
+                         GnState* __restrict__ st, const Pose16 T0, const float4* __restrict__ nn_pts,
                          const unsigned char* __restrict__ nn_cnt, double* __restrict__ Jst /* [7][n] */, unsigned char* __restrict__ flag,
                          double* __restrict__ partials, unsigned* __restrict__ ticket, Mailbox* __restrict__ mb, const unsigned match_id,
                          const double plane_thres, const double rot_thr, const double pos_thr) {
     const int i = blockIdx.x * kFitThreads + threadIdx.x;
-    const int done = first ? 0 : st->done;
+    const int done = FIRST ? 0 : st->done;
     double T44[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) T44[k] = first ? T0.m[k] : st->T[k];
-    const double last_rot = first ? 0.0 : st->last_rot, last_pos = first ? 0.0 : st->last_pos;
-    const int it = first ? 0 : st->iter;
+    for (int k = 0; k < 16; ++k) T44[k] = FIRST ? T0.m[k] : st->T[k];
+    const double last_rot = FIRST ? 0.0 : st->last_rot, last_pos = FIRST ? 0.0 : st->last_pos;
+    const int it = FIRST ? 0 : st->iter;
+    // every per-point input is loaded up front on a clamped index (one memory round trip; the neighbour points
+    // are fetched whether or not all five exist, the stale flag whether or not it is needed)
+    const int ii = i < n ? i : 0;
+    const int cnt = nn_cnt[ii];
+    float4 nn[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) nn[j] = nn_pts[(size_t)ii * 5 + j];
+    const float px = sx[ii], py = sy[ii], pz = sz[ii];
+    const unsigned char stale = FIRST ? (unsigned char)0 : flag[ii];  // the first kNN launch of a Match cleared the flags
     if (done) return;
     __shared__ LoamTailSmem sm;
     __shared__ double wsum[kFitThreads / 64][32];
@@ -336,13 +349,8 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
     bool contrib = false;
     double J[6] = {0, 0, 0, 0, 0, 0}, res = 0.0;
     if (i < n) {
-        const int cnt = nn_cnt[i];
         bool valid_now = false;
         if (cnt == 5) {
-            float4 nn[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) nn[j] = nn_pts[(size_t)i * 5 + j];
-            const float px = sx[i], py = sy[i], pz = sz[i];
             const double x = px, y = py, z = pz;
             const float ptx = (float)(((T44[0] * x + T44[4] * y) + T44[8] * z) + T44[12]);
             const float pty = (float)(((T44[1] * x + T44[5] * y) + T44[9] * z) + T44[13]);
@@ -355,41 +363,42 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
             Jst[(size_t)6 * n + i] = res;
             flag[i] = 1;
             contrib = true;
-        } else if (flag[i]) {  // Q1: stale contribution of an earlier iteration
+        } else if (stale) {  // Q1: stale contribution of an earlier iteration
 #pragma unroll
             for (int a = 0; a < 6; ++a) J[a] = Jst[(size_t)a * n + i];
             res = Jst[(size_t)6 * n + i];
             contrib = true;
         }
     }
+#ifdef FLS_TIMING
+    const long long t_fit = (long long)__builtin_readcyclecounter();
+#endif
     // wave sums -> LDS -> one row per workgroup (fixed order: wave 0 + wave 1 + ...)
     reduce_rank1_and_store(contrib, J, res, &wsum[threadIdx.x >> 6][0]);
+#ifdef FLS_TIMING
+    const long long t_red = (long long)__builtin_readcyclecounter();
+#endif
     __syncthreads();
     if (threadIdx.x < 29) {
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < kFitThreads / 64; ++w) v += wsum[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
+        // write-through (sc1) publish: visible to every XCD once this wave's stores have drained -- no L2 write-back
+        __hip_atomic_store((unsigned long long*)partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x,
+                           (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != gridDim.x - 1) return;
-    // ---- last workgroup: Gauss-Newton tail ----
+    // ---- last workgroup: Gauss-Newton tail (reads the rows with sc1 loads: no acquire fence either) ----
 #ifdef FLS_TIMING
-    if (threadIdx.x == 0) st->dbg[0] = t_begin;
+    if (threadIdx.x == 0) { st->dbg[0] = t_begin; st->dbg[13] = t_fit; st->dbg[14] = t_red; }
 #endif
     FLS_STAMP(1);
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-    }
-    __syncthreads();
-    loam_tail<kFitThreads>(st, sm, nullptr, 0, partials, (int)gridDim.x, rot_thr, pos_thr, T44, last_rot, last_pos, it, mb, match_id);
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    loam_tail<kFitThreads, true>(st, sm, nullptr, 0, partials, (int)gridDim.x, rot_thr, pos_thr, T44, last_rot, last_pos, it, mb, match_id);
 }
 
 // ---------------------------------------------------------------------------------------------

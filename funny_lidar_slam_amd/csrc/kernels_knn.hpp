@@ -400,17 +400,7 @@ gn_solve_lu_kernel(GnState* __restrict__ st, const int first, const Pose16 T0, c
         }
         st->iter = it + 1;
         if (mb) {
-            for (int q = 0; q < 16; ++q) mb->T[q] = Tl[q];
-            for (int q = 0; q < 6; ++q) mb->last_dx[q] = dxo[q];
-            mb->sum_res = sres;
-            mb->sum_res2 = 0.0;
-            mb->iter = it + 1;
-            mb->done = stop;
-            mb->converged = conv;
-            mb->n_valid = effective;
-            mb->n_valid2 = 0;
-            __hip_atomic_store(&mb->seq, (match_id << 9) | ((unsigned)stop << 8) | (unsigned)(it + 1), __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
+            mailbox_publish(mb, Tl, dxo, sres, 0.0, it + 1, stop, conv, effective, 0, (match_id << 9) | ((unsigned)stop << 8) | (unsigned)(it + 1));
         }
     }
 }

@@ -93,7 +93,9 @@ __device__ __forceinline__ void reduce_rank1_and_store(const bool contrib, const
 // Result in tot[32] (LDS), valid after the call.  Summation order is fixed => reproducible.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSolveThreads = 1024;
-template <int NT>
+// SC1 = true: the rows were published write-through by OTHER workgroups of the SAME launch (the fused fit + solve
+// kernel): read them with relaxed agent-scope loads (sc1: served from memory, never from a stale L1 / L2 line).
+template <int NT, bool SC1 = false>
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, const int nrows, double* tot /*LDS 32*/,
                                                 double (*red)[33] /*LDS (NT/32) x 33*/) {
     constexpr int NG = NT / 32;
@@ -104,7 +106,14 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int rr = r + u * NG;
-            v[u] = rr < nrows ? partials[(size_t)rr * kPartialStride + col] : 0.0;
+            if (SC1) {
+                v[u] = rr < nrows ? __longlong_as_double((long long)__hip_atomic_load(
+                                        (const unsigned long long*)partials + (size_t)rr * kPartialStride + col, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT))
+                                  : 0.0;
+            } else {
+                v[u] = rr < nrows ? partials[(size_t)rr * kPartialStride + col] : 0.0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc += v[u];
@@ -139,7 +148,7 @@ struct LoamTailSmem {
 // workgroup of NT threads: all reduce the rows, wave 0 then runs the cooperative full-pivot Householder QR
 // (wave_solve.hpp), lane 0 applies the left-multiplicative update and the stop rule.
 // Tl / last_rot / last_pos / it: state words loaded by the caller BEFORE any waiting (latency overlap).
-template <int NT>
+template <int NT, bool SC1 = false>
 __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem& sm, const double* __restrict__ partials_a,
                                           const int nrows_a, const double* __restrict__ partials_b, const int nrows_b,
                                           const double rot_thr, const double pos_thr, double (&Tl)[16], const double last_rot,
@@ -148,7 +157,7 @@ __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem
     if (nrows_a > 0) reduce_partials<NT>(partials_a, nrows_a, sm.tot_a, sm.red);
     else { if (threadIdx.x < 32) sm.tot_a[threadIdx.x] = 0.0; __syncthreads(); }
     FLS_STAMP(2);
-    reduce_partials<NT>(partials_b, nrows_b, sm.tot_b, sm.red);
+    reduce_partials<NT, SC1>(partials_b, nrows_b, sm.tot_b, sm.red);
     if (threadIdx.x >= 64) return;  // wave 0 only from here on
     FLS_STAMP(3);
     const int lane = threadIdx.x;
@@ -202,17 +211,7 @@ __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem
         const int stop = ((rn < rot_thr && pn < pos_thr) || (drot < 1.0e-4 && dpos < 1.0e-4)) ? 1 : 0;
         st->done = stop;
         if (mb) {
-            for (int q = 0; q < 16; ++q) mb->T[q] = Tl[q];
-            for (int q = 0; q < 6; ++q) mb->last_dx[q] = dx[q];
-            mb->sum_res = srb;
-            mb->sum_res2 = sra;
-            mb->iter = it + 1;
-            mb->done = stop;
-            mb->converged = 0;
-            mb->n_valid = nvb;
-            mb->n_valid2 = nva;
-            __hip_atomic_store(&mb->seq, (match_id << 9) | ((unsigned)stop << 8) | (unsigned)(it + 1), __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
+            mailbox_publish(mb, Tl, dx, srb, sra, it + 1, stop, 0, nvb, nva, (match_id << 9) | ((unsigned)stop << 8) | (unsigned)(it + 1));
         }
         FLS_STAMP(5);
     }

@@ -210,9 +210,15 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     template <int G>
     void launch_knn(const size_t n, const int first, const Pose16& T0, const DevGrid& g, const DenseWindow& win) {
         const dim3 grid(unsigned((((n * G + 255) / 256) + 7) / 8 * 8));  // multiple of 8: XCD re-map is a bijection
-#define FLS_KNN(C, D)                                                                                                                \
-    hipLaunchKernelGGL((ivox_knn_kernel<G, C, D>), grid, dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, first, T0, g, \
-                       win, ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p)
+#define FLS_KNN(C, D)                                                                                                                  \
+    do {                                                                                                                               \
+        if (first)                                                                                                                     \
+            hipLaunchKernelGGL((ivox_knn_kernel<G, C, D, true>), grid, dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),     \
+                               d_state.p, T0, g, win, ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p);                      \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((ivox_knn_kernel<G, C, D, false>), grid, dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),    \
+                               d_state.p, T0, g, win, ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p);                      \
+    } while (0)
         if (win.cells) { if (count_traffic) FLS_KNN(true, true); else FLS_KNN(false, true); }
         else { if (count_traffic) FLS_KNN(true, false); else FLS_KNN(false, false); }
 #undef FLS_KNN
@@ -250,10 +256,12 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
             if (variant == 4) launch_knn<4>(n, first, T0, g, win); else launch_knn<8>(n, first, T0, g, win);
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
-            hipLaunchKernelGGL(p2plane_fit_solve_kernel, dim3(nwg), dim3(kFitThreads), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),
-                               d_state.p, first, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p,
-                               d_partials_b.p, d_ticket.p, mb_dev, match_id, p.point_to_planar_thres, p.rotation_converge_thres,
-                               p.position_converge_thres);
+#define FLS_FIT(F)                                                                                                                   \
+    hipLaunchKernelGGL(p2plane_fit_solve_kernel<F>, dim3(nwg), dim3(kFitThreads), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),  \
+                       d_state.p, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,     \
+                       d_ticket.p, mb_dev, match_id, p.point_to_planar_thres, p.rotation_converge_thres, p.position_converge_thres)
+            if (first) FLS_FIT(true); else FLS_FIT(false);
+#undef FLS_FIT
         });
         const Mailbox& mb = *mb_host;
         const int used = int(word & 0xffu);

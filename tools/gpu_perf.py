@@ -38,5 +38,5 @@ for v in variants:
         st = (C.c_int64 * 16)()
         _lib.lib().fls_get_debug_stamps(m._h, st)
         v = list(st)
-        print("   solve-kernel cycle stamps (delta from start):", [v[i] - v[0] for i in range(13)])
+        print("   solve-kernel cycle stamps (delta from start):", [v[i] - v[0] for i in range(15)])
     m.close()
