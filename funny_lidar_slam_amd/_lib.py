@@ -16,7 +16,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 # every symbol include/fls_reg.h declares (tests check they are all exported)
 EXPORTED_SYMBOLS = [
     "fls_create", "fls_destroy", "fls_add_cloud_to_local_map", "fls_match", "fls_get_fitness_score",
-    "fls_scan_upload", "fls_match_resident", "fls_get_iteration_log", "fls_get_correspondences", "fls_map_size",
+    "fls_scan_upload", "fls_match_resident", "fls_match_batch", "fls_get_iteration_log", "fls_get_correspondences", "fls_map_size",
     "fls_set_profiling", "fls_get_kernel_time", "fls_get_traffic_counters", "fls_get_debug_stamps", "fls_status_string", "fls_abi_version",
     "fls_device_count",
 ]
@@ -126,6 +126,9 @@ def lib():
         L.fls_scan_upload.argtypes = [hp, fp, C.c_size_t, fp, C.c_size_t, C.c_int]
         L.fls_match_resident.restype = C.c_int
         L.fls_match_resident.argtypes = [hp, dp, C.c_int, C.POINTER(Stats)]
+        L.fls_match_batch.restype = C.c_int
+        L.fls_match_batch.argtypes = [hp, C.c_size_t, C.POINTER(fp), C.POINTER(C.c_size_t), C.POINTER(fp), C.POINTER(C.c_size_t), C.c_int,
+                                      dp, C.POINTER(Stats), ip, C.c_int]
         L.fls_get_iteration_log.restype = C.c_int
         L.fls_get_iteration_log.argtypes = [hp, dp, ip, dp, C.c_int]
         L.fls_get_correspondences.restype = C.c_int

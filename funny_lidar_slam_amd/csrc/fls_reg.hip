@@ -131,6 +131,18 @@ fls_status fls_match(fls_handle h, const float* s0, size_t n0, const float* s1, 
     });
 }
 
+fls_status fls_match_batch(fls_handle h, size_t n_jobs, const float* const* src0, const size_t* n0, const float* const* src1,
+                           const size_t* n1, int stride, double* T, fls_stats* stats, int32_t* status, int lanes) {
+    if (!h || stride < 3 || (n_jobs && (!src0 || !n0 || !T))) return FLS_ERR_INVALID;
+    if ((src1 == nullptr) != (n1 == nullptr)) return FLS_ERR_INVALID;
+    for (size_t j = 0; j < n_jobs; ++j)
+        if (!src0[j] && n0[j]) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(h->device));
+        return h->match_batch(n_jobs, src0, n0, src1, n1, stride, T, stats, status, lanes);
+    });
+}
+
 fls_status fls_get_fitness_score(fls_handle h, float max_range, float* score) {
     if (!h || !score) return FLS_ERR_INVALID;
     return guarded([&]() -> fls_status {

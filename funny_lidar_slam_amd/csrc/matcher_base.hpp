@@ -53,6 +53,23 @@ struct fls_matcher {
     virtual fls_status fitness(float max_range, float* score) = 0;
     virtual int correspondences(int slot, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) = 0;
     virtual size_t map_size(int slot) const = 0;
+    // state a FRESH reference matcher would not have (e.g. nearest_points_ of an earlier Match): cleared per batch job
+    virtual void reset_job_state() {}
+    // Batch of independent registrations against the CURRENT map (BASELINE configs[4]): every job is what a
+    // fresh reference process holding this map would compute for Match(scan_j, T_j) -- no map update, no state carried
+    // from job to job.  Default: the jobs run one after the other on this handle's stream.
+    virtual fls_status match_batch(size_t n_jobs, const float* const* s0, const size_t* n0, const float* const* s1, const size_t* n1,
+                                   int stride, double* T, fls_stats* st, int32_t* status, int lanes) {
+        (void)lanes;
+        for (size_t j = 0; j < n_jobs; ++j) {
+            reset_job_state();
+            fls_status rc = scan_upload(s0[j], n0[j], s1 ? s1[j] : nullptr, n1 ? n1[j] : 0, stride);
+            if (rc == FLS_OK) rc = match_resident(T + 16 * j, 0, st ? &st[j] : nullptr);
+            if (status) status[j] = int32_t(rc);
+            if (rc < 0) return rc;
+        }
+        return FLS_OK;
+    }
 
     void init_common() {
         FLS_HIP(hipSetDevice(device));

@@ -12,6 +12,7 @@
 #include "kernels_knn.hpp"
 #include "kernels_ivox_coop.hpp"
 #include "fitness_host.hpp"
+#include <thread>
 
 namespace fls {
 
@@ -19,6 +20,10 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     HostIvox ivox;
     GridImage image;
     bool image_dirty = true, image_built = false;
+    // batch lanes (fls_match_batch): clones with their own stream / Gauss-Newton state / mailbox / per-point buffers
+    // that READ this handle's resident map image; created on first use, kept for the next batch
+    const GridImage* borrowed = nullptr;
+    std::vector<std::unique_ptr<P2PlaneIvoxMatcher>> lanes;
     size_t n_incremental = 0, n_full_rebuilds = 0;
     PinnedBuf<char> upd_stage;
     DevBuf<unsigned char> d_code;
@@ -237,7 +242,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             log_n = 0; log_stale = false;
             return FLS_NOT_CONVERGED;
         }
-        refresh_image();
+        if (!borrowed) refresh_image();
+        const GridImage& im = borrowed ? *borrowed : image;
         // nearest_points_.resize(n) semantics (:257): grown tail is empty, shrink forgets
         d_nn.reserve(n * 5, /*keep=*/true, stream);
         d_nn_cnt.reserve(n, /*keep=*/true, stream);
@@ -248,8 +254,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         const int nwg = int((n + kFitThreads - 1) / kFitThreads);
         d_partials_b.reserve(size_t(nwg) * kPartialStride);
         const int iters = int(p.max_iterations);
-        const DevGrid g = image.dev();
-        const DenseWindow win = use_dense ? image.window() : DenseWindow{nullptr, 0, 0, 0, 0, 0, 0};
+        const DevGrid g = im.dev();
+        const DenseWindow win = use_dense ? im.window() : DenseWindow{nullptr, 0, 0, 0, 0, 0, 0};
         Pose16 T0;
         std::memcpy(T0.m, T, sizeof(T0.m));
         const unsigned word = run_mailbox_loop(iters, n, [&](int it, int first) {
@@ -277,13 +283,63 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         std::memcpy(stats.last_dx, mb.last_dx, sizeof(stats.last_dx));
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
-        if (has_converge && !p.is_localization_mode && update_map) {  // :205-206
+        if (has_converge && !p.is_localization_mode && update_map && !borrowed) {  // :205-206
             const fls_status arc = add_cloud_impl(scan.host, /*from_resident_scan=*/true);
             if (arc != FLS_OK) rc = arc;
             stats.map_updated = 1;
         }
         if (out) *out = stats;
         return rc;
+    }
+
+    void reset_job_state() override { nn_n = 0; have_final = false; }  // nearest_points_ of a fresh matcher is empty
+
+    // configs[4]: `lanes` registrations in flight on `lanes` streams (one host thread each, spinning on its own
+    // mailbox); all read the same resident map image.  While one job runs its single-workgroup Gauss-Newton tail
+    // or its under-occupied fit kernel, the correspondence kernels of the other jobs fill the machine.
+    fls_status match_batch(size_t n_jobs, const float* const* s0, const size_t* n0, const float* const* s1, const size_t* n1, int stride,
+                           double* T, fls_stats* st, int32_t* status, int n_lanes) override {
+        const size_t L = size_t(std::max(1, std::min(n_lanes, 16)));
+        if (borrowed) return FLS_ERR_STATE;
+        if (L <= 1 || n_jobs <= 1) return fls_matcher::match_batch(n_jobs, s0, n0, s1, n1, stride, T, st, status, 1);
+        refresh_image();
+        FLS_HIP(hipStreamSynchronize(stream));  // the image is complete before other streams read it
+        while (lanes.size() < L) {
+            auto q = std::make_unique<P2PlaneIvoxMatcher>();
+            q->kind = kind; q->p = p; q->device = device;
+            const fls_status rc = q->init();
+            if (rc != FLS_OK) return rc;
+            q->borrowed = &image;
+            lanes.push_back(std::move(q));
+        }
+        std::vector<fls_status> lane_rc(L, FLS_OK);
+        std::vector<std::thread> th;
+        for (size_t l = 0; l < L; ++l) {
+            P2PlaneIvoxMatcher* q = lanes[l].get();
+            q->use_dense = use_dense; q->variant = variant; q->expect_iters = expect_iters;
+            th.emplace_back([=, &lane_rc]() {
+                try {
+                    FLS_HIP(hipSetDevice(q->device));
+                    for (size_t j = l; j < n_jobs; j += L) {
+                        q->reset_job_state();
+                        fls_status rc = q->scan_upload(s0[j], n0[j], s1 ? s1[j] : nullptr, n1 ? n1[j] : 0, stride);
+                        if (rc == FLS_OK) rc = q->match_resident(T + 16 * j, 0, st ? &st[j] : nullptr);
+                        if (status) status[j] = int32_t(rc);
+                        if (rc < 0) { lane_rc[l] = rc; return; }
+                    }
+                } catch (const HipError& e) {
+                    std::fprintf(stderr, "[fls_reg] batch lane %zu: %s\n", l, e.what());
+                    lane_rc[l] = FLS_ERR_DEVICE;
+                } catch (const std::bad_alloc&) {
+                    lane_rc[l] = FLS_ERR_NOMEM;
+                } catch (...) {
+                    lane_rc[l] = FLS_ERR_INVALID;
+                }
+            });
+        }
+        for (auto& t : th) t.join();
+        for (const fls_status rc : lane_rc) if (rc < 0) return rc;
+        return FLS_OK;
     }
 
     fls_status fitness(float max_range, float* score) override {

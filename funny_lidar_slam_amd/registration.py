@@ -92,6 +92,35 @@ class RegistrationInterface:
         T[...] = Tf.reshape(4, 4).T
         return rc == _lib.FLS_OK
 
+    def MatchBatch(self, clusters, T_inits, lanes: int = 4):
+        """fls_match_batch: independent registrations of `clusters[j]` from `T_inits[j]` against the current map (no map
+        update, no state carried between jobs).  Returns (ok[j], T[j] (n,4,4), stats[j]) -- BASELINE configs[4]."""
+        n = len(clusters)
+        fp = C.POINTER(C.c_float)
+        keep, p0s, n0s, p1s, n1s = [], (fp * n)(), (C.c_size_t * n)(), (fp * n)(), (C.c_size_t * n)()
+        stride, two = None, False
+        for j, cl in enumerate(clusters):
+            s0, s1 = self._sources(cl)
+            a0, p0, n0, st0 = _cloud(s0)
+            a1, p1, n1, st1 = _cloud(s1)
+            if stride not in (None, st0) or (a1 is not None and st1 != st0):
+                raise ValueError("clouds must share a stride")
+            stride = st0
+            keep += [a0, a1]
+            p0s[j], n0s[j] = p0, n0
+            if a1 is not None:
+                two = True
+                p1s[j], n1s[j] = p1, n1
+        Tf = np.ascontiguousarray(np.asarray(T_inits, dtype=np.float64).reshape(n, 4, 4).transpose(0, 2, 1)).reshape(-1)  # column-major
+        stats = (Stats * n)()
+        status = (C.c_int32 * n)()
+        rc = _lib.lib().fls_match_batch(self._h, n, p0s, n0s, p1s if two else None, n1s if two else None, stride or 3,
+                                        Tf.ctypes.data_as(C.POINTER(C.c_double)), stats, status, int(lanes))
+        if rc < 0:
+            raise FlsError(rc, "fls_match_batch")
+        T = Tf.reshape(n, 4, 4).transpose(0, 2, 1).copy()
+        return [status[j] == _lib.FLS_OK for j in range(n)], T, list(stats)
+
     def GetFitnessScore(self, max_range: float) -> float:
         out = C.c_float()
         rc = _lib.lib().fls_get_fitness_score(self._h, max_range, C.byref(out))

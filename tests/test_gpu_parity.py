@@ -158,3 +158,51 @@ def test_mapping_replay_with_lru_eviction(monkeypatch):
     evicts voxels during the replay; evicted cells must disappear from the device image."""
     m, o = _replay(6, capacity=9000, monkeypatch=monkeypatch)
     assert o.map_voxels() <= 9000
+
+
+def test_match_batch_equals_fresh_matchers():
+    """BASELINE configs[4] (shape): independent scans against ONE map through fls_match_batch on several stream lanes.
+    Every job must equal (bit for bit) what a fresh handle computes for the same scan, and agree with a fresh oracle."""
+    n_jobs, scale = 7, 0.05
+    cfgs = [synth.make_config(1, job=j, scale=scale) for j in range(n_jobs)]
+    y = reg.YAML_NCLT_IVOX
+    m = reg.make_matcher("PointToPlane_IVOX", y)
+    m.AddCloudToLocalMap([cfgs[0]["map"]])
+    warm = np.eye(4)
+    m.Match(reg.PointcloudCluster(planar_cloud_=cfgs[3]["scan"]), warm, update_map=False)  # the owner's own state must not leak into jobs
+    clusters = [reg.PointcloudCluster(planar_cloud_=c["scan"]) for c in cfgs]
+    oks, Ts, stats = m.MatchBatch(clusters, [np.eye(4)] * n_jobs, lanes=3)
+    oks1, Ts1, stats1 = m.MatchBatch(clusters, [np.eye(4)] * n_jobs, lanes=1)  # back-to-back path on the owner
+    for j, c in enumerate(cfgs):
+        f = reg.make_matcher("PointToPlane_IVOX", y)
+        f.AddCloudToLocalMap([c["map"]])
+        T = np.eye(4)
+        ok = f.Match(clusters[j], T, update_map=False)
+        assert ok == oks[j] == oks1[j]
+        assert np.array_equal(T, Ts[j]) and np.array_equal(T, Ts1[j]), j
+        assert f.stats.iterations == stats[j].iterations == stats1[j].iterations
+        assert f.stats.n_valid == stats[j].n_valid == stats1[j].n_valid
+        o = util.oracle_for("PointToPlane_IVOX", y)
+        o.AddCloudToLocalMap(c["map"])
+        ok_ref, T_ref = o.Match(c["scan"], np.eye(4), update_map=False)
+        dt, dr = synth.pose_error(Ts[j], T_ref)
+        assert ok_ref == oks[j] and dt < 1e-4 and dr < 1e-4
+        assert o.stats.iterations == stats[j].iterations and o.stats.n_valid == stats[j].n_valid
+        f.close()
+    m.close()
+
+
+def test_match_batch_default_path_other_kind():
+    """Kinds without stream lanes run the jobs back to back; same contract (fresh state per job)."""
+    cfgs = [synth.make_config(0, job=j) for j in range(3)]
+    y = reg.YAML_NCLT_ICP
+    m = reg.make_matcher("IcpOptimized", y, is_localization_mode=True)
+    m.AddCloudToLocalMap([cfgs[0]["map"]])
+    clusters = [reg.PointcloudCluster(ordered_cloud_=c["scan"]) for c in cfgs]
+    oks, Ts, stats = m.MatchBatch(clusters, [np.eye(4)] * 3, lanes=4)
+    for j, c in enumerate(cfgs):
+        f = reg.make_matcher("IcpOptimized", y, is_localization_mode=True)
+        f.AddCloudToLocalMap([c["map"]])
+        T = np.eye(4)
+        ok = f.Match(clusters[j], T, update_map=False)
+        assert ok == oks[j] and np.array_equal(T, Ts[j]) and f.stats.iterations == stats[j].iterations
