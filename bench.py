@@ -8,15 +8,18 @@ A "step" is one full ``Match`` (all Gauss-Newton iterations until the reference'
 rule, map update excluded) of one synthetic Velodyne-64 scan (64 x 1800 = 115,200 points)
 against the 1e6-point iVox map with ``LoamPointToPlaneIVOX`` semantics = BASELINE.json
 configs[1].  The scan and the map are resident in HBM before the timed region.  With N GPUs
-every rank registers its own, different scan against a replicated map (independent jobs:
-BASELINE configs[4] sharding, no data-path collective; "scaling": "weak"); the only
-collectives are the start/stop barriers, the MAX of the per-rank times and the gather of
-the poses.
+every rank registers the SAME scan against a replica of the map (identical work per GPU, so
+that value(N) / N is comparable with value(1); independent jobs, no data-path collective;
+"scaling": "weak"); the only collectives are the start/stop barriers, the MAX of the
+per-rank times and the gather of the poses.
 
 Extra objects on the line:
   roofline      HBM-bound correspondence kernel: algorithmic bytes per launch (SURVEY.md 8d
                 formula, counters counted on the device) / average launch duration measured
                 with hipEvents on the handle's own stream during the timed region.
+  c5_batch      BASELINE configs[4] shape: 64 independent scan-to-map jobs per GPU (8 distinct scans cycled)
+                through fls_match_batch on 4 stream lanes, host-to-device scan upload and the gather of the
+                result table (RCCL all_gather for N > 1) inside the timed region.
   cpu_baseline  the CPU oracle (a port of the reference algorithm, the reference itself needs
                 Eigen/PCL/ROS and cannot be built here) timed on this box's host cores on the
                 same workload, rank 0, N=1 only.
@@ -30,6 +33,10 @@ import sys
 import time
 
 import numpy as np
+
+# configs[4] batch: 4 stream lanes map 1:1 onto hardware queues only if the runtime may open that many
+# (ROCm's default is 4 per process, shared with torch's own streams); must be set before HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -85,6 +92,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="skip the configs[4] batch measurement")
+    ap.add_argument("--batch-jobs", type=int, default=64, help="configs[4] jobs per GPU")
     args = ap.parse_args()
 
     import torch
@@ -110,7 +119,7 @@ def main():
     torch.cuda.set_device(dev)
 
     y = reg.YAML_NCLT_IVOX
-    cfg = synth.make_config(1, job=rank)  # same map (salted seed), per-rank scan / T_gt
+    cfg = synth.make_config(1, job=0)  # identical scan / map on every rank (fixed per-GPU work)
     m = reg.make_matcher("PointToPlane_IVOX", y, device_id=dev)
     m.AddCloudToLocalMap([cfg["map"]])
     cluster = reg.PointcloudCluster(planar_cloud_=cfg["scan"])
@@ -162,6 +171,45 @@ def main():
         row = batch.pack_result(T, ok, m.stats.iterations, m.stats.n_valid, m.stats.sum_res)
         table = batch.gather_results(row[None, :], world, batch.RESULT_WIDTH, device="cuda")  # one job per rank per step
         assert table.shape == (world, batch.RESULT_WIDTH)
+        assert bool(np.all(table == table[0])), "identical jobs on identical GPUs must give bit-identical results"
+
+    c5 = None
+    if not args.no_batch:
+        # configs[4]: jobs_per_gpu independent jobs per rank (job ids block-partitioned, batch.partition), 4 stream lanes
+        from funny_lidar_slam_amd import batch
+        jpg, lanes = args.batch_jobs, 4
+        n_jobs = jpg * n_gpus
+        b_, e_ = batch.partition(n_jobs, n_gpus, rank)
+        scans = [cfg["scan"]] + [synth.cast_scan(
+            cfg["scene"], synth.random_pose(synth.rng_for(1, j)), rng=synth.rng_for(1, j, salt=7), max_range=cfg["radius"],
+            **synth.VELODYNE_64) for j in range(1, 8)]
+        clusters = [reg.PointcloudCluster(planar_cloud_=scans[j % 8]) for j in range(b_, e_)]
+        T0s = [np.eye(4)] * len(clusters)
+        for _ in range(3):  # warm-up: lane creation, buffer growth, clocks back up after the host-side scan generation
+            m.MatchBatch(clusters, T0s, lanes=lanes)
+        reps = []
+        for _ in range(5):  # median of five passes over the whole batch
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            oks, Tb, sb = m.MatchBatch(clusters, T0s, lanes=lanes)
+            rows = np.stack([batch.pack_result(Tb[k], oks[k], sb[k].iterations, sb[k].n_valid, sb[k].sum_res) for k in range(len(clusters))])
+            tab = batch.gather_results(rows, n_jobs, batch.RESULT_WIDTH, device="cuda" if distributed else None)
+            torch.cuda.synchronize()
+            if distributed:
+                dist.barrier()
+            tb = time.perf_counter() - tb
+            if distributed:
+                tm = torch.tensor([tb], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                tb = float(tm.item())
+            reps.append(tb)
+        tb = float(np.median(reps))
+        assert tab.shape == (n_jobs, batch.RESULT_WIDTH) and bool(np.all(tab[:, 16] == 1.0))
+        c5 = {"jobs": n_jobs, "jobs_per_gpu": jpg, "lanes_per_gpu": lanes, "scans_per_s": n_jobs / tb, "ms_total": 1e3 * tb, "ms_passes": [1e3 * t for t in reps],
+              "gn_iterations": sorted({int(v) for v in tab[:, 17]}),
+              "note": "fls_match_batch: per-job scan upload from host memory and the result gather are inside the timed region"}
 
     if rank == 0:
         total_scans = args.steps * n_gpus
@@ -176,7 +224,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: Velodyne-64 synthetic scan (64x1800 = 115,200 pts), point-to-plane "
-                                   "(LoamPointToPlaneIVOX semantics, YAML config_nclt.yaml) into a 1e6-pt iVox map, 1 scan per GPU per step",
+                                   "(LoamPointToPlaneIVOX semantics, YAML config_nclt.yaml) into a 1e6-pt iVox map, 1 scan per GPU per step "
+                                   "(the same scan on every GPU)",
                        "scan_points": int(cfg["scan"].shape[0]), "map_points": int(cfg["map"].shape[0]),
                        "gn_iterations": int(iters), "converged": bool(ok), "pose_err_vs_gt_m_rad": [dt, dr]},
             "roofline": {"bound": "hbm", "kernel": "ivox_knn_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -184,6 +233,8 @@ def main():
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_us": 1e6 * avg_launch_s,
                          "launches_timed": int(launches)},
         }
+        if c5 is not None:
+            line["c5_batch"] = c5
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, y)
         print(json.dumps(line))

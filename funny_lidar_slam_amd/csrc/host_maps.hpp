@@ -26,13 +26,17 @@ static_assert(sizeof(Pt4) == 16, "Pt4 must alias float4");
 
 struct PtI { float x, y, z, i; };  // xyz + intensity (VoxelGrid averages all fields)
 
+// intensity of one AoS point: pcl::PointXYZI (stride 8) keeps it in float 4 (x, y, z, pad | intensity, pad x3),
+// a packed xyzi row (stride 4..7) in float 3
+inline float intensity_of(const float* q, int stride) { return stride >= 8 ? q[4] : stride >= 4 ? q[3] : 0.0f; }
+
 inline std::vector<PtI> cloud_from(const float* p, size_t n, int stride) {
     std::vector<PtI> c(n);
     for (size_t k = 0; k < n; ++k) {
         c[k].x = p[k * stride];
         c[k].y = p[k * stride + 1];
         c[k].z = p[k * stride + 2];
-        c[k].i = stride >= 4 ? p[k * stride + 3] : 0.0f;
+        c[k].i = intensity_of(p + k * stride, stride);
     }
     return c;
 }

@@ -184,6 +184,25 @@ struct DevScan {
     PinnedBuf<float> stage;
     size_t n = 0;
     std::vector<PtI> host;  // kept for map updates / fitness
+    // straight from the caller's strided AoS into the pinned SoA staging buffer (no temporary cloud; the
+    // per-point host copy is kept only when the caller needs intensities / points later)
+    void upload_raw(const float* p, size_t count, int stride, hipStream_t s, bool keep_host) {
+        n = count;
+        if (keep_host) {
+            host.resize(n);
+            for (size_t i = 0; i < n; ++i) host[i] = PtI{p[i * stride], p[i * stride + 1], p[i * stride + 2], intensity_of(p + i * stride, stride)};
+        } else {
+            host.clear();
+        }
+        if (n == 0) return;
+        x.reserve(n); y.reserve(n); z.reserve(n);
+        stage.reserve(3 * n);
+        float* sx = stage.p; float* sy = stage.p + n; float* sz = stage.p + 2 * n;
+        for (size_t i = 0; i < n; ++i) { sx[i] = p[i * stride]; sy[i] = p[i * stride + 1]; sz[i] = p[i * stride + 2]; }
+        FLS_HIP(hipMemcpyAsync(x.p, sx, n * sizeof(float), hipMemcpyHostToDevice, s));
+        FLS_HIP(hipMemcpyAsync(y.p, sy, n * sizeof(float), hipMemcpyHostToDevice, s));
+        FLS_HIP(hipMemcpyAsync(z.p, sz, n * sizeof(float), hipMemcpyHostToDevice, s));
+    }
     void upload(const std::vector<PtI>& c, hipStream_t s) {
         host = c;
         n = c.size();

@@ -208,7 +208,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
 
     fls_status scan_upload(const float* s0, size_t n0, const float* s1, size_t n1, int stride) override {
         (void)s1; (void)n1;
-        scan.upload(cloud_from(s0, n0, stride), stream);
+        // (the pinned staging buffer is free again: fls_scan_upload synchronises, a Match ends after its copies)
+        scan.upload_raw(s0, n0, stride, stream, /*keep_host=*/!borrowed);
         return FLS_OK;
     }
 

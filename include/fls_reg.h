@@ -18,8 +18,9 @@
  * reference: one owner thread, frontend.cpp:207-210 / localization.cpp:246-249).
  *
  * Clouds are passed as float AoS with a stride in floats: pcl::PointXYZI is
- * 32 B => pass cloud.points.data() with stride_floats = 8; a packed xyz array
- * uses 3, xyzi uses 4.  Poses are Eigen::Matrix4d::data(): 16 doubles,
+ * 32 B (x, y, z, pad | intensity, pad x3) => pass cloud.points.data() with
+ * stride_floats = 8 (intensity is read from float 4); a packed xyz array uses 3,
+ * xyzi uses 4 (intensity in float 3).  Poses are Eigen::Matrix4d::data(): 16 doubles,
  * COLUMN-major, world <- body.
  *
  * The library has no CPU fallback: every entry point that computes fails with

@@ -24,7 +24,7 @@ static inline Cloud make_cloud(const float* p, size_t n, int stride) {
         c[k].x = p[k * stride + 0];
         c[k].y = p[k * stride + 1];
         c[k].z = p[k * stride + 2];
-        c[k].i = stride >= 4 ? p[k * stride + 3] : 0.0f;
+        c[k].i = stride >= 8 ? p[k * stride + 4] : stride >= 4 ? p[k * stride + 3] : 0.0f;  // pcl::PointXYZI keeps intensity in float 4
     }
     return c;
 }
