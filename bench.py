@@ -218,6 +218,14 @@ def main():
         avg_launch_s = (ms_kernel / 1e3) / max(launches, 1)
         achieved = per_launch_bytes / avg_launch_s / 1e9 if launches else 0.0
         dt, dr = synth.pose_error(T, cfg["T_gt"])
+        # HBM bytes per launch of the same kernel from the committed PMC passes (rocprofv3 cannot collect counters from
+        # inside this process; gpurun keeps --pmc runs separate from everything else): profiles/traffic_ivox_knn.json
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic_ivox_knn.json")) as f:
+                traffic = float(json.load(f)["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            traffic = None
         line = {
             "metric": "scans/sec (64-ring x 1800 pts -> 1e6-pt iVox map), SE(3) err vs CPU ref",
             "value": value, "unit": "scans/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -229,7 +237,8 @@ def main():
                        "scan_points": int(cfg["scan"].shape[0]), "map_points": int(cfg["map"].shape[0]),
                        "gn_iterations": int(iters), "converged": bool(ok), "pose_err_vs_gt_m_rad": [dt, dr]},
             "roofline": {"bound": "hbm", "kernel": "ivox_knn_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/traffic_ivox_knn.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_us": 1e6 * avg_launch_s,
                          "launches_timed": int(launches)},
         }
