@@ -127,6 +127,50 @@ def cast_scan(scene: dict, T_gt: np.ndarray, n_rings: int, n_az: int, elev0_deg:
     return pts.astype(np.float32)
 
 
+# raw driver point of the reference (include/lidar/lidar_point_type.h VelodynePointXYZIRT, 32 bytes, 16-byte aligned)
+RAW_POINT_DTYPE = np.dtype({"names": ["x", "y", "z", "intensity", "ring", "time"],
+                            "formats": ["<f4", "<f4", "<f4", "<f4", "<u2", "<f4"],
+                            "offsets": [0, 4, 8, 16, 20, 24], "itemsize": 32})
+
+
+def cast_raw_scan(scene: dict, T_gt: np.ndarray, n_rings: int, n_az: int, elev0_deg: float, elev_step_deg: float,
+                  rng: np.random.Generator, range_noise: float = 0.02, max_range: float = MAX_RANGE, dup_frac: float = 0.02,
+                  drop_frac: float = 0.01) -> np.ndarray:
+    """Raw driver cloud (RAW_POINT_DTYPE) in firing order: azimuth-major, all lasers of one firing together; misses
+    are simply absent; `dup_frac` extra returns land in already occupied range-image cells (the projector keeps the
+    first), `drop_frac` of the returns are removed at random (ragged rows), a few are outside [min, max] range."""
+    R, t = T_gt[:3, :3], T_gt[:3, 3]
+    o_body = np.array([0.0, 0.0, SENSOR_Z])
+    o_world = R @ o_body + t
+    ring = np.tile(np.arange(n_rings), n_az).astype(np.float64)
+    step = 2.0 * np.pi / n_az
+    az = np.repeat(np.arange(n_az) * step, n_rings) - np.pi + 0.25 * step  # firing angle, (-pi, pi)
+    d_body = _ray_dirs(ring, az, elev0_deg, elev_step_deg)
+    r = _ray_cast(scene, o_world, d_body @ R.T)
+    ok = np.isfinite(r) & (r >= 0.5) & (r <= max_range * 1.05)
+    ok &= rng.uniform(size=ok.size) >= drop_frac
+    idx = np.nonzero(ok)[0]
+    rr = r[idx] + rng.normal(0.0, range_noise, idx.size)
+    pts = o_body[None, :] + rr[:, None] * d_body[idx]
+    rg = ring[idx]
+    tm = (az[idx] + np.pi) / (2.0 * np.pi) * 0.1
+    # duplicates: a second return of the same firing direction, slightly farther, appended later in the stream
+    nd = int(dup_frac * idx.size)
+    if nd:
+        pick = rng.choice(idx.size, nd, replace=False)
+        extra = o_body[None, :] + (rr[pick] + rng.uniform(0.05, 1.0, nd))[:, None] * d_body[idx[pick]]
+        pos = np.sort(rng.integers(0, idx.size, nd))
+        pts = np.insert(pts, pos, extra, axis=0)
+        rg = np.insert(rg, pos, rg[pick])
+        tm = np.insert(tm, pos, tm[pick])
+    out = np.zeros(pts.shape[0], dtype=RAW_POINT_DTYPE)
+    out["x"], out["y"], out["z"] = pts[:, 0].astype(np.float32), pts[:, 1].astype(np.float32), pts[:, 2].astype(np.float32)
+    out["intensity"] = rng.uniform(0.0, 255.0, pts.shape[0]).astype(np.float32)
+    out["ring"] = rg.astype(np.uint16)
+    out["time"] = tm.astype(np.float32)
+    return out
+
+
 def _surfaces(scene: dict):
     """List of vertical wall rectangles (origin, u, v, normal) for area sampling."""
     rects = []

@@ -99,6 +99,26 @@ size_t flo_map_dump(void* h, int slot, float* xyz, size_t cap_points);
 /* NDT voxel dump: keys (n x 3 int32), mu (n x 3), info (n x 9 col-major), estimated (n) */
 size_t flo_ndt_dump(void* h, int32_t* keys, double* mu, double* info, uint8_t* est, int32_t* npts, size_t cap);
 
+/* ---- LOAM feature front-end (src/loam/pointcloud_projector.cpp, src/loam/feature_extractor.cpp): see flo_features.h ---- */
+typedef struct flo_feat_params {
+    uint32_t struct_size;
+    int32_t vertical_scan, horizontal_scan;
+    float horizontal_resolution, min_distance, max_distance, corner_thres, planar_thres;
+} flo_feat_params;
+enum { FLO_FEAT_ORDERED = 0, FLO_FEAT_DEPTH = 1, FLO_FEAT_COL = 2, FLO_FEAT_ROW_START = 3, FLO_FEAT_ROW_END = 4, FLO_FEAT_CORNER = 5,
+       FLO_FEAT_PLANAR = 6, FLO_FEAT_IS_CORNER = 7, FLO_FEAT_ROUGHNESS = 8, FLO_FEAT_VALID_PRE = 9, FLO_FEAT_VALID_POST = 10,
+       FLO_FEAT_CORNER_IDX = 11, FLO_FEAT_PLANAR_IDX = 12, FLO_FEAT_RAW_INDEX = 13 };
+void* flo_feat_create(const flo_feat_params* p);
+void flo_feat_destroy(void* h);
+/* Project(): raw points as a byte-strided AoS (x,y,z floats at off_xyz, intensity float at off_intensity, ring u16 at off_ring) */
+int64_t flo_feat_project(void* h, const void* raw, size_t n, size_t stride_bytes, size_t off_xyz, size_t off_intensity, size_t off_ring);
+int flo_feat_extract(void* h); /* 1 = ran, 0 = fewer than 12 ordered points */
+/* copy one result array (element = 16 B xyzi, float, int32 or uint8 depending on `what`); returns its element count */
+size_t flo_feat_get(void* h, int what, void* out, size_t cap_elems);
+uint64_t flo_feat_tie_pairs(void* h);
+int flo_col_index(float x, float y, float h_res, int cols);
+float flo_fast_atan2f(float y, float x);
+
 /* stand-alone pieces for unit tests */
 size_t flo_voxel_grid(const float* in, size_t n, int stride_floats, float leaf, float* out_xyzi /* n x 4 */);
 void flo_so3_exp(const double v[3], double R_colmajor[9]);

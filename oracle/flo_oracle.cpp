@@ -23,6 +23,7 @@
 // ============================================================================
 #include "flo_api.h"
 #include "flo_common.h"
+#include "flo_features.h"
 #include <deque>
 #include <set>
 #include <memory>
@@ -1058,6 +1059,55 @@ size_t flo_ndt_dump(void* h, int32_t* keys, double* mu, double* info, uint8_t* e
         npts[i] = v[i]->second.num_points;
     }
     return v.size();
+}
+
+void* flo_feat_create(const flo_feat_params* p) {
+    if (!p || p->struct_size != sizeof(flo_feat_params) || p->vertical_scan <= 0 || p->horizontal_scan <= 0) return nullptr;
+    auto* s = new flo::FeatState();
+    s->p.rows = p->vertical_scan; s->p.cols = p->horizontal_scan; s->p.h_res = p->horizontal_resolution;
+    s->p.min_dist = p->min_distance; s->p.max_dist = p->max_distance; s->p.corner_thr = p->corner_thres; s->p.planar_thr = p->planar_thres;
+    return s;
+}
+void flo_feat_destroy(void* h) { delete static_cast<flo::FeatState*>(h); }
+int64_t flo_feat_project(void* h, const void* raw, size_t n, size_t stride, size_t off_xyz, size_t off_i, size_t off_ring) {
+    auto* s = static_cast<flo::FeatState*>(h);
+    flo::feat_project(*s, static_cast<const uint8_t*>(raw), n, stride, off_xyz, off_i, off_ring);
+    return int64_t(s->ordered.size());
+}
+int flo_feat_extract(void* h) { return flo::feat_extract(*static_cast<flo::FeatState*>(h)) ? 1 : 0; }
+uint64_t flo_feat_tie_pairs(void* h) { return static_cast<flo::FeatState*>(h)->tie_pairs; }
+int flo_col_index(float x, float y, float h_res, int cols) { return flo::col_index(x, y, h_res, cols); }
+float flo_fast_atan2f(float y, float x) { return flo::fast_atan2f(y, x); }
+size_t flo_feat_get(void* h, int what, void* out, size_t cap) {
+    auto* s = static_cast<flo::FeatState*>(h);
+    auto copy = [&](const void* src, size_t count, size_t elem) -> size_t {
+        if (out) std::memcpy(out, src, std::min(count, cap) * elem);
+        return count;
+    };
+    auto cloud = [&](const std::vector<int>& idx) -> size_t {
+        if (out) {
+            auto* o = static_cast<flo::FeatPoint*>(out);
+            for (size_t k = 0; k < std::min(idx.size(), cap); ++k) o[k] = s->ordered[size_t(idx[k])];
+        }
+        return idx.size();
+    };
+    switch (what) {
+        case FLO_FEAT_ORDERED: return copy(s->ordered.data(), s->ordered.size(), sizeof(flo::FeatPoint));
+        case FLO_FEAT_DEPTH: return copy(s->depth.data(), s->depth.size(), 4);
+        case FLO_FEAT_COL: return copy(s->col.data(), s->col.size(), 4);
+        case FLO_FEAT_ROW_START: return copy(s->row_start.data(), s->row_start.size(), 4);
+        case FLO_FEAT_ROW_END: return copy(s->row_end.data(), s->row_end.size(), 4);
+        case FLO_FEAT_CORNER: return cloud(s->corner_idx);
+        case FLO_FEAT_PLANAR: return cloud(s->planar_idx);
+        case FLO_FEAT_IS_CORNER: return copy(s->is_corner.data(), s->is_corner.size(), 1);
+        case FLO_FEAT_ROUGHNESS: return copy(s->roughness.data(), s->roughness.size(), 4);
+        case FLO_FEAT_VALID_PRE: return copy(s->valid_pre.data(), s->valid_pre.size(), 1);
+        case FLO_FEAT_VALID_POST: return copy(s->valid_post.data(), s->valid_post.size(), 1);
+        case FLO_FEAT_CORNER_IDX: return copy(s->corner_idx.data(), s->corner_idx.size(), 4);
+        case FLO_FEAT_PLANAR_IDX: return copy(s->planar_idx.data(), s->planar_idx.size(), 4);
+        case FLO_FEAT_RAW_INDEX: return copy(s->raw_index.data(), s->raw_index.size(), 4);
+        default: return 0;
+    }
 }
 
 size_t flo_voxel_grid(const float* in, size_t n, int stride, float leaf, float* out) {

@@ -91,6 +91,56 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+class FeatParams(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("vertical_scan", C.c_int32), ("horizontal_scan", C.c_int32),
+                ("horizontal_resolution", C.c_float), ("min_distance", C.c_float), ("max_distance", C.c_float),
+                ("corner_thres", C.c_float), ("planar_thres", C.c_float)]
+
+
+# flo_feat_get selectors -> (numpy dtype, columns)
+FEAT_ARRAYS = {"ordered": (0, np.float32, 4), "depth": (1, np.float32, 1), "col": (2, np.int32, 1), "row_start": (3, np.int32, 1),
+               "row_end": (4, np.int32, 1), "corner": (5, np.float32, 4), "planar": (6, np.float32, 4), "is_corner": (7, np.uint8, 1),
+               "roughness": (8, np.float32, 1), "valid_pre": (9, np.uint8, 1), "valid_post": (10, np.uint8, 1),
+               "corner_idx": (11, np.int32, 1), "planar_idx": (12, np.int32, 1), "raw_index": (13, np.int32, 1)}
+
+
+class OracleFeatures:
+    """CPU oracle of PointcloudProjector::Project + FeatureExtractor::ExtractFeatures (oracle/flo_features.h)."""
+
+    def __init__(self, vertical_scan, horizontal_scan, horizontal_resolution, min_distance, max_distance, corner_thres, planar_thres):
+        self.params = FeatParams(C.sizeof(FeatParams), vertical_scan, horizontal_scan, horizontal_resolution, min_distance, max_distance,
+                                 corner_thres, planar_thres)
+        self._h = lib().flo_feat_create(C.byref(self.params))
+        assert self._h
+
+    def Project(self, raw: np.ndarray) -> int:
+        """raw: structured array with fields x, y, z, intensity, ring (any itemsize / offsets)."""
+        raw = np.ascontiguousarray(raw)
+        f = raw.dtype.fields
+        assert f["y"][1] == f["x"][1] + 4 and f["z"][1] == f["x"][1] + 8
+        self._raw = raw
+        return int(lib().flo_feat_project(self._h, raw.ctypes.data, raw.shape[0], raw.dtype.itemsize, f["x"][1], f["intensity"][1], f["ring"][1]))
+
+    def ExtractFeatures(self) -> bool:
+        return bool(lib().flo_feat_extract(self._h))
+
+    def get(self, name: str) -> np.ndarray:
+        what, dt, cols = FEAT_ARRAYS[name]
+        n = lib().flo_feat_get(self._h, what, None, 0)
+        out = np.zeros((max(n, 1), cols), dtype=dt)
+        lib().flo_feat_get(self._h, what, out.ctypes.data, n)
+        out = out[:n]
+        return out if cols > 1 else out.reshape(-1)
+
+    def tie_pairs(self) -> int:
+        return int(lib().flo_feat_tie_pairs(self._h))
+
+    def close(self):
+        if self._h:
+            lib().flo_feat_destroy(self._h)
+            self._h = None
+
+
 _lib = None
 
 
@@ -138,6 +188,19 @@ def lib():
         L.flo_svd3.argtypes = [dp, dp, dp, dp]
         L.flo_knn_bruteforce.argtypes = [fp, C.c_size_t, fp, C.c_int, ip, fp]
         L.flo_kdtree_knn.argtypes = [fp, C.c_size_t, fp, C.c_size_t, C.c_int, ip, fp]
+        L.flo_feat_create.restype = C.c_void_p
+        L.flo_feat_create.argtypes = [C.POINTER(FeatParams)]
+        L.flo_feat_destroy.argtypes = [C.c_void_p]
+        L.flo_feat_project.restype = C.c_int64
+        L.flo_feat_project.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+        L.flo_feat_extract.argtypes = [C.c_void_p]
+        L.flo_feat_get.restype = C.c_size_t
+        L.flo_feat_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.flo_feat_tie_pairs.restype = C.c_uint64
+        L.flo_feat_tie_pairs.argtypes = [C.c_void_p]
+        L.flo_col_index.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
+        L.flo_fast_atan2f.restype = C.c_float
+        L.flo_fast_atan2f.argtypes = [C.c_float, C.c_float]
         _lib = L
     return _lib
 
