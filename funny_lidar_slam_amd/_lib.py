@@ -19,6 +19,8 @@ EXPORTED_SYMBOLS = [
     "fls_scan_upload", "fls_match_resident", "fls_match_batch", "fls_get_iteration_log", "fls_get_correspondences", "fls_map_size",
     "fls_set_profiling", "fls_get_kernel_time", "fls_get_traffic_counters", "fls_get_debug_stamps", "fls_status_string", "fls_abi_version",
     "fls_device_count",
+    # include/fls_features.h
+    "fls_features_create", "fls_features_destroy", "fls_features_project", "fls_features_extract", "fls_features_get", "fls_features_get_time",
 ]
 
 FLS_OK, FLS_NOT_CONVERGED = 0, 1
@@ -89,6 +91,21 @@ class Stats(C.Structure):
     ]
 
 
+class FeatureParams(C.Structure):
+    """fls_feature_params (include/fls_features.h)."""
+
+    _fields_ = [("struct_size", C.c_uint32), ("lidar_vertical_scan", C.c_int32), ("lidar_horizontal_scan", C.c_int32),
+                ("lidar_horizontal_resolution", C.c_float), ("min_distance", C.c_float), ("max_distance", C.c_float),
+                ("corner_thres", C.c_float), ("planar_thres", C.c_float), ("corner_voxel_filter_size", C.c_float),
+                ("planar_voxel_filter_size", C.c_float)]
+
+
+class PointLayout(C.Structure):
+    """fls_point_layout (include/fls_features.h)."""
+
+    _fields_ = [("stride_bytes", C.c_uint32), ("xyz_offset", C.c_uint32), ("intensity_offset", C.c_uint32), ("ring_offset", C.c_uint32)]
+
+
 def build(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 build of libfls_reg.so (cross-compiles without a GPU)."""
     if force or not os.path.exists(LIB_PATH):
@@ -143,6 +160,18 @@ def lib():
         L.fls_get_traffic_counters.argtypes = [hp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.fls_get_debug_stamps.restype = C.c_int
         L.fls_get_debug_stamps.argtypes = [hp, C.POINTER(C.c_int64)]
+        L.fls_features_create.restype = C.c_int
+        L.fls_features_create.argtypes = [C.POINTER(FeatureParams), C.c_int, C.POINTER(hp)]
+        L.fls_features_destroy.restype = None
+        L.fls_features_destroy.argtypes = [hp]
+        L.fls_features_project.restype = C.c_int
+        L.fls_features_project.argtypes = [hp, C.c_void_p, C.c_size_t, C.POINTER(PointLayout), C.POINTER(C.c_size_t)]
+        L.fls_features_extract.restype = C.c_int
+        L.fls_features_extract.argtypes = [hp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.fls_features_get.restype = C.c_size_t
+        L.fls_features_get.argtypes = [hp, C.c_int, C.c_void_p, C.c_size_t]
+        L.fls_features_get_time.restype = C.c_int
+        L.fls_features_get_time.argtypes = [hp, dp, dp]
         L.fls_status_string.restype = C.c_char_p
         L.fls_status_string.argtypes = [C.c_int]
         L.fls_abi_version.restype = C.c_int

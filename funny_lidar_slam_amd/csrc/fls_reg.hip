@@ -5,6 +5,7 @@
 #include "matcher_p2plane_ivox.hpp"
 #include "matchers_kd.hpp"
 #include "matcher_ndt.hpp"
+#include "features_host.hpp"
 #include <new>
 
 using namespace fls;
@@ -209,6 +210,58 @@ fls_status fls_get_traffic_counters(fls_handle h, uint64_t* probes, uint64_t* hi
     if (probes) *probes = h->last_tc.probes;
     if (hit_voxels) *hit_voxels = h->last_tc.hits;
     if (cand_points) *cand_points = h->last_tc.cand;
+    return FLS_OK;
+}
+
+// ---- LOAM feature front-end (include/fls_features.h) ------------------------------------------------------------
+fls_status fls_features_create(const fls_feature_params* params, int device_id, fls_features_handle* out) {
+    if (!out) return FLS_ERR_INVALID;
+    *out = nullptr;
+    if (!params) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return FLS_ERR_DEVICE;
+        hipDeviceProp_t prop;
+        FLS_HIP(hipGetDeviceProperties(&prop, device_id));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FLS_ERR_DEVICE;
+        std::unique_ptr<fls_features> f(new fls_features());
+        f->p = *params;
+        f->device = device_id;
+        const fls_status rc = f->init();
+        if (rc != FLS_OK) return rc;
+        *out = f.release();
+        return FLS_OK;
+    });
+}
+
+void fls_features_destroy(fls_features_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    delete h;
+}
+
+fls_status fls_features_project(fls_features_handle h, const void* raw, size_t n, const fls_point_layout* layout, size_t* n_ordered) {
+    if (!h || !layout || (!raw && n)) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(h->device));
+        return h->project(raw, n, *layout, n_ordered);
+    });
+}
+
+fls_status fls_features_extract(fls_features_handle h, size_t* n_corner, size_t* n_planar) {
+    if (!h) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(h->device));
+        return h->extract(n_corner, n_planar);
+    });
+}
+
+size_t fls_features_get(fls_features_handle h, int what, void* out, size_t cap_elems) { return h ? h->get(what, out, cap_elems) : 0; }
+
+fls_status fls_features_get_time(fls_features_handle h, double* project_ms, double* extract_ms) {
+    if (!h) return FLS_ERR_INVALID;
+    if (project_ms) *project_ms = h->project_ms;
+    if (extract_ms) *extract_ms = h->extract_ms;
     return FLS_OK;
 }
 

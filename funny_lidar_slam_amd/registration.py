@@ -38,6 +38,13 @@ class PointcloudCluster:
     ordered_cloud_: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
     planar_cloud_: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
     corner_cloud_: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    # LOAM front-end fields (lidar/pointcloud_cluster.h): raw driver cloud in, range-image bookkeeping out
+    raw_cloud_: np.ndarray = None          # structured array with x, y, z, intensity, ring (e.g. synth.RAW_POINT_DTYPE)
+    point_depth_vec_: np.ndarray = None
+    point_col_index_vec_: np.ndarray = None
+    row_start_index_vec_: np.ndarray = None
+    row_end_index_vec_: np.ndarray = None
+    feature_state_: object = None          # device-resident projection the FeatureExtractor continues from
 
 
 def _cloud(c):

@@ -14,9 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "fls_reg.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(fls_[a-z_0-9]+)\s*\(", src)))
+    syms = set()
+    for header in ("fls_reg.h", "fls_features.h"):
+        src = open(os.path.join(ROOT, "include", header)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        syms |= set(re.findall(r"\b(fls_[a-z_0-9]+)\s*\(", src))
+    return sorted(syms)
 
 
 def test_header_symbols_all_exported(built):
@@ -37,6 +40,12 @@ def test_struct_layouts_match_header(built):
     assert names == [f[0] for f in _lib.Params._fields_]
     assert [f[0] for f in O.Params._fields_] == names  # the oracle mirrors the same layout independently
     assert C.sizeof(_lib.Params) == 128 and C.sizeof(_lib.Stats) == 96
+    src = open(os.path.join(ROOT, "include", "fls_features.h")).read()
+    body = re.search(r"typedef struct fls_feature_params \{(.*?)\} fls_feature_params;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n for decl in re.findall(r"(?:uint32_t|int32_t|float)\s+([^;]+);", body) for n in re.split(r"\s*,\s*", decl.strip())]
+    assert names == [f[0] for f in _lib.FeatureParams._fields_]
+    assert C.sizeof(_lib.FeatureParams) == 40 and C.sizeof(_lib.PointLayout) == 16
 
 
 def test_invalid_arguments_rejected(built):
@@ -67,6 +76,9 @@ def test_no_cpu_fallback_without_gpu(built):
     from funny_lidar_slam_amd import registration as reg
     with pytest.raises(_lib.FlsError):
         reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+    from funny_lidar_slam_amd import features
+    with pytest.raises(_lib.FlsError):
+        features.FeatureFrontEnd(1800, 64, 0.00349, 4.0, 100.0, 1.0, 0.1)
 
 
 def test_product_does_not_reference_the_oracle():
