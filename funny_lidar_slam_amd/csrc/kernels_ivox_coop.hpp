@@ -144,7 +144,7 @@ __device__ __forceinline__ unsigned slot_select(const unsigned idx, const unsign
     return idx + sel;
 }
 
-template <int G, bool COUNT, bool DENSE, bool FIRST>
+template <int G, bool COUNT, bool DENSE, bool FIRST, bool BAL = false>
 __global__ void __launch_bounds__(256)
 ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
                 const GnState* __restrict__ st, const Pose16 T0, const DevGrid grid, const DenseWindow win,
@@ -260,6 +260,65 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
     // (unsigned wrap-around is intended)
     const unsigned o0 = b0, o1 = b1 - p1, o2 = b2 - p2, o3 = b3 - p3, o4 = b4 - p4;
     auto slot_of = [=](const unsigned idx) -> unsigned { return slot_select<R>(idx, p1, p2, p3, p4, o0, o1, o2, o3, o4); };
+    if (BAL && G == 4) {
+        // Balanced split: the group's candidates (all hit voxels of the query, concatenated) are cut into four equal
+        // contiguous ranges, one per lane, instead of whole voxels per lane: a wave runs max-over-lanes trips of the
+        // loop below, and voxels hold 1..20+ points (4.7 trips of four candidates per wave before, 2.8 after).
+        // The hit voxels are compacted into a per-group LDS table {prefix end, begin - prefix start}; a lane walks
+        // its range through a 5-entry window of that table (four candidates span at most five voxels).
+        __shared__ __attribute__((aligned(16))) unsigned s_end[QPB][24];
+        __shared__ __attribute__((aligned(16))) unsigned s_off[QPB][24];
+        const int g = threadIdx.x / G;
+        const unsigned nz = (c0 ? 1u : 0u) + (c1 ? 1u : 0u) + (c2 ? 1u : 0u) + (c3 ? 1u : 0u) + (c4 ? 1u : 0u);
+        const unsigned packed = tot * 32u + nz;  // candidates (< 2^27) and hit voxels (<= 19 per group) of this lane
+        const unsigned t0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)packed, 0x00, 0xf, 0xf, true);  // quad broadcasts
+        const unsigned t1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)packed, 0x55, 0xf, 0xf, true);
+        const unsigned t2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)packed, 0xAA, 0xf, 0xf, true);
+        const unsigned t3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)packed, 0xFF, 0xf, 0xf, true);
+        const unsigned before = (sub > 0 ? t0 : 0u) + (sub > 1 ? t1 : 0u) + (sub > 2 ? t2 : 0u), all = t0 + t1 + t2 + t3;
+        const unsigned TOT = all >> 5;
+        unsigned pos = before & 31u, run = before >> 5;
+        // every entry behind the last real one is a sentinel (the window looks four entries ahead, the start search
+        // reads twenty): the whole row is filled first, the real entries overwrite (LDS operations of a wave are in order)
+        {
+            uint2* const rowp = reinterpret_cast<uint2*>(&s_end[g][6 * sub]);
+            rowp[0] = make_uint2(~0u, ~0u); rowp[1] = make_uint2(~0u, ~0u); rowp[2] = make_uint2(~0u, ~0u);
+        }
+        if (c0) { s_off[g][pos] = b0 - run; run += c0; s_end[g][pos] = run; ++pos; }
+        if (c1) { s_off[g][pos] = b1 - run; run += c1; s_end[g][pos] = run; ++pos; }
+        if (c2) { s_off[g][pos] = b2 - run; run += c2; s_end[g][pos] = run; ++pos; }
+        if (c3) { s_off[g][pos] = b3 - run; run += c3; s_end[g][pos] = run; ++pos; }
+        if (c4) { s_off[g][pos] = b4 - run; run += c4; s_end[g][pos] = run; ++pos; }
+        // a group lives inside one wave and the LDS serves a wave's operations in order: no workgroup barrier, only a
+        // compiler-level ordering point between the table writes and the cross-lane reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned Q = (TOT + 3u) >> 2, a = sub * Q, e = a + Q < TOT ? a + Q : TOT;
+        unsigned k = 0;  // first table entry whose range reaches past a
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            const uint4 e4 = *reinterpret_cast<const uint4*>(&s_end[g][4 * v]);
+            k += (e4.x <= a ? 1u : 0u) + (e4.y <= a ? 1u : 0u) + (e4.z <= a ? 1u : 0u) + (e4.w <= a ? 1u : 0u);
+        }
+        for (unsigned idx = a; idx < e; idx += 4) {
+            const unsigned E0 = s_end[g][k], E1 = s_end[g][k + 1], E2 = s_end[g][k + 2], E3 = s_end[g][k + 3];
+            const unsigned O0 = s_off[g][k], O1 = s_off[g][k + 1], O2 = s_off[g][k + 2], O3 = s_off[g][k + 3], O4 = s_off[g][k + 4];
+            const unsigned last = e - 1;
+            const unsigned i1 = idx + 1, i2 = idx + 2, i3 = idx + 3;
+            const unsigned s0 = slot_select<5>(idx, E0, E1, E2, E3, O0, O1, O2, O3, O4);
+            const unsigned s1 = slot_select<5>(i1 < last ? i1 : last, E0, E1, E2, E3, O0, O1, O2, O3, O4);
+            const unsigned s2 = slot_select<5>(i2 < last ? i2 : last, E0, E1, E2, E3, O0, O1, O2, O3, O4);
+            const unsigned s3 = slot_select<5>(i3 < last ? i3 : last, E0, E1, E2, E3, O0, O1, O2, O3, O4);
+            const float4 q0 = grid.pts[s0], q1 = grid.pts[s1], q2 = grid.pts[s2], q3 = grid.pts[s3];
+            consider(q0, s0, true);
+            consider(q1, s1, i1 <= last);
+            consider(q2, s2, i2 <= last);
+            consider(q3, s3, i3 <= last);
+            const unsigned nx = idx + 4;
+            k += (E0 <= nx ? 1u : 0u) + (E1 <= nx ? 1u : 0u) + (E2 <= nx ? 1u : 0u) + (E3 <= nx ? 1u : 0u);
+        }
+    } else
     for (unsigned j = 0; j < tot; j += 4) {
         const unsigned last = tot - 1;
         const unsigned i1 = j + 1, i2 = j + 2, i3 = j + 3;
