@@ -149,16 +149,19 @@ __global__ void __launch_bounds__(256)
 ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
                 const GnState* __restrict__ st, const Pose16 T0, const DevGrid grid, const DenseWindow win,
                 const float inv_res, float4* __restrict__ nn_pts /* [n][5] */, unsigned char* __restrict__ nn_cnt,
-                unsigned char* __restrict__ flag, TrafficCounters* __restrict__ tc) {
+                unsigned char* __restrict__ flag, TrafficCounters* __restrict__ tc, const int chunk) {
     static_assert(G == 4 || G == 8, "group size");
     constexpr int QPB = 256 / G;       // queries per workgroup
     constexpr int R = (19 + G - 1) / G;  // probe rounds per lane
-    // XCD-aware block order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with
-    // its own 4 MiB L2.  Re-map so that XCD x walks ONE contiguous eighth of the (ring-major, hence spatially
-    // coherent) scan: every L2 then caches its own slice of the map instead of all of it.  Affects speed only.
-    // (the grid is launched rounded up to a multiple of 8 so that the re-map is a bijection)
-    const int nb = (n + QPB - 1) / QPB, per = gridDim.x >> 3;
-    const int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    // XCD-aware block order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with its own
+    // 4 MiB L2.  Re-map so that XCD x walks CHUNKS of `chunk` consecutive workgroups (chunk * QPB consecutive points of
+    // the ring-major, hence spatially coherent, scan), the chunks of the 8 XCDs interleaved.  One contiguous eighth of
+    // the scan per XCD (the first version) caches best but balances worst: the rings differ in map density, the
+    // busiest XCD carried 38 % more candidate work than the mean.  Affects speed only.
+    // (the grid is launched rounded up to a multiple of 8 * chunk so that the re-map is a bijection)
+    const int nb = (n + QPB - 1) / QPB;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int lb = ((seq / chunk) * 8 + xcd) * chunk + (seq % chunk);
     const int sub = threadIdx.x % G;
     const int q = lb * QPB + threadIdx.x / G;
     const bool active = lb < nb && q < n;

@@ -32,6 +32,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     std::vector<Pt4> h_pw;
     DevBuf<unsigned> d_ticket;
     bool use_dense = true; // dense voxel window instead of the hash table when the map extent allows (FLS_IVOX_DENSE=0 disables)
+    int xcd_chunk = 8;     // workgroups per XCD chunk of the kNN block re-map (FLS_IVOX_XCD_CHUNK)
     bool balanced = true;  // equal candidate ranges per lane through an LDS voxel table (FLS_IVOX_BALANCED=0: whole voxels per lane)
     int variant = 4;       // lanes cooperating on one query in ivox_knn_kernel: 4 or 8 (FLS_IVOX_VARIANT)
     bool is_first = true;  // the reference's function-static flag (:62), per handle here
@@ -60,6 +61,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (const char* e = std::getenv("FLS_IVOX_VARIANT")) { const int v = std::atoi(e); if (v == 4 || v == 8) variant = v; }
         if (const char* e = std::getenv("FLS_IVOX_DENSE")) use_dense = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_BALANCED")) balanced = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_IVOX_XCD_CHUNK")) { const int c = std::atoi(e); if (c >= 1 && c <= 4096) xcd_chunk = c; }
         d_ticket.reserve(1);
         FLS_HIP(hipMemsetAsync(d_ticket.p, 0, sizeof(unsigned), stream));
         ivox.resolution = 0.5f;       // InitIVox :53-58
@@ -217,10 +219,11 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
 
     template <int G>
     void launch_knn(const size_t n, const int first, const Pose16& T0, const DevGrid& g, const DenseWindow& win) {
-        const dim3 grid(unsigned((((n * G + 255) / 256) + 7) / 8 * 8));  // multiple of 8: XCD re-map is a bijection
+        const size_t nblk = (n * G + 255) / 256, gran = size_t(8) * size_t(xcd_chunk);
+        const dim3 grid(unsigned((nblk + gran - 1) / gran * gran));  // multiple of 8 * chunk: the XCD re-map is a bijection
 #define FLS_KNN_L(C, D, F, B)                                                                                                        \
     hipLaunchKernelGGL((ivox_knn_kernel<G, C, D, F, B>), grid, dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, T0, g, \
-                       win, ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p)
+                       win, ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p, xcd_chunk)
 #define FLS_KNN(C, D)                                                                                                                \
     do {                                                                                                                             \
         if (balanced && G == 4) { if (first) FLS_KNN_L(C, D, true, true); else FLS_KNN_L(C, D, false, true); }                        \
@@ -319,7 +322,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         std::vector<std::thread> th;
         for (size_t l = 0; l < L; ++l) {
             P2PlaneIvoxMatcher* q = lanes[l].get();
-            q->use_dense = use_dense; q->variant = variant; q->balanced = balanced; q->expect_iters = expect_iters;
+            q->use_dense = use_dense; q->variant = variant; q->balanced = balanced; q->xcd_chunk = xcd_chunk; q->expect_iters = expect_iters;
             th.emplace_back([=, &lane_rc]() {
                 try {
                     FLS_HIP(hipSetDevice(q->device));
