@@ -74,6 +74,23 @@ def run_sequence():
     return out
 
 
+FEAT16 = dict(vertical_scan=16, horizontal_scan=1800, min_distance=4.0, max_distance=100.0, corner_thres=1.0, planar_thres=0.1)
+
+
+def run_features():
+    """One Velodyne-16 frame (16 x 900 firings, lidar_model.cpp:24-30 columns) through the feature front-end oracle."""
+    from oracle import oracle as O
+    scene = synth.make_scene()
+    raw = synth.cast_raw_scan(scene, synth.random_pose(synth.rng_for(0, 4), 10.0, 2.0), rng=synth.rng_for(0, 0, 4), **synth.VELODYNE_16)
+    o = O.OracleFeatures(horizontal_resolution=float(np.float32(0.2) / 180.0 * np.pi), **FEAT16)
+    o.Project(raw)
+    o.ExtractFeatures()
+    out = dict(raw=raw.view(np.uint8).reshape(raw.shape[0], raw.dtype.itemsize))
+    for name in O.FEAT_ARRAYS:
+        out[name] = o.get(name)
+    return out
+
+
 if __name__ == "__main__":
     for name, args in CASES.items():
         d = run_case(*args)
@@ -83,3 +100,6 @@ if __name__ == "__main__":
     d = run_sequence()
     np.savez_compressed(os.path.join(HERE, "p2plane_ivox_sequence.npz"), **d)
     print("sequence", d["map_sizes"], d["n_valid"], d["iterations"], d["ok"])
+    d = run_features()
+    np.savez_compressed(os.path.join(HERE, "features_velodyne16.npz"), **d)
+    print("features", {k: v.shape for k, v in d.items() if k in ("raw", "ordered", "corner", "planar")})

@@ -97,3 +97,32 @@ def test_hip_matches_golden_sequence(built):
         good, dt, dr = util.pose_close(T, g["T"][k])
         assert good, (k, dt, dr)
         guess = T
+
+
+def _features_raw(g):
+    return np.ascontiguousarray(g["raw"]).view(synth.RAW_POINT_DTYPE).reshape(-1)
+
+
+def test_oracle_reproduces_golden_features():
+    from oracle import oracle as O
+    from tests.golden.make_golden import FEAT16
+    g = load("features_velodyne16")
+    o = O.OracleFeatures(horizontal_resolution=float(np.float32(0.2) / 180.0 * np.pi), **FEAT16)
+    o.Project(_features_raw(g))
+    assert o.ExtractFeatures()
+    for name in O.FEAT_ARRAYS:
+        assert np.array_equal(o.get(name).view(np.uint8), g[name].view(np.uint8)), name
+
+
+@pytest.mark.gpu
+def test_gpu_matches_golden_features(built):
+    from funny_lidar_slam_amd import features
+    from oracle import oracle as O
+    from tests.golden.make_golden import FEAT16
+    g = load("features_velodyne16")
+    f = features.FeatureFrontEnd(FEAT16["horizontal_scan"], FEAT16["vertical_scan"], float(np.float32(0.2) / 180.0 * np.pi), FEAT16["min_distance"],
+                                 FEAT16["max_distance"], FEAT16["corner_thres"], FEAT16["planar_thres"])
+    f.project(_features_raw(g))
+    f.extract()
+    for name in O.FEAT_ARRAYS:
+        assert np.array_equal(f.get(name).view(np.uint8), g[name].view(np.uint8)), name
