@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the configs[4] batch measurement")
     ap.add_argument("--batch-jobs", type=int, default=64, help="configs[4] jobs per GPU")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl == RCCL; gloo + FLS_BENCH_SHARE_DEVICE=1 exercises the N > 1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -103,10 +105,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    share = os.environ.get("FLS_BENCH_SHARE_DEVICE", "0") == "1"  # test hook: every rank on device 0 (1-GPU box)
+    dev = 0 if (share or not distributed) else local_rank
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"  # where the tiny collective payloads live
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend="gloo")
     n_gpus = world if distributed else 1
     if args.gpus != n_gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
@@ -115,7 +123,6 @@ def main():
 
     if _lib.device_count() < 1:
         raise RuntimeError("bench.py needs an MI355X (gfx950); the HIP path has no CPU fallback")
-    dev = local_rank if distributed else 0
     torch.cuda.set_device(dev)
 
     y = reg.YAML_NCLT_IVOX
@@ -164,12 +171,12 @@ def main():
     assert m.stats.iterations == iters
 
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         from funny_lidar_slam_amd import batch
         row = batch.pack_result(T, ok, m.stats.iterations, m.stats.n_valid, m.stats.sum_res)
-        table = batch.gather_results(row[None, :], world, batch.RESULT_WIDTH, device="cuda")  # one job per rank per step
+        table = batch.gather_results(row[None, :], world, batch.RESULT_WIDTH, device=coll_dev)  # one job per rank per step
         assert table.shape == (world, batch.RESULT_WIDTH)
         assert bool(np.all(table == table[0])), "identical jobs on identical GPUs must give bit-identical results"
 
@@ -195,13 +202,13 @@ def main():
             tb = time.perf_counter()
             oks, Tb, sb = m.MatchBatch(clusters, T0s, lanes=lanes)
             rows = np.stack([batch.pack_result(Tb[k], oks[k], sb[k].iterations, sb[k].n_valid, sb[k].sum_res) for k in range(len(clusters))])
-            tab = batch.gather_results(rows, n_jobs, batch.RESULT_WIDTH, device="cuda" if distributed else None)
+            tab = batch.gather_results(rows, n_jobs, batch.RESULT_WIDTH, device=coll_dev if distributed else None)
             torch.cuda.synchronize()
             if distributed:
                 dist.barrier()
             tb = time.perf_counter() - tb
             if distributed:
-                tm = torch.tensor([tb], dtype=torch.float64, device="cuda")
+                tm = torch.tensor([tb], dtype=torch.float64, device=coll_dev)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 tb = float(tm.item())
             reps.append(tb)
