@@ -162,13 +162,9 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
     resolve(pv2, k2, h2, e2, b2, c2);
     resolve(pv3, k3, h3, e3, b3, c3);
     const unsigned tot = c1 + c2 + c3;
-    auto slot_of = [&](unsigned idx) -> unsigned {
-        if (idx < c1) return b1 + idx;
-        idx -= c1;
-        if (idx < c2) return b2 + idx;
-        idx -= c2;
-        return b3 + idx;
-    };
+    // candidate index -> map slot: compare / select chain on values (kernels_ivox_coop.hpp slot_select), no branches
+    const unsigned p1 = c1, p2 = c1 + c2, o0 = b1, o1 = b2 - p1, o2 = b3 - p2;
+    auto slot_of = [=](const unsigned idx) -> unsigned { return slot_select<3>(idx, p1, p2, 0u, 0u, o0, o1, o2, 0u, 0u); };
     for (unsigned j = 0; j < tot; j += 4) {
         const unsigned last = tot - 1;
         const unsigned i1 = j + 1, i2 = j + 2, i3 = j + 3;

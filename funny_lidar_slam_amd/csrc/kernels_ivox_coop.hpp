@@ -1,22 +1,22 @@
 // kernels_ivox_coop.hpp -- the production iVox point-to-plane path, split for the machine:
 //
-//   ivox_knn_kernel<G>   G lanes cooperate on ONE source point: the 19 voxel probes are dealt round-robin
-//                        to the G lanes (all first-slot hash loads of a wave are in flight together), every
-//                        lane scans the points of the voxels it hit into a private top-5 held as 64-bit
-//                        keys {float-bits(d2) : map slot}, and the G private lists are merged by five
-//                        rounds of a DPP/shuffle group-min.  Few registers -> 8 waves/SIMD, G x more waves
-//                        than points/64: the dependent gathers (table -> voxel points) are hidden by
-//                        thread-level parallelism instead of being serialised in one lane (the first,
-//                        fused kernel spent 117 us per launch that way).
+//   ivox_knn_kernel<G>   G lanes cooperate on ONE source point: the 19 voxel probes are dealt round-robin to the G
+//                        lanes (all probe loads of a wave are in flight together); the hit voxels' points are then
+//                        split into equal contiguous ranges per lane (BAL: per-group LDS voxel table) or taken
+//                        voxel-wise (hash-table fallback, G = 8); every lane scans its candidates four loads at a
+//                        time into a private sorted top-5 of keys {float-bits(d2) : map slot} held as IEEE doubles
+//                        (v_min_f64 / v_max_f64 insertion), and the G private lists are merged by five rounds of a
+//                        DPP group-min.  58 VGPRs -> 8 waves/SIMD, G x more waves than points/64: the dependent
+//                        gathers (cell -> voxel points) are hidden by thread-level parallelism instead of being
+//                        serialised in one lane (the first, fused kernel spent 117 us per launch that way).
 //                        Output: nearest_points_[i] (<=5 float4 {x,y,z,id}) + count; untouched when no
 //                        candidate exists (ivox_map.cpp:21-23 quirk).
 //   p2plane_fit_solve_kernel  one lane per source point: 5x3 column-pivoted Householder plane fit, gates,
 //                        Jacobian (FP64), the Q1 stale-slot rule, DPP wave reduction of the 6x6 system; the last
 //                        workgroup to finish also runs the Gauss-Newton tail (solve, pose update, stop rule).
 //
-// (An earlier single-kernel variant with one lane per point ran 117 us per launch: it serialised ~60
-// dependent gathers per lane.)  Exact-tie rule of the selection: lower map slot wins (the reference's
-// order under exact float ties is libstdc++-introselect-defined; parity tests count such queries).
+// Exact-tie rule of the selection: lower map slot wins (the reference's order under exact float ties is
+// libstdc++-introselect-defined; parity tests count such queries).
 #pragma once
 #include "kernels_p2plane.hpp"
 
@@ -74,16 +74,6 @@ __device__ __forceinline__ int group_sum_i32(int v) {
     if (G >= 16) v += (int)dpp_pair_u32<3>((unsigned)v);
     if (G == 32) v += __shfl_xor(v, 16, 64);
     return v;
-}
-
-__device__ __forceinline__ void top5_insert_key(unsigned long long (&t)[5], const unsigned long long key) {
-    if (key < t[4]) {
-        t[4] = key;
-#pragma unroll
-        for (int j = 4; j > 0; --j) {
-            if (t[j] < t[j - 1]) { const unsigned long long x = t[j]; t[j] = t[j - 1]; t[j - 1] = x; }
-        }
-    }
 }
 
 // Selection keys as IEEE doubles: the 64-bit key {float-bits(d2) + kKeyBias : map slot} read as a positive NORMAL

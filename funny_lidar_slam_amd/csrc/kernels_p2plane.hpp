@@ -13,7 +13,7 @@
 //   and the per-wave part of SumCoefficient      :326-340
 // gn_solve_loam_kernel finishes SumCoefficient (fixed-order reduction of the wave partials) and runs
 //   dx = H.fullPivHouseholderQr().solve(g); R <- Exp(dx[0:3]) R; t += dx[3:6]; stop rule   :167-195
-// on the device so that a whole Match needs one host synchronisation.
+// on the device: the host never synchronises inside a Match, it polls the result mailbox.
 //
 // This header holds what every LOAM-family kind shares: the point-to-plane residual, the wave reduction of
 // the rank-1 normal-equation terms (DPP row shifts: no LDS, no atomics -> bit-reproducible) and the

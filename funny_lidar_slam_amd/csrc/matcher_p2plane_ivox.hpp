@@ -3,8 +3,8 @@
 //
 //   AddCloudToLocalMap  :60-139   first call / localization: insert all; later: the
 //                                 centre-distance down-sampling rule on the last kNN result
-//   Match               :141-216  device-resident Gauss-Newton loop (2 launches / iteration,
-//                                 one host synchronisation per Match)
+//   Match               :141-216  device-resident Gauss-Newton loop (2 launches / iteration, the host waits on a
+//                                 mailbox word instead of synchronising the stream)
 //   GetFitnessScore     :225-253  localization mode only (FloatNaN otherwise)
 #pragma once
 #include "matcher_base.hpp"
