@@ -142,9 +142,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # hipEvents bracket every correspondence-kernel launch of every EVENT_EVERY-th step of the timed region
-    # (each recorded event is a marker packet between two kernels: ~2-3 us; bracketing every step would cost
-    # ~10 % of `value`).  The events are settled after the region.
+    # start / stop hipEvents are attached to every correspondence-kernel launch of every EVENT_EVERY-th step of the
+    # timed region (hipExtLaunchKernelGGL: the kernel's own execution time); they are settled after the region.
     EVENT_EVERY = 4
     m.kernel_time()  # reset the accumulators
     if distributed:

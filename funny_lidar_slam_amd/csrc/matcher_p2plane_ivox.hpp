@@ -13,6 +13,7 @@
 #include "kernels_ivox_coop.hpp"
 #include "fitness_host.hpp"
 #include <thread>
+#include <hip/hip_ext.h>
 
 namespace fls {
 
@@ -217,13 +218,18 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         return FLS_OK;
     }
 
+    // e0 / e1 (profiling only): start / stop events attached to the kernel's own dispatch packet (hipExtLaunchKernelGGL),
+    // i.e. the kernel's execution time as a kernel trace sees it -- a hipEventRecord bracket also times the dispatch of
+    // the kernel between its two marker packets (about 3 us more on an 18 us kernel)
     template <int G>
-    void launch_knn(const size_t n, const int first, const Pose16& T0, const DevGrid& g, const DenseWindow& win) {
+    void launch_knn(const size_t n, const int first, const Pose16& T0, const DevGrid& g, const DenseWindow& win, hipEvent_t e0 = nullptr,
+                    hipEvent_t e1 = nullptr) {
         const size_t nblk = (n * G + 255) / 256, gran = size_t(8) * size_t(xcd_chunk);
         const dim3 grid(unsigned((nblk + gran - 1) / gran * gran));  // multiple of 8 * chunk: the XCD re-map is a bijection
 #define FLS_KNN_L(C, D, F, B)                                                                                                        \
-    hipLaunchKernelGGL((ivox_knn_kernel<G, C, D, F, B>), grid, dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, T0, g, \
-                       win, ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p, xcd_chunk)
+    hipExtLaunchKernelGGL((ivox_knn_kernel<G, C, D, F, B>), grid, dim3(256), 0, stream, e0, e1, 0, (const float*)scan.x.p,           \
+                          (const float*)scan.y.p, (const float*)scan.z.p, int(n), (const GnState*)d_state.p, T0, g, win,            \
+                          ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p, xcd_chunk)
 #define FLS_KNN(C, D)                                                                                                                \
     do {                                                                                                                             \
         if (balanced && G == 4) { if (first) FLS_KNN_L(C, D, true, true); else FLS_KNN_L(C, D, false, true); }                        \
@@ -265,9 +271,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         Pose16 T0;
         std::memcpy(T0.m, T, sizeof(T0.m));
         const unsigned word = run_mailbox_loop(iters, n, [&](int it, int first) {
-            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
-            if (variant == 4) launch_knn<4>(n, first, T0, g, win); else launch_knn<8>(n, first, T0, g, win);
-            if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
+            hipEvent_t e0 = profiling ? ev[2 * it] : nullptr, e1 = profiling ? ev[2 * it + 1] : nullptr;
+            if (variant == 4) launch_knn<4>(n, first, T0, g, win, e0, e1); else launch_knn<8>(n, first, T0, g, win, e0, e1);
 #define FLS_FIT(F)                                                                                                                   \
     hipLaunchKernelGGL(p2plane_fit_solve_kernel<F>, dim3(nwg), dim3(kFitThreads), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),  \
                        d_state.p, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,     \
