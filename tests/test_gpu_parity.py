@@ -206,3 +206,21 @@ def test_match_batch_default_path_other_kind():
         T = np.eye(4)
         ok = f.Match(clusters[j], T, update_map=False)
         assert ok == oks[j] and np.array_equal(T, Ts[j]) and f.stats.iterations == stats[j].iterations
+
+
+@pytest.mark.parametrize("job", list(range(1, 9)))
+def test_config2_many_scans_reduced(job):
+    """Eight more scans (different ground-truth poses and noise draws) at a 4 % slice of configs[1]: the bit-exact
+    correspondence claim is a claim about every query, so it is exercised on more than the one benchmark scan."""
+    cfg = synth.make_config(1, job=job, scale=0.04)
+    run_pair("PointToPlane_IVOX", reg.YAML_NCLT_IVOX, [cfg["map"]], cfg["scan"], sets_only_tail=True)
+
+
+@pytest.mark.parametrize("job", [1, 2, 3])
+def test_other_kinds_more_scans_reduced(job):
+    cfg = synth.make_config(2, job=job, scale=0.05)
+    run_pair("IncrementalNDT", reg.YAML_NCLT_NDT, [cfg["map"]], cfg["scan"])
+    cfg = synth.make_config(3, job=job, scale=0.05)
+    run_pair("LoamFull_KdTree", reg.YAML_NCLT_LOAM_FULL, [cfg["map"], cfg["corner_map"]], cfg["scan"], corner=cfg["corner_scan"])
+    cfg = synth.make_config(0, job=job)
+    run_pair("IcpOptimized", reg.YAML_NCLT_ICP, [cfg["map"]], cfg["scan"], loc=True)
