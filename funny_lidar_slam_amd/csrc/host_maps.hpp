@@ -395,8 +395,10 @@ inline std::vector<PtI> voxel_grid(const std::vector<PtI>& in, float leaf) {
 // ---------------------------------------------------------------------------------------------
 struct CellGridImage : GridImage {
     float cell = 1.0f, inv_cell = 1.0f;
+    int rings = 1;  // 2: the cell is half the gate radius, the search covers the 5x5x5 block in two stages
     size_t n_cells = 0;
-    fls_status build(const std::vector<PtI>& cloud, float cell_size, hipStream_t s) {
+    fls_status build(const std::vector<PtI>& cloud, float cell_size, hipStream_t s, int n_rings = 1) {
+        rings = n_rings;
         cell = cell_size;
         inv_cell = 1.0f / cell_size;
         const size_t n = cloud.size();

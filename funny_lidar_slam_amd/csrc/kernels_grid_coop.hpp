@@ -27,6 +27,12 @@ namespace fls {
 // centre, 6 faces, 12 edges, 8 corners
 __device__ const unsigned char kCellOrder[27] = {13, 4, 10, 12, 14, 16, 22, 1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25, 0, 2, 6, 8, 18, 20, 24, 26};
 
+// the 98 cells of the 5x5x5 block that are not in the inner 3x3x3 (code = (dx+2) + 5 (dy+2) + 25 (dz+2)), nearest-first
+__device__ const unsigned char kShellOrder[98] = {
+    12, 52, 60, 64, 72, 112, 7, 11, 13, 17, 27, 35, 39, 47, 51, 53, 55, 59, 65, 69, 71, 73, 77, 85, 89, 97, 107, 111, 113, 117, 6, 8, 16, 18,
+    26, 28, 30, 34, 40, 44, 46, 48, 76, 78, 80, 84, 90, 94, 96, 98, 106, 108, 116, 118, 2, 10, 14, 22, 50, 54, 70, 74, 102, 110, 114, 122, 1,
+    3, 5, 9, 15, 19, 21, 23, 25, 29, 45, 49, 75, 79, 95, 99, 101, 103, 105, 109, 115, 119, 121, 123, 0, 4, 20, 24, 100, 104, 120, 124};
+
 template <int K>
 __device__ __forceinline__ void topk_insert(unsigned long long (&t)[K], unsigned (&s)[K], const unsigned long long key, const unsigned slot) {
     if (key < t[K - 1]) {
@@ -78,7 +84,7 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
         qz = (float)(((T[2] * x + T[6] * y) + T[10] * z) + T[14]);
     }
     const double fx = floor((double)qx * cg.inv_cell), fy = floor((double)qy * cg.inv_cell), fz = floor((double)qz * cg.inv_cell);
-    const bool in_range = active && fabs(fx) < (double)(kKeyLimit - 2) && fabs(fy) < (double)(kKeyLimit - 2) && fabs(fz) < (double)(kKeyLimit - 2);
+    const bool in_range = active && fabs(fx) < (double)(kKeyLimit - 3) && fabs(fy) < (double)(kKeyLimit - 3) && fabs(fz) < (double)(kKeyLimit - 3);
     const int cx = in_range ? (int)fx : 0, cy = in_range ? (int)fy : 0, cz = in_range ? (int)fz : 0;
 
     // The 27 cells are visited nearest-first (centre, 6 faces, 12 edges, 8 corners): cell order[sub + 8 r] in
@@ -140,17 +146,20 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
     bound = gate < bound ? gate : bound;
     // ---- rounds 1..3: probe + scan only the cells that can still matter
     const double qdx = (double)qx, qdy = (double)qy, qdz = (double)qz;
+    // squared minimum distance from the query to the box of the cell at offset (dx, dy, dz), shrunk by a 1e-5 margin
+    auto box_dmin2 = [&](const int dx, const int dy, const int dz) -> double {
+        const double ax = dx > 0 ? (double)(cx + dx) * cg.cell - qdx : (dx < 0 ? qdx - (double)(cx + dx + 1) * cg.cell : 0.0);
+        const double ay = dy > 0 ? (double)(cy + dy) * cg.cell - qdy : (dy < 0 ? qdy - (double)(cy + dy + 1) * cg.cell : 0.0);
+        const double az = dz > 0 ? (double)(cz + dz) * cg.cell - qdz : (dz < 0 ? qdz - (double)(cz + dz + 1) * cg.cell : 0.0);
+        const double bx = ax > 0.0 ? ax : 0.0, by = ay > 0.0 ? ay : 0.0, bz = az > 0.0 ? az : 0.0;
+        return ((bx * bx + by * by) + bz * bz) * (1.0 - 1e-5);
+    };
     auto plan = [&](const int r, bool& pv) -> unsigned long long {
         const int k = sub + G * r;
         int dx, dy, dz;
         cell_of(k, dx, dy, dz);
         // minimum distance from the query to the cell's box, per axis (0 when the query's own slab)
-        const double ax = dx > 0 ? (double)(cx + 1) * cg.cell - qdx : (dx < 0 ? qdx - (double)cx * cg.cell : 0.0);
-        const double ay = dy > 0 ? (double)(cy + 1) * cg.cell - qdy : (dy < 0 ? qdy - (double)cy * cg.cell : 0.0);
-        const double az = dz > 0 ? (double)(cz + 1) * cg.cell - qdz : (dz < 0 ? qdz - (double)cz * cg.cell : 0.0);
-        const double bx = ax > 0.0 ? ax : 0.0, by = ay > 0.0 ? ay : 0.0, bz = az > 0.0 ? az : 0.0;
-        const double dmin2 = ((bx * bx + by * by) + bz * bz) * (1.0 - 1e-5);
-        pv = in_range && k < 27 && !(dmin2 > (double)bound);
+        pv = in_range && k < 27 && !(box_dmin2(dx, dy, dz) > (double)bound);
         return pack_key(cx + dx, cy + dy, cz + dz);
     };
     bool pv1, pv2, pv3;
@@ -177,24 +186,65 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
         consider(p3, s3, i3 <= last);
     }
     // merge the 8 private lists: K rounds of group-min + pop; the j-th neighbour lands in lane sub == j
-    const int total = group_sum_i32<G>(ncand);
     unsigned long long mine_key = ~0ull, last_key = ~0ull;
     unsigned mine_slot = 0u;
+    int found = 0;
+    float kth = INFINITY;
+    auto merge = [&]() {
+        const int total = group_sum_i32<G>(ncand);
+        mine_key = ~0ull; last_key = ~0ull; mine_slot = 0u;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const unsigned long long m = group_min_u64<G>(t[0]);
-        const bool owner = (t[0] == m) && (m != ~0ull);
-        const unsigned ms = group8_min_u32(owner ? sl[0] : 0xffffffffu);
-        if (owner) {
+        for (int j = 0; j < K; ++j) {
+            const unsigned long long m = group_min_u64<G>(t[0]);
+            const bool owner = (t[0] == m) && (m != ~0ull);
+            const unsigned ms = group8_min_u32(owner ? sl[0] : 0xffffffffu);
+            if (owner) {
 #pragma unroll
-            for (int u = 0; u + 1 < K; ++u) { t[u] = t[u + 1]; sl[u] = sl[u + 1]; }
-            t[K - 1] = ~0ull;
+                for (int u = 0; u + 1 < K; ++u) { t[u] = t[u + 1]; sl[u] = sl[u + 1]; }
+                t[K - 1] = ~0ull;
+            }
+            if (sub == j) { mine_key = m; mine_slot = ms; }
+            last_key = m;
         }
-        if (sub == j) { mine_key = m; mine_slot = ms; }
-        last_key = m;
+        found = total < K ? total : K;
+        kth = (total >= K && last_key != ~0ull) ? __uint_as_float((unsigned)(last_key >> 32)) : INFINITY;
+    };
+    merge();
+    // ---- stage 2 (half-size cells): the inner 27 cells certify the result only if the K-th neighbour lies within one
+    // cell size; otherwise the 98 shell cells of the 5x5x5 block (which covers the gate) are examined, nearest-first,
+    // each only if its box can hold something closer than the bound (exact K-th so far, or the gate).  The merged
+    // top-K is dealt back one entry per lane, so the second merge sees stage-1 results and shell candidates together.
+    if (cg.rings == 2) {
+        const bool enough = found == K && (double)kth <= cg.cell * cg.cell * (1.0 - 1e-5);
+        if (!enough) {  // uniform within the group
+            float b2 = found == K ? kth : INFINITY;
+            b2 = gate < b2 ? gate : b2;
+#pragma unroll
+            for (int j = 0; j < K; ++j) { t[j] = ~0ull; sl[j] = 0u; }
+            ncand = 0;
+            if (sub < K && mine_key != ~0ull) { t[0] = mine_key; sl[0] = mine_slot; ncand = 1; }
+            for (int r = 0; r < 13; ++r) {
+                const int k = sub + G * r;
+                const int code = kShellOrder[k < 98 ? k : 0];
+                const int dx = code % 5 - 2, dy = (code / 5) % 5 - 2, dz = code / 25 - 2;
+                const bool pv = in_range && k < 98 && !(box_dmin2(dx, dy, dz) > (double)b2);
+                const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
+                unsigned h, bb, cc;
+                const HashEntry e = first_load(pv, key, h);
+                resolve(pv, key, h, e, bb, cc);
+                const unsigned last = bb + cc - 1;  // only dereferenced when cc > 0
+                for (unsigned s = bb; s < bb + cc; s += 4) {
+                    const unsigned s1 = s + 1 < last ? s + 1 : last, s2 = s + 2 < last ? s + 2 : last, s3 = s + 3 < last ? s + 3 : last;
+                    const float4 p0 = cg.g.pts[s], p1 = cg.g.pts[s1], p2 = cg.g.pts[s2], p3 = cg.g.pts[s3];
+                    consider(p0, s, true);
+                    consider(p1, s1, s + 1 <= last);
+                    consider(p2, s2, s + 2 <= last);
+                    consider(p3, s3, s + 3 <= last);
+                }
+            }
+            merge();
+        }
     }
-    int found = total < K ? total : K;
-    float kth = (total >= K && last_key != ~0ull) ? __uint_as_float((unsigned)(last_key >> 32)) : INFINITY;
     // un-gated search (LoamPointToPlaneKdtree): the 27 cells certify the result only if the K-th neighbour lies
     // within one cell size; otherwise lane 0 of the group redoes the query with the serial ring search
     const double rad2 = cg.cell * cg.cell * (1.0 - 1e-5);

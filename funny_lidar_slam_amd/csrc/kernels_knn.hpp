@@ -28,6 +28,7 @@ struct CellGridDev {
     DevGrid g;
     double inv_cell;
     double cell;
+    int rings;  // 1: the gate fits into one cell (27-cell block suffices); 2: half-size cells, 125-cell block in two stages
 };
 
 template <int K>

@@ -14,6 +14,10 @@
 
 namespace fls {
 
+// LOAM feature maps: cells of half the gate radius, 5x5x5 block searched in two stages (kernels_grid_coop.hpp): the inner
+// 27 cells hold 4-8x fewer candidates than 27 gate-sized cells and finish almost every query (-10 % kernel time; the
+// kernel is bound by the 27 hash probes, not by the candidates)
+constexpr int kGridRings = 2;
 inline float cell_for_gate(double gate_sq) {  // smallest safe cell for a squared-distance gate
     return float(std::sqrt(gate_sq) * 1.0001);
 }
@@ -53,6 +57,8 @@ struct IcpMatcher final : fls_matcher {
             for (const auto& c : cloud_deque) local_map.insert(local_map.end(), c.begin(), c.end());
         }
         local_map = voxel_grid(local_map, p.map_cloud_filter_size);  // Q13: always
+        // gate-sized cells here: the ICP scan starts far from the map (1-NN often beyond half the gate in the early
+        // iterations), the two-stage search would run its second stage for most queries (measured 25 vs 13.5 us / launch)
         const fls_status rc = grid.build(local_map, cell_for_gate(p.point_search_thres), stream);
         have_map = rc == FLS_OK;
         return rc;
@@ -197,10 +203,10 @@ struct LoamFullMatcher final : fls_matcher {
         for (const auto& c : corner_deque) local_corner.insert(local_corner.end(), c.begin(), c.end());
         if (planar_deque.size() > 5) local_planar = voxel_grid(local_planar, p.planar_voxel_filter_size);
         if (corner_deque.size() > 5) local_corner = voxel_grid(local_corner, p.corner_voxel_filter_size);
-        const float cs = cell_for_gate(p.point_search_thres);
-        fls_status rc = planar_grid.build(local_planar, cs, stream);
+        const float cs = 0.5f * cell_for_gate(p.point_search_thres);
+        fls_status rc = planar_grid.build(local_planar, cs, stream, kGridRings);
         if (rc != FLS_OK) return rc;
-        rc = corner_grid.build(local_corner, cs, stream);
+        rc = corner_grid.build(local_corner, cs, stream, kGridRings);
         have_map = rc == FLS_OK;
         return rc;
     }

@@ -224,3 +224,12 @@ def test_other_kinds_more_scans_reduced(job):
     run_pair("LoamFull_KdTree", reg.YAML_NCLT_LOAM_FULL, [cfg["map"], cfg["corner_map"]], cfg["scan"], corner=cfg["corner_scan"])
     cfg = synth.make_config(0, job=job)
     run_pair("IcpOptimized", reg.YAML_NCLT_ICP, [cfg["map"]], cfg["scan"], loc=True)
+
+
+def test_loam_sparse_maps_second_search_stage():
+    """LOAM feature maps thinned 12x: the 5th neighbour usually lies beyond half the gate radius, so the grid search
+    has to run its second stage (the 98 shell cells of the 5x5x5 block) -- results still bit-exact."""
+    cfg = synth.make_config(3, scale=0.1)
+    m, o, T, T_ref = run_pair("LoamFull_KdTree", reg.YAML_NCLT_LOAM_FULL, [cfg["map"][::12].copy(), cfg["corner_map"][::6].copy()], cfg["scan"],
+                              corner=cfg["corner_scan"])
+    assert m.stats.n_valid > 50
