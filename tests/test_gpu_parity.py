@@ -233,3 +233,34 @@ def test_loam_sparse_maps_second_search_stage():
     m, o, T, T_ref = run_pair("LoamFull_KdTree", reg.YAML_NCLT_LOAM_FULL, [cfg["map"][::12].copy(), cfg["corner_map"][::6].copy()], cfg["scan"],
                               corner=cfg["corner_scan"])
     assert m.stats.n_valid > 50
+
+
+@pytest.mark.parametrize("mode,y,cid,loc", [("PointToPlane_IVOX", reg.YAML_NCLT_IVOX, 1, False), ("IcpOptimized", reg.YAML_NCLT_ICP, 0, True),
+                                            ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, False), ("LoamFull_KdTree", reg.YAML_NCLT_LOAM_FULL, 3, False)])
+def test_empty_and_tiny_inputs(mode, y, cid, loc):
+    """Edge cases at the boundary: an empty source cloud, a source with fewer points than any gate needs, a scan that sees
+    nothing of the map (every query without candidates) -- same return value / iteration count / pose as the oracle."""
+    cfg = synth.make_config(cid, scale=0.03 if cid else 1.0)
+    maps = [cfg["map"]] + ([cfg["corner_map"]] if "corner_map" in cfg else [])
+    empty = np.zeros((0, 3), np.float32)
+    far = (cfg["scan"][:200] + np.float32(5000.0)).astype(np.float32)  # 5 km away from every map point
+    for scan, corner in ((empty, empty), (cfg["scan"][:7].copy(), cfg.get("corner_scan", empty)[:3].copy()), (far, far[:20].copy())):
+        m = reg.make_matcher(mode, y, is_localization_mode=loc)
+        o = util.oracle_for(mode, y, loc)
+        m.AddCloudToLocalMap(maps)
+        o.AddCloudToLocalMap(*maps)
+        T = np.eye(4)
+        cr = corner if mode == "LoamFull_KdTree" else None
+        if mode == "IcpOptimized" and scan.shape[0] <= 10:
+            # CHECK_GT(ordered_cloud_.size(), 10u) aborts the reference process (icp_optimized.h:55): an error status here
+            with pytest.raises(_lib.FlsError):
+                m.Match(util.cluster_for(mode, scan, cr), T, update_map=False)
+            m.close()
+            continue
+        ok = m.Match(util.cluster_for(mode, scan, cr), T, update_map=False)
+        ok_ref, T_ref = o.Match(scan, np.eye(4), src1=cr, update_map=False)
+        assert ok == ok_ref, (mode, scan.shape)
+        assert m.stats.iterations == o.stats.iterations and m.stats.n_valid == o.stats.n_valid, (mode, scan.shape, m.stats.iterations, o.stats.iterations)
+        dt, dr = synth.pose_error(T, T_ref)
+        assert (dt < 1e-4 and dr < 1e-4) or (not np.all(np.isfinite(T)) and not np.all(np.isfinite(T_ref))), (mode, scan.shape, dt, dr)
+        m.close()
