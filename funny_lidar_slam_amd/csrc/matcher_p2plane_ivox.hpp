@@ -13,6 +13,7 @@
 #include "kernels_ivox_coop.hpp"
 #include "fitness_host.hpp"
 #include <thread>
+#include <chrono>
 #include <hip/hip_ext.h>
 
 namespace fls {
@@ -34,6 +35,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     DevBuf<unsigned> d_ticket;
     bool use_dense = true; // dense voxel window instead of the hash table when the map extent allows (FLS_IVOX_DENSE=0 disables)
     int xcd_chunk = 8;     // workgroups per XCD chunk of the kNN block re-map (FLS_IVOX_XCD_CHUNK)
+    bool host_timing = false;  // FLS_HOST_TIMING=1: print the host-side cost of every map update
     bool balanced = true;  // equal candidate ranges per lane through an LDS voxel table (FLS_IVOX_BALANCED=0: whole voxels per lane)
     int variant = 4;       // lanes cooperating on one query in ivox_knn_kernel: 4 or 8 (FLS_IVOX_VARIANT)
     bool is_first = true;  // the reference's function-static flag (:62), per handle here
@@ -62,6 +64,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (const char* e = std::getenv("FLS_IVOX_VARIANT")) { const int v = std::atoi(e); if (v == 4 || v == 8) variant = v; }
         if (const char* e = std::getenv("FLS_IVOX_DENSE")) use_dense = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_BALANCED")) balanced = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_HOST_TIMING")) host_timing = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_XCD_CHUNK")) { const int c = std::atoi(e); if (c >= 1 && c <= 4096) xcd_chunk = c; }
         d_ticket.reserve(1);
         FLS_HIP(hipMemsetAsync(d_ticket.p, 0, sizeof(unsigned), stream));
@@ -141,6 +144,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             // per source point; the host only walks the codes to build the two insertion lists in index order.
             std::vector<PtI> to_add, no_downsample;
             const size_t n = std::min(number_planar_point, scan.n);
+            const auto tm0 = std::chrono::steady_clock::now();
             if (n) {
                 d_code.reserve(n);
                 d_pw.reserve(n);
@@ -161,10 +165,17 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
                     (h_code[i] == 1 ? to_add : no_downsample).push_back(pw);
                 }
             }
+            const auto tm1 = std::chrono::steady_clock::now();
             rc = ivox.add_points(to_add.data(), to_add.size());
             if (rc != FLS_OK) return rc;
             rc = ivox.add_points(no_downsample.data(), no_downsample.size());
             if (rc != FLS_OK) return rc;
+            if (host_timing) {
+                const auto tm2 = std::chrono::steady_clock::now();
+                std::fprintf(stderr, "[fls host] decide+lists %.3f ms (%zu + %zu pts), AddPoints %.3f ms\n",
+                             std::chrono::duration<double, std::milli>(tm1 - tm0).count(), to_add.size(), no_downsample.size(),
+                             std::chrono::duration<double, std::milli>(tm2 - tm1).count());
+            }
         } else {
             // external non-first call with an arbitrary cloud: same rule on the host (:79-131)
             download_nn();
@@ -203,7 +214,14 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             if (rc != FLS_OK) return rc;
         }
         image_dirty = true;
-        refresh_image();
+        {
+            const auto tr0 = std::chrono::steady_clock::now();
+            refresh_image();
+            if (host_timing)
+                std::fprintf(stderr, "[fls host] refresh_image %.3f ms (%zu pt updates, %zu cell updates)\n",
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(), image.pt_upd.size(),
+                             image.cell_upd.size());
+        }
         if (p.is_localization_mode) {  // :134-138 kd-tree for GetFitnessScore
             rc = fitness_grid.build(planar_cloud, 1.0f, stream);
             have_fitness_grid = (rc == FLS_OK);
