@@ -100,3 +100,32 @@ def test_reference_class_mirror_and_voxel_filters():
         features.FeatureExtractor(1.0, 0.1, 1800, 64).ExtractFeatures(reg.PointcloudCluster(raw_cloud_=raw))
     with pytest.raises(_lib.FlsError):
         features.FeatureFrontEnd(1800, 64, VELO64["horizontal_resolution"], 4.0, 100.0, float(np.finfo(np.float32).max), 0.1)  # CHECK_NE(corner_threshold_, FloatNaN)
+
+
+def test_front_end_feeds_loam_full_match():
+    """Raw driver cloud -> GPU feature front-end -> GPU LoamFull::Match, against oracle front-end -> oracle LoamFull:
+    the two pipelines see bit-identical feature clouds, hence the usual registration parity."""
+    from tests import util
+    scene = synth.make_scene()
+    cfg = synth.make_config(3, scale=0.25)
+    T_gt = synth.random_pose(synth.rng_for(3, 31), 1.5, 0.25)
+    raw = synth.cast_raw_scan(scene, T_gt, rng=synth.rng_for(3, 0, 31), max_range=cfg["radius"], **synth.VELODYNE_64)
+    g = features.FeatureFrontEnd(1800, 64, VELO64["horizontal_resolution"], 4.0, 100.0, 1.0, 0.1)
+    g.project(raw)
+    g.extract()
+    o = O.OracleFeatures(**VELO64)
+    o.Project(raw)
+    o.ExtractFeatures()
+    corner, planar = g.get("corner")[:, :3].copy(), g.get("planar")[::2, :3].copy()
+    assert np.array_equal(corner, o.get("corner")[:, :3]) and np.array_equal(planar, o.get("planar")[::2, :3])
+    y = reg.YAML_NCLT_LOAM_FULL
+    m = reg.make_matcher("LoamFull_KdTree", y)
+    r = util.oracle_for("LoamFull_KdTree", y, False)
+    m.AddCloudToLocalMap([cfg["map"], cfg["corner_map"]])
+    r.AddCloudToLocalMap(cfg["map"], cfg["corner_map"])
+    T = np.eye(4)
+    ok = m.Match(reg.PointcloudCluster(planar_cloud_=planar, corner_cloud_=corner), T, update_map=False)
+    ok_ref, T_ref = r.Match(planar, np.eye(4), src1=corner, update_map=False)
+    util.assert_same_registration(m, r, ok, T, ok_ref, T_ref, slots=(0, 1), max_tie_rows=int(r.counters().tie_queries))
+    dt, dr = synth.pose_error(T, T_gt)
+    assert ok and dt < 0.1 and dr < 0.01  # the extracted features really register the frame
