@@ -209,7 +209,8 @@ feat_select_kernel(const int* __restrict__ n_ordered, const FeatParamsDev p, con
     // +-5 suppression around a local position (the column-gap rule, :167-186 / :194-212).  Executed by the whole of
     // wave 0 with uniform arguments: every lane stores the same zeros to the same LDS bytes.
     // (all eleven columns are fetched at once: the walk is a chain of dependent LDS round trips otherwise)
-    auto suppress = [&](const int q) {
+    // Returns the cleared range [lo, hi] so that a caller holding prefetched flags can patch them.
+    auto suppress = [&](const int q, int& lo, int& hi) {
         int c[11];
 #pragma unroll
         for (int k = 0; k < 11; ++k) c[k] = (int)sm.col[q - 5 + k];  // q - 5 >= 0 and q + 5 < count for every walked position
@@ -223,6 +224,8 @@ feat_select_kernel(const int* __restrict__ n_ordered, const FeatParamsDev p, con
 #pragma unroll
         for (int k = -5; k <= 5; ++k)
             if (k >= -nb && k <= nf) sm.valid[q + k] = 0;
+        lo = q - nb;
+        hi = q + nf;
     };
     for (int s = 0; s < 6; ++s) {
         const int b0 = 5 + s * t, b1 = 5 + (s + 1) * t;  // local positions of block_start_index / block_end_index
@@ -256,9 +259,9 @@ feat_select_kernel(const int* __restrict__ n_ordered, const FeatParamsDev p, con
             int large = 0;
             bool stop = false;
             for (int c0 = len; c0 >= 0 && !stop; c0 -= 64) {  // chunk = walk elements c0, c0-1, ..., c0-63
-                float rv = 0.f; int qv = 0;
-                const int e_l = c0 - lane;
-                if (e_l >= 0) elem(e_l, rv, qv);
+                float rv = 0.f; int qv = 0, vv = 0;  // vv: this lane's element's valid flag, fetched once per chunk and
+                const int e_l = c0 - lane;            // patched after every suppression inside the chunk
+                if (e_l >= 0) { elem(e_l, rv, qv); vv = sm.valid[qv]; }
                 const int cnt = c0 + 1 < 64 ? c0 + 1 : 64;
                 for (int u = 0; u < cnt; ++u) {
                     const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), u));
@@ -268,13 +271,15 @@ feat_select_kernel(const int* __restrict__ n_ordered, const FeatParamsDev p, con
                         stop = true;
                         break;
                     }
-                    if (sm.valid[q]) {
+                    if (__builtin_amdgcn_readlane(vv, u)) {
                         ++large;
                         if (large > 20) { stop = true; break; }
                         sm.corner[q] = 1;
                         if (lane == 0) crow[nc] = base + q;
                         ++nc;
-                        suppress(q);
+                        int lo, hi;
+                        suppress(q, lo, hi);
+                        if (qv >= lo && qv <= hi) vv = 0;
                     }
                 }
             }
@@ -282,18 +287,22 @@ feat_select_kernel(const int* __restrict__ n_ordered, const FeatParamsDev p, con
             // possibly the boundary element), the emission of every non-corner element is order-preserving compaction
             bool prefix = true;
             for (int c0 = 0; c0 <= len; c0 += 64) {
-                float rv = 0.f; int qv = 0;
+                float rv = 0.f; int qv = 0, vv = 0;
                 const int e_l = c0 + lane;
                 const bool have = e_l <= len;
-                if (have) elem(e_l, rv, qv);
+                if (have) { elem(e_l, rv, qv); vv = sm.valid[qv]; }
                 const int cnt = len + 1 - c0 < 64 ? len + 1 - c0 : 64;
                 for (int u = 0; u < cnt; ++u) {
                     const int e = c0 + u;
                     if (!prefix && e < len) continue;  // past the prefix only the boundary element (e == len) is still looked at
                     const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), u));
-                    const int q = __builtin_amdgcn_readlane(qv, u);
-                    if (r < p.planar_thr) { if (sm.valid[q]) suppress(q); }
-                    else if (e < len) prefix = false;
+                    if (r < p.planar_thr) {
+                        if (__builtin_amdgcn_readlane(vv, u)) {
+                            int lo, hi;
+                            suppress(__builtin_amdgcn_readlane(qv, u), lo, hi);
+                            if (qv >= lo && qv <= hi) vv = 0;
+                        }
+                    } else if (e < len) prefix = false;
                 }
                 const bool emit = have && !sm.corner[qv];
                 const unsigned long long m = __ballot(emit);
