@@ -208,22 +208,23 @@ feat_select_kernel(const int* __restrict__ n_ordered, const FeatParamsDev p, con
     const int t = (row_end[row] - row_start[row]) / 6;  // :124-125, truncating division
     // +-5 suppression around a local position (the column-gap rule, :167-186 / :194-212).  Executed by the whole of
     // wave 0 with uniform arguments: every lane stores the same zeros to the same LDS bytes.
-    // (all eleven columns are fetched at once: the walk is a chain of dependent LDS round trips otherwise)
+    // Lane-parallel: lanes 0..10 hold the columns of q-5..q+5 (one LDS read), the ten column gaps become a ballot mask,
+    // the two break positions are bit scans of it, and the zeros go out as one predicated store (the scalar form of
+    // the same rule cost about 1,500 cycles per call in dependent LDS round trips and branches).
     // Returns the cleared range [lo, hi] so that a caller holding prefetched flags can patch them.
     auto suppress = [&](const int q, int& lo, int& hi) {
-        int c[11];
-#pragma unroll
-        for (int k = 0; k < 11; ++k) c[k] = (int)sm.col[q - 5 + k];  // q - 5 >= 0 and q + 5 < count for every walked position
-        int nf = 0, nb = 0;
-        bool go = true;
-#pragma unroll
-        for (int k = 1; k <= 5; ++k) { go = go && !(abs(c[5 + k] - c[4 + k]) > 10); nf += go ? 1 : 0; }
-        go = true;
-#pragma unroll
-        for (int k = 1; k <= 5; ++k) { go = go && !(abs(c[5 - k] - c[6 - k]) > 10); nb += go ? 1 : 0; }
-#pragma unroll
-        for (int k = -5; k <= 5; ++k)
-            if (k >= -nb && k <= nf) sm.valid[q + k] = 0;
+        const int l = lane < 11 ? lane : 10;                                         // q - 5 >= 0 and q + 5 < count for every walked position
+        const int c = (int)sm.col[q - 5 + l];
+        const int cprev = __builtin_amdgcn_update_dpp(0, c, 0x111, 0xf, 0xf, false);  // row_shr:1: the column of position q - 6 + l
+        const bool gap = lane >= 1 && lane < 11 && abs(c - cprev) > 10;              // bit l: gap between positions q-6+l and q-5+l
+        const unsigned gm = (unsigned)__ballot(gap);
+        const unsigned fwd = gm >> 6;      // bit k-1: gap between q+k-1 and q+k, k = 1..5
+        const unsigned bwd = gm & 0x3Eu;   // bit 6-k: gap between q-k and q-k+1, k = 1..5
+        int nf = fwd ? __builtin_ctz(fwd) : 5;
+        nf = nf < 5 ? nf : 5;
+        const int nb = bwd ? 5 - (31 - __builtin_clz(bwd)) : 5;
+        const int k = lane - 5;
+        if (lane < 11 && k >= -nb && k <= nf) sm.valid[q + k] = 0;
         lo = q - nb;
         hi = q + nf;
     };
@@ -255,59 +256,55 @@ feat_select_kernel(const int* __restrict__ n_ordered, const FeatParamsDev p, con
                 if (e < len) { const unsigned long long k = sm.key[e]; r = __uint_as_float((unsigned)(k >> 32)); q = (int)(unsigned)(k & 0xffffffffull); }
                 else { r = sm.rough[b1]; q = b1; }
             };
-            // corner loop: from the largest roughness down; nothing can happen once roughness <= corner_thr
+            // corner loop: from the largest roughness down.  A chunk of 64 walk elements sits one per lane; the ballot of
+            // "roughness above the threshold and still valid" is the work list, visited in order by bit scan, and every
+            // suppression patches the prefetched flags of the lanes it hits before the list is re-read: the sequential
+            // rule exactly, at the price of one loop trip per ACCEPTED point instead of one per element.
             int large = 0;
             bool stop = false;
             for (int c0 = len; c0 >= 0 && !stop; c0 -= 64) {  // chunk = walk elements c0, c0-1, ..., c0-63
-                float rv = 0.f; int qv = 0, vv = 0;  // vv: this lane's element's valid flag, fetched once per chunk and
-                const int e_l = c0 - lane;            // patched after every suppression inside the chunk
-                if (e_l >= 0) { elem(e_l, rv, qv); vv = sm.valid[qv]; }
-                const int cnt = c0 + 1 < 64 ? c0 + 1 : 64;
-                for (int u = 0; u < cnt; ++u) {
-                    const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), u));
+                float rv = 0.f; int qv = 0, vv = 0;
+                const int e_l = c0 - lane;
+                const bool have = e_l >= 0;
+                if (have) { elem(e_l, rv, qv); vv = sm.valid[qv]; }
+                const bool cand = have && rv > p.corner_thr;
+                unsigned long long m = __ballot(cand && vv);
+                while (m) {
+                    const int u = __builtin_ctzll(m);
+                    ++large;
+                    if (large > 20) { stop = true; break; }
                     const int q = __builtin_amdgcn_readlane(qv, u);
-                    if (!(r > p.corner_thr)) {
-                        if (c0 - u == len) continue;  // the boundary element is not part of the sorted order
-                        stop = true;
-                        break;
-                    }
-                    if (__builtin_amdgcn_readlane(vv, u)) {
-                        ++large;
-                        if (large > 20) { stop = true; break; }
-                        sm.corner[q] = 1;
-                        if (lane == 0) crow[nc] = base + q;
-                        ++nc;
-                        int lo, hi;
-                        suppress(q, lo, hi);
-                        if (qv >= lo && qv <= hi) vv = 0;
-                    }
+                    sm.corner[q] = 1;
+                    if (lane == 0) crow[nc] = base + q;
+                    ++nc;
+                    int lo, hi;
+                    suppress(q, lo, hi);
+                    if (qv >= lo && qv <= hi) vv = 0;
+                    m = __ballot(cand && vv) & (u == 63 ? 0ull : (~0ull << (u + 1)));
                 }
+                // a sorted element at or below the threshold ends the search (the boundary element e == len is not sorted)
+                if (__ballot(have && !cand && e_l != len)) stop = true;
             }
-            // planar loop: ascending; suppression can only happen while roughness < planar_thr (a sorted prefix, plus
-            // possibly the boundary element), the emission of every non-corner element is order-preserving compaction
-            bool prefix = true;
+            // planar loop: ascending; same scheme with "roughness below planar_thr and still valid" as the work list;
+            // the emission of every non-corner element is order-preserving ballot compaction
             for (int c0 = 0; c0 <= len; c0 += 64) {
                 float rv = 0.f; int qv = 0, vv = 0;
                 const int e_l = c0 + lane;
                 const bool have = e_l <= len;
                 if (have) { elem(e_l, rv, qv); vv = sm.valid[qv]; }
-                const int cnt = len + 1 - c0 < 64 ? len + 1 - c0 : 64;
-                for (int u = 0; u < cnt; ++u) {
-                    const int e = c0 + u;
-                    if (!prefix && e < len) continue;  // past the prefix only the boundary element (e == len) is still looked at
-                    const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), u));
-                    if (r < p.planar_thr) {
-                        if (__builtin_amdgcn_readlane(vv, u)) {
-                            int lo, hi;
-                            suppress(__builtin_amdgcn_readlane(qv, u), lo, hi);
-                            if (qv >= lo && qv <= hi) vv = 0;
-                        }
-                    } else if (e < len) prefix = false;
+                const bool cand = have && rv < p.planar_thr;
+                unsigned long long m = __ballot(cand && vv);
+                while (m) {
+                    const int u = __builtin_ctzll(m);
+                    int lo, hi;
+                    suppress(__builtin_amdgcn_readlane(qv, u), lo, hi);
+                    if (qv >= lo && qv <= hi) vv = 0;
+                    m = __ballot(cand && vv) & (u == 63 ? 0ull : (~0ull << (u + 1)));
                 }
                 const bool emit = have && !sm.corner[qv];
-                const unsigned long long m = __ballot(emit);
-                if (emit) prow[np + __popcll(m & ((1ull << lane) - 1ull))] = base + qv;
-                np += __popcll(m);
+                const unsigned long long me = __ballot(emit);
+                if (emit) prow[np + __popcll(me & ((1ull << lane) - 1ull))] = base + qv;
+                np += __popcll(me);
             }
         }
         __syncthreads();
