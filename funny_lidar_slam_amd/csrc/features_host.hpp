@@ -18,7 +18,9 @@ struct fls_features {
     bool projected = false, extracted = false;
     double project_ms = 0.0, extract_ms = 0.0;
 
-    fls::DevBuf<unsigned char> d_raw, d_valid, d_is_corner;
+    fls::DevBuf<unsigned char> d_raw, d_valid, d_valid_pre, d_is_corner;
+    // introspection arrays (raw_index, roughness, the three flag arrays) come down only when somebody asks for them
+    bool have_raw_index = false, have_intro = false;
     fls::DevBuf<unsigned> d_owner;
     fls::DevBuf<int> d_row_count, d_row_start, d_row_end, d_n, d_col, d_raw_index, d_corner_idx, d_corner_cnt, d_planar_idx, d_planar_cnt;
     fls::DevBuf<float4> d_ordered;
@@ -56,7 +58,7 @@ struct fls_features {
         d_row_count.reserve(size_t(pd.rows)); d_row_start.reserve(size_t(pd.rows)); d_row_end.reserve(size_t(pd.rows));
         d_n.reserve(1);
         d_ordered.reserve(cells); d_depth.reserve(cells); d_rough.reserve(cells); d_col.reserve(cells); d_raw_index.reserve(cells);
-        d_valid.reserve(cells); d_is_corner.reserve(cells);
+        d_valid.reserve(cells); d_valid_pre.reserve(cells); d_is_corner.reserve(cells);
         d_corner_idx.reserve(size_t(pd.rows) * 120); d_corner_cnt.reserve(size_t(pd.rows));
         d_planar_idx.reserve(size_t(pd.rows) * size_t(pd.cols + 6)); d_planar_cnt.reserve(size_t(pd.rows));
         return FLS_OK;
@@ -89,12 +91,12 @@ struct fls_features {
         FLS_HIP(hipMemcpyAsync(row_end.data(), d_row_end.p, size_t(pd.rows) * sizeof(int), hipMemcpyDeviceToHost, stream));
         FLS_HIP(hipStreamSynchronize(stream));
         const size_t m = size_t(N);
-        ordered.resize(m); depth.resize(m); col.resize(m); raw_index.resize(m);
+        ordered.resize(m); depth.resize(m); col.resize(m);
+        have_raw_index = have_intro = false;
         if (m) {
             FLS_HIP(hipMemcpyAsync(ordered.data(), d_ordered.p, m * sizeof(float4), hipMemcpyDeviceToHost, stream));
             FLS_HIP(hipMemcpyAsync(depth.data(), d_depth.p, m * sizeof(float), hipMemcpyDeviceToHost, stream));
             FLS_HIP(hipMemcpyAsync(col.data(), d_col.p, m * sizeof(int), hipMemcpyDeviceToHost, stream));
-            FLS_HIP(hipMemcpyAsync(raw_index.data(), d_raw_index.p, m * sizeof(int), hipMemcpyDeviceToHost, stream));
             FLS_HIP(hipStreamSynchronize(stream));
         }
         float ms = 0.f;
@@ -108,7 +110,7 @@ struct fls_features {
     fls_status extract(size_t* n_corner, size_t* n_planar) {
         if (!projected) return FLS_ERR_STATE;
         const size_t m = size_t(N);
-        rough.assign(m, 0.f); valid_pre.assign(m, 1); valid_post.assign(m, 1); is_corner.assign(m, 0);
+        have_intro = false;
         corner_idx.clear(); planar_idx.clear(); corner.clear(); planar.clear(); corner_f.clear(); planar_f.clear();
         if (N >= 12) {
             const size_t rows = size_t(pd.rows);
@@ -116,14 +118,11 @@ struct fls_features {
             FLS_HIP(hipEventRecord(ev[2], stream));
             hipLaunchKernelGGL(fls::feat_valid_rough_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, stream, d_n.p, d_depth.p, d_col.p, d_rough.p,
                                d_valid.p);
-            FLS_HIP(hipMemcpyAsync(valid_pre.data(), d_valid.p, m, hipMemcpyDeviceToHost, stream));
+            FLS_HIP(hipMemcpyAsync(d_valid_pre.p, d_valid.p, m, hipMemcpyDeviceToDevice, stream));  // snapshot before SelectFeatures edits the flags
             hipLaunchKernelGGL(fls::feat_select_kernel, dim3(unsigned(pd.rows)), dim3(fls::kFeatSelectThreads), 0, stream, d_n.p, pd, d_row_start.p, d_row_end.p, d_rough.p,
                                d_col.p, d_valid.p, d_is_corner.p, d_corner_idx.p, d_corner_cnt.p, d_planar_idx.p, d_planar_cnt.p);
             FLS_HIP(hipGetLastError());
             FLS_HIP(hipEventRecord(ev[3], stream));
-            FLS_HIP(hipMemcpyAsync(rough.data(), d_rough.p, m * sizeof(float), hipMemcpyDeviceToHost, stream));
-            FLS_HIP(hipMemcpyAsync(valid_post.data(), d_valid.p, m, hipMemcpyDeviceToHost, stream));
-            FLS_HIP(hipMemcpyAsync(is_corner.data(), d_is_corner.p, m, hipMemcpyDeviceToHost, stream));
             FLS_HIP(hipMemcpyAsync(h_ccnt.data(), d_corner_cnt.p, rows * sizeof(int), hipMemcpyDeviceToHost, stream));
             FLS_HIP(hipMemcpyAsync(h_pcnt.data(), d_planar_cnt.p, rows * sizeof(int), hipMemcpyDeviceToHost, stream));
             FLS_HIP(hipMemcpyAsync(h_cidx.data(), d_corner_idx.p, h_cidx.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -152,12 +151,39 @@ struct fls_features {
         return FLS_OK;
     }
 
+    void fetch_raw_index() {
+        if (have_raw_index) return;
+        const size_t m = size_t(N);
+        raw_index.resize(m);
+        if (m && projected) {
+            FLS_HIP(hipSetDevice(device));
+            FLS_HIP(hipMemcpyAsync(raw_index.data(), d_raw_index.p, m * sizeof(int), hipMemcpyDeviceToHost, stream));
+            FLS_HIP(hipStreamSynchronize(stream));
+        }
+        have_raw_index = true;
+    }
+    void fetch_intro() {
+        if (have_intro) return;
+        const size_t m = size_t(N);
+        rough.assign(m, 0.f); valid_pre.assign(m, 1); valid_post.assign(m, 1); is_corner.assign(m, 0);
+        if (m && extracted && N >= 12) {
+            FLS_HIP(hipSetDevice(device));
+            FLS_HIP(hipMemcpyAsync(rough.data(), d_rough.p, m * sizeof(float), hipMemcpyDeviceToHost, stream));
+            FLS_HIP(hipMemcpyAsync(valid_pre.data(), d_valid_pre.p, m, hipMemcpyDeviceToHost, stream));
+            FLS_HIP(hipMemcpyAsync(valid_post.data(), d_valid.p, m, hipMemcpyDeviceToHost, stream));
+            FLS_HIP(hipMemcpyAsync(is_corner.data(), d_is_corner.p, m, hipMemcpyDeviceToHost, stream));
+            FLS_HIP(hipStreamSynchronize(stream));
+        }
+        have_intro = true;
+    }
     template <class T>
     static size_t copy_out(const std::vector<T>& v, void* out, size_t cap) {
         if (out && !v.empty()) std::memcpy(out, v.data(), std::min(cap, v.size()) * sizeof(T));
         return v.size();
     }
-    size_t get(int what, void* out, size_t cap) const {
+    size_t get(int what, void* out, size_t cap) {
+        if (what == FLS_FEAT_RAW_INDEX) fetch_raw_index();
+        if (what == FLS_FEAT_IS_CORNER || what == FLS_FEAT_ROUGHNESS || what == FLS_FEAT_VALID_PRE || what == FLS_FEAT_VALID_POST) fetch_intro();
         switch (what) {
             case FLS_FEAT_ORDERED: return copy_out(ordered, out, cap);
             case FLS_FEAT_DEPTH: return copy_out(depth, out, cap);

@@ -256,7 +256,12 @@ fls_status fls_features_extract(fls_features_handle h, size_t* n_corner, size_t*
     });
 }
 
-size_t fls_features_get(fls_features_handle h, int what, void* out, size_t cap_elems) { return h ? h->get(what, out, cap_elems) : 0; }
+size_t fls_features_get(fls_features_handle h, int what, void* out, size_t cap_elems) {
+    if (!h) return 0;
+    size_t n = 0;
+    (void)guarded([&]() -> fls_status { n = h->get(what, out, cap_elems); return FLS_OK; });  // may read an introspection array back
+    return n;
+}
 
 fls_status fls_features_get_time(fls_features_handle h, double* project_ms, double* extract_ms) {
     if (!h) return FLS_ERR_INVALID;
