@@ -22,8 +22,22 @@ struct Mat4d {  // Eigen::Matrix4d: 16 doubles, column-major
     double* data() { return m; }
     const double* data() const { return m; }
 };
-struct PointcloudCluster {
+struct alignas(16) PointXYZIRT {  // include/lidar/lidar_point_type.h VelodynePointXYZIRT: 32 bytes
+    float x, y, z, pad0;
+    float intensity;
+    unsigned short ring;
+    float time;
+};
+static_assert(sizeof(PointXYZIRT) == 32, "VelodynePointXYZIRT layout");
+struct PCLPointCloudXYZIRT {
+    std::vector<PointXYZIRT> points;
+    std::size_t size() const { return points.size(); }
+};
+struct PointcloudCluster {  // include/lidar/pointcloud_cluster.h:13-85 (the members the registration path and the LOAM front-end touch)
+    PCLPointCloudXYZIRT raw_cloud_;
     PCLPointCloudXYZI ordered_cloud_, corner_cloud_, planar_cloud_;
+    std::vector<float> point_depth_vec_;
+    std::vector<int> point_col_index_vec_, row_start_index_vec_, row_end_index_vec_;
 };
 typedef std::shared_ptr<PointcloudCluster> PointcloudClusterPtr;
 
