@@ -477,16 +477,47 @@ struct CellGridImage : GridImage {
         for (size_t a = 0; a < n; ++a) if (a == 0 || kv[a].first != kv[a - 1].first) ++cells;
         n_cells = cells;
         begin_build(cells, n);
+        // dense cell window {begin, count} over the bounding box of the occupied cells (one aligned 8-byte load per
+        // probe instead of a hash probe sequence; neighbouring cells share cache lines), when the box is small enough
+        int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+        for (size_t a = 0; a < n; ++a) {
+            if (a && kv[a].first == kv[a - 1].first) continue;
+            int x, y, z;
+            unpack_key(kv[a].first, x, y, z);
+            mn[0] = std::min(mn[0], x); mx[0] = std::max(mx[0], x);
+            mn[1] = std::min(mn[1], y); mx[1] = std::max(mx[1], y);
+            mn[2] = std::min(mn[2], z); mx[2] = std::max(mx[2], z);
+        }
+        have_window = false;
+        this->cells.clear();
+        if (n) {
+            size_t nc = 1;
+            for (int a = 0; a < 3; ++a) { win_o[a] = mn[a]; win_n[a] = mx[a] - mn[a] + 1; nc *= size_t(win_n[a]); }
+            have_window = nc <= kMaxWindowCells;
+            if (have_window) this->cells.assign(nc, make_uint2(0u, 0u));
+        }
         std::vector<Pt4> bucket;
         for (size_t a = 0; a < n;) {
             size_t b = a + 1;
             while (b < n && kv[b].first == kv[a].first) ++b;
             bucket.clear();
             for (size_t k = a; k < b; ++k) { const PtI& p = cloud[kv[k].second]; bucket.push_back(Pt4{p.x, p.y, p.z, int(kv[k].second)}); }
+            if (have_window) {
+                int x, y, z;
+                unpack_key(kv[a].first, x, y, z);
+                size_t idx;
+                if (cell_index(x, y, z, idx)) this->cells[idx] = make_uint2(unsigned(pts.size()), unsigned(bucket.size()));
+            }
             insert_bucket(kv[a].first, bucket.data(), bucket.size());
             a = b;
         }
         upload(s);
+        if (have_window) {
+            d_cells.reserve(this->cells.size());
+            FLS_HIP(hipMemcpyAsync(d_cells.p, this->cells.data(), this->cells.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
+            FLS_HIP(hipStreamSynchronize(s));
+            std::vector<uint2>().swap(this->cells);  // the host copy is not needed again (the grid is rebuilt, never patched)
+        }
         return FLS_OK;
     }
 };

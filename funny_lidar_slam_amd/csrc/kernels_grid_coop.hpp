@@ -61,8 +61,10 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
                 float4* __restrict__ nn_pts /* [n][K] */, unsigned char* __restrict__ nn_cnt, float* __restrict__ kth_d2,
                 unsigned char* __restrict__ flag_to_clear /* may be null */) {
     constexpr int G = 8, QPB = 256 / G;  // 27 cells over 8 lanes: 4 rounds
-    const int nb = (n + QPB - 1) / QPB, per = gridDim.x >> 3;
-    const int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order (grid is a multiple of 8)
+    // XCD-aware order: interleaved chunks of 8 workgroups per XCD (kernels_ivox_coop.hpp; the grid is a multiple of 64).
+    // One contiguous eighth per XCD left the XCD that owns the sparse upper rings with all the second-stage searches.
+    const int nb = (n + QPB - 1) / QPB;
+    const int lb = (((blockIdx.x >> 3) >> 3) * 8 + (blockIdx.x & 7)) * 8 + ((blockIdx.x >> 3) & 7);
     const int sub = threadIdx.x % G;
     const int q = lb * QPB + threadIdx.x / G;
     const bool active = lb < nb && q < n;
@@ -109,6 +111,21 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
         b = hit ? ek.begin : 0u;
         c = hit ? ek.count : 0u;
     };
+    // cell (cx + dx, cy + dy, cz + dz) -> its point range; count = 0 when empty / not wanted
+    auto lookup = [&](const bool pv, const int dx, const int dy, const int dz, unsigned& b, unsigned& c) {
+        if (cg.win.cells) {  // uniform
+            const int wx = cx + dx - cg.win.ox, wy = cy + dy - cg.win.oy, wz = cz + dz - cg.win.oz;
+            const bool ok = pv && (unsigned)wx < (unsigned)cg.win.nx && (unsigned)wy < (unsigned)cg.win.ny && (unsigned)wz < (unsigned)cg.win.nz;
+            const uint2 e = cg.win.cells[ok ? (unsigned)((wz * cg.win.ny + wy) * cg.win.nx + wx) : 0u];
+            b = e.x;
+            c = ok ? e.y : 0u;
+        } else {
+            const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
+            unsigned h;
+            const HashEntry e0 = first_load(pv, key, h);
+            resolve(pv, key, h, e0, b, c);
+        }
+    };
     unsigned long long t[K];
     unsigned sl[K];
 #pragma unroll
@@ -126,10 +143,8 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
     {
         int dx, dy, dz;
         cell_of(sub, dx, dy, dz);
-        const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
-        unsigned h, b0, c0;
-        const HashEntry e0 = first_load(in_range, key, h);
-        resolve(in_range, key, h, e0, b0, c0);
+        unsigned b0, c0;
+        lookup(in_range, dx, dy, dz, b0, c0);
         const unsigned last = b0 + c0 - 1;  // only dereferenced when c0 > 0
         for (unsigned s = b0; s < b0 + c0; s += 4) {
             const unsigned s1 = s + 1 < last ? s + 1 : last, s2 = s + 2 < last ? s + 2 : last, s3 = s + 3 < last ? s + 3 : last;
@@ -154,22 +169,17 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
         const double bx = ax > 0.0 ? ax : 0.0, by = ay > 0.0 ? ay : 0.0, bz = az > 0.0 ? az : 0.0;
         return ((bx * bx + by * by) + bz * bz) * (1.0 - 1e-5);
     };
-    auto plan = [&](const int r, bool& pv) -> unsigned long long {
+    auto plan = [&](const int r, unsigned& b, unsigned& c) {
         const int k = sub + G * r;
         int dx, dy, dz;
         cell_of(k, dx, dy, dz);
-        // minimum distance from the query to the cell's box, per axis (0 when the query's own slab)
-        pv = in_range && k < 27 && !(box_dmin2(dx, dy, dz) > (double)bound);
-        return pack_key(cx + dx, cy + dy, cz + dz);
+        const bool pv = in_range && k < 27 && !(box_dmin2(dx, dy, dz) > (double)bound);
+        lookup(pv, dx, dy, dz, b, c);
     };
-    bool pv1, pv2, pv3;
-    unsigned h1, h2, h3;
-    const unsigned long long k1 = plan(1, pv1), k2 = plan(2, pv2), k3 = plan(3, pv3);
-    const HashEntry e1 = first_load(pv1, k1, h1), e2 = first_load(pv2, k2, h2), e3 = first_load(pv3, k3, h3);
     unsigned b1, b2, b3, c1, c2, c3;
-    resolve(pv1, k1, h1, e1, b1, c1);
-    resolve(pv2, k2, h2, e2, b2, c2);
-    resolve(pv3, k3, h3, e3, b3, c3);
+    plan(1, b1, c1);
+    plan(2, b2, c2);
+    plan(3, b3, c3);
     const unsigned tot = c1 + c2 + c3;
     // candidate index -> map slot: compare / select chain on values (kernels_ivox_coop.hpp slot_select), no branches
     const unsigned p1 = c1, p2 = c1 + c2, o0 = b1, o1 = b2 - p1, o2 = b3 - p2;
@@ -223,23 +233,37 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
             for (int j = 0; j < K; ++j) { t[j] = ~0ull; sl[j] = 0u; }
             ncand = 0;
             if (sub < K && mine_key != ~0ull) { t[0] = mine_key; sl[0] = mine_slot; ncand = 1; }
-            for (int r = 0; r < 13; ++r) {
+            // 13 shell cells per lane in batches of five: the (pruned) cell lookups of a batch are in flight together, then
+            // one flattened candidate loop over the cells that survived -- two memory round trips per batch, not per cell
+            auto shell = [&](const int r, unsigned& bb, unsigned& cc) {
                 const int k = sub + G * r;
                 const int code = kShellOrder[k < 98 ? k : 0];
                 const int dx = code % 5 - 2, dy = (code / 5) % 5 - 2, dz = code / 25 - 2;
-                const bool pv = in_range && k < 98 && !(box_dmin2(dx, dy, dz) > (double)b2);
-                const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
-                unsigned h, bb, cc;
-                const HashEntry e = first_load(pv, key, h);
-                resolve(pv, key, h, e, bb, cc);
-                const unsigned last = bb + cc - 1;  // only dereferenced when cc > 0
-                for (unsigned s = bb; s < bb + cc; s += 4) {
-                    const unsigned s1 = s + 1 < last ? s + 1 : last, s2 = s + 2 < last ? s + 2 : last, s3 = s + 3 < last ? s + 3 : last;
-                    const float4 p0 = cg.g.pts[s], p1 = cg.g.pts[s1], p2 = cg.g.pts[s2], p3 = cg.g.pts[s3];
-                    consider(p0, s, true);
-                    consider(p1, s1, s + 1 <= last);
-                    consider(p2, s2, s + 2 <= last);
-                    consider(p3, s3, s + 3 <= last);
+                const bool pv = in_range && r < 13 && k < 98 && !(box_dmin2(dx, dy, dz) > (double)b2);
+                lookup(pv, dx, dy, dz, bb, cc);
+            };
+#pragma unroll
+            for (int batch = 0; batch < 3; ++batch) {
+                unsigned sb0, sb1, sb2, sb3, sb4, sc0, sc1, sc2, sc3, sc4;
+                shell(5 * batch + 0, sb0, sc0);
+                shell(5 * batch + 1, sb1, sc1);
+                shell(5 * batch + 2, sb2, sc2);
+                shell(5 * batch + 3, sb3, sc3);
+                shell(5 * batch + 4, sb4, sc4);
+                const unsigned q1 = sc0, q2 = q1 + sc1, q3 = q2 + sc2, q4 = q3 + sc3, stot = q4 + sc4;
+                const unsigned u0 = sb0, u1 = sb1 - q1, u2 = sb2 - q2, u3 = sb3 - q3, u4 = sb4 - q4;
+                for (unsigned j = 0; j < stot; j += 4) {
+                    const unsigned last = stot - 1;
+                    const unsigned i1 = j + 1, i2 = j + 2, i3 = j + 3;
+                    const unsigned s0 = slot_select<5>(j, q1, q2, q3, q4, u0, u1, u2, u3, u4);
+                    const unsigned s1 = slot_select<5>(i1 < last ? i1 : last, q1, q2, q3, q4, u0, u1, u2, u3, u4);
+                    const unsigned s2 = slot_select<5>(i2 < last ? i2 : last, q1, q2, q3, q4, u0, u1, u2, u3, u4);
+                    const unsigned s3 = slot_select<5>(i3 < last ? i3 : last, q1, q2, q3, q4, u0, u1, u2, u3, u4);
+                    const float4 p0 = cg.g.pts[s0], p1 = cg.g.pts[s1], p2 = cg.g.pts[s2], p3 = cg.g.pts[s3];
+                    consider(p0, s0, true);
+                    consider(p1, s1, i1 <= last);
+                    consider(p2, s2, i2 <= last);
+                    consider(p3, s3, i3 <= last);
                 }
             }
             merge();

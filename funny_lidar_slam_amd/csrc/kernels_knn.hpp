@@ -29,6 +29,7 @@ struct CellGridDev {
     double inv_cell;
     double cell;
     int rings;  // 1: the gate fits into one cell (27-cell block suffices); 2: half-size cells, 125-cell block in two stages
+    DenseWindow win;  // cells == nullptr: no dense window (extent too large), hash table only
 };
 
 template <int K>

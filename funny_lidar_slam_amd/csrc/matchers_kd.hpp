@@ -87,7 +87,7 @@ struct IcpMatcher final : fls_matcher {
         d_eff.reserve(std::max<size_t>(n, 1));
         d_partials_b.reserve(size_t(std::max(nwg, 1)) * kPartialStride);
         const CellGridDev cg = cell_dev(grid);
-        const dim3 knn_grid_dim(unsigned((((n * 8 + 255) / 256) + 7) / 8 * 8));
+        const dim3 knn_grid_dim(unsigned((((n * 8 + 255) / 256) + 63) / 64 * 64));  // multiple of 64: the XCD chunk re-map is a bijection
         Pose16 T0;
         std::memcpy(T0.m, T, sizeof(T0.m));
         const unsigned word = run_mailbox_loop(int(p.max_iterations), n, [&](int it, int first) {
@@ -165,7 +165,7 @@ struct FeatureDev {
     void launch(hipStream_t s, GnState* st, int first, const Pose16& T0, const CellGridDev& cg, float gate, double thres, double* partials) {
         const size_t n = scan.n;
         if (n == 0) return;
-        const dim3 knn_grid_dim(unsigned((((n * 8 + 255) / 256) + 7) / 8 * 8));
+        const dim3 knn_grid_dim(unsigned((((n * 8 + 255) / 256) + 63) / 64 * 64));  // multiple of 64: the XCD chunk re-map is a bijection
         hipLaunchKernelGGL((grid_knn_kernel<5, false>), knn_grid_dim, dim3(256), 0, s, scan.x.p, scan.y.p, scan.z.p, int(n), st, first, T0, cg, gate,
                            nn_pts.p, nn_cnt.p, kth.p, flag.p);
         hipLaunchKernelGGL((feature_fit_kernel<LINE>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, scan.x.p, scan.y.p, scan.z.p, int(n), st,
