@@ -264,3 +264,32 @@ def test_empty_and_tiny_inputs(mode, y, cid, loc):
         dt, dr = synth.pose_error(T, T_ref)
         assert (dt < 1e-4 and dr < 1e-4) or (not np.all(np.isfinite(T)) and not np.all(np.isfinite(T_ref))), (mode, scan.shape, dt, dr)
         m.close()
+
+
+def test_handle_lifecycle_many_cycles():
+    """Create / use / destroy handles of every kind repeatedly (streams, pinned mailboxes, batch lanes, events): nothing
+    leaks into the next handle, results stay bit-identical."""
+    cfg = synth.make_config(1, scale=0.02)
+    cl = reg.PointcloudCluster(planar_cloud_=cfg["scan"])
+    first = None
+    for cycle in range(12):
+        m = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+        m.AddCloudToLocalMap([cfg["map"]])
+        oks, Ts, st = m.MatchBatch([cl, cl, cl], [np.eye(4)] * 3, lanes=2 + cycle % 3)
+        T = np.eye(4)
+        ok = m.Match(cl, T, update_map=bool(cycle % 2))  # every other cycle also grows the map afterwards
+        m.set_profiling(True)
+        T2 = np.eye(4)
+        m.Match(cl, T2, update_map=False)
+        m.kernel_time()
+        if first is None:
+            first = (ok, T.copy(), Ts[0].copy())
+        assert ok == first[0] and np.array_equal(T, first[1]) and np.array_equal(Ts[0], first[2]) and np.array_equal(Ts[1], Ts[2])
+        m.close()
+        for mode, y, cid, loc in (("IcpOptimized", reg.YAML_NCLT_ICP, 0, True), ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, False)):
+            if cycle % 4 == 0:
+                c2 = synth.make_config(cid, scale=0.02 if cid else 1.0)
+                k = reg.make_matcher(mode, y, is_localization_mode=loc)
+                k.AddCloudToLocalMap([c2["map"]])
+                k.Match(util.cluster_for(mode, c2["scan"], None), np.eye(4), update_map=False)
+                k.close()
