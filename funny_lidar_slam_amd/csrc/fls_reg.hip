@@ -92,6 +92,7 @@ fls_status fls_create(fls_kind kind, const fls_params* params, int device_id, fl
 void fls_destroy(fls_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    h->lanes.clear();  // the batch lanes read this handle's map: they go first
     delete h;
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include "host_maps.hpp"
 #include <memory>
+#include <thread>
 
 struct fls_matcher {
     fls_kind kind;
@@ -57,17 +58,68 @@ struct fls_matcher {
     virtual void reset_job_state() {}
     // Batch of independent registrations against the CURRENT map (BASELINE configs[4]): every job is what a
     // fresh reference process holding this map would compute for Match(scan_j, T_j) -- no map update, no state carried
-    // from job to job.  Default: the jobs run one after the other on this handle's stream.
-    virtual fls_status match_batch(size_t n_jobs, const float* const* s0, const size_t* n0, const float* const* s1, const size_t* n1,
-                                   int stride, double* T, fls_stats* st, int32_t* status, int lanes) {
-        (void)lanes;
-        for (size_t j = 0; j < n_jobs; ++j) {
-            reset_job_state();
-            fls_status rc = scan_upload(s0[j], n0[j], s1 ? s1[j] : nullptr, n1 ? n1[j] : 0, stride);
-            if (rc == FLS_OK) rc = match_resident(T + 16 * j, 0, st ? &st[j] : nullptr);
-            if (status) status[j] = int32_t(rc);
-            if (rc < 0) return rc;
+    // from job to job.  With lanes > 1 the jobs run on `lanes` clones of this handle (own stream, own
+    // Gauss-Newton state, mailbox and per-point buffers; one host thread each, spinning on its own mailbox) that READ
+    // this handle's resident map: while one job runs its single-workgroup tail or an under-occupied fit kernel, the
+    // correspondence kernels of the other jobs fill the machine.  lanes <= 1: one after the other on this handle.
+    std::vector<std::unique_ptr<fls_matcher>> lanes;
+    bool is_lane = false;
+    virtual std::unique_ptr<fls_matcher> clone_for_lane() { return nullptr; }  // same kind, borrowing this handle's map
+    virtual fls_status prepare_batch() { return FLS_OK; }                     // map image current and complete on the device
+    virtual void tune_lane(fls_matcher&) {}                                    // copy run-time switches to a lane
+    fls_status match_batch(size_t n_jobs, const float* const* s0, const size_t* n0, const float* const* s1, const size_t* n1, int stride,
+                           double* T, fls_stats* st, int32_t* status, int n_lanes) {
+        if (is_lane) return FLS_ERR_STATE;
+        size_t L = size_t(std::max(1, std::min(n_lanes, 16)));
+        if (L > 1 && n_jobs > 1) {
+            const fls_status prc = prepare_batch();
+            if (prc != FLS_OK) return prc;
+            while (lanes.size() < L) {
+                std::unique_ptr<fls_matcher> q = clone_for_lane();
+                if (!q) break;
+                q->is_lane = true;
+                lanes.push_back(std::move(q));
+            }
+            if (lanes.size() < L) L = 1;  // the kind cannot clone itself (or the clone failed): sequential
         }
+        if (L <= 1 || n_jobs <= 1) {
+            for (size_t j = 0; j < n_jobs; ++j) {
+                reset_job_state();
+                fls_status rc = scan_upload(s0[j], n0[j], s1 ? s1[j] : nullptr, n1 ? n1[j] : 0, stride);
+                if (rc == FLS_OK) rc = match_resident(T + 16 * j, 0, st ? &st[j] : nullptr);
+                if (status) status[j] = int32_t(rc);
+                if (rc < 0) return rc;
+            }
+            return FLS_OK;
+        }
+        std::vector<fls_status> lane_rc(L, FLS_OK);
+        std::vector<std::thread> th;
+        for (size_t l = 0; l < L; ++l) {
+            fls_matcher* q = lanes[l].get();
+            tune_lane(*q);
+            q->expect_iters = expect_iters;
+            th.emplace_back([=, &lane_rc]() {
+                try {
+                    FLS_HIP(hipSetDevice(q->device));
+                    for (size_t j = l; j < n_jobs; j += L) {
+                        q->reset_job_state();
+                        fls_status rc = q->scan_upload(s0[j], n0[j], s1 ? s1[j] : nullptr, n1 ? n1[j] : 0, stride);
+                        if (rc == FLS_OK) rc = q->match_resident(T + 16 * j, 0, st ? &st[j] : nullptr);
+                        if (status) status[j] = int32_t(rc);
+                        if (rc < 0) { lane_rc[l] = rc; return; }
+                    }
+                } catch (const fls::HipError& e) {
+                    std::fprintf(stderr, "[fls_reg] batch lane %zu: %s\n", l, e.what());
+                    lane_rc[l] = FLS_ERR_DEVICE;
+                } catch (const std::bad_alloc&) {
+                    lane_rc[l] = FLS_ERR_NOMEM;
+                } catch (...) {
+                    lane_rc[l] = FLS_ERR_INVALID;
+                }
+            });
+        }
+        for (auto& t : th) t.join();
+        for (const fls_status rc : lane_rc) if (rc < 0) return rc;
         return FLS_OK;
     }
 

@@ -215,7 +215,8 @@ struct NdtMatcher final : fls_matcher {
         return FLS_OK;
     }
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
-        if (grids.empty() || !have_map) return FLS_ERR_STATE;  // CHECK(!grids_.empty()) :230
+        const NdtMatcher& M = owner ? *owner : *this;  // a batch lane reads its owner's voxel tables
+        if (M.grids.empty() || !M.have_map) return FLS_ERR_STATE;  // CHECK(!grids_.empty()) :230
         const size_t n = scan.n;
         const int nblk = int((n + 63) / 64);
         stats = fls_stats{};
@@ -225,7 +226,7 @@ struct NdtMatcher final : fls_matcher {
         d_hit_vid.reserve(std::max<size_t>(n * 7, 1));
         d_eff7.reserve(std::max<size_t>(n * 7, 1));
         d_partials_b.reserve(size_t(std::max(nblk, 1)) * kPartialStride);
-        const NdtGridDev ng{d_table.p, mask, d_mu.p, d_info.p, d_vid.p, inv_voxel};
+        const NdtGridDev ng{M.d_table.p, M.mask, M.d_mu.p, M.d_info.p, M.d_vid.p, M.inv_voxel};
         Pose16 T0;
         std::memcpy(T0.m, T, sizeof(T0.m));
         const unsigned word = run_mailbox_loop(int(p.max_iterations), n, [&](int it, int first) {
@@ -256,7 +257,7 @@ struct NdtMatcher final : fls_matcher {
             return FLS_NOT_CONVERGED;
         }
         // has_converge = true unconditionally (:325, Q10)
-        if (!p.is_localization_mode && update_map) {
+        if (!p.is_localization_mode && update_map && !owner) {
             add_cloud_impl(hm::xform_cloud_f(source, T_in));  // Q11: transformed with the INPUT T (:327-329)
             stats.map_updated = 1;
         }
@@ -267,6 +268,15 @@ struct NdtMatcher final : fls_matcher {
         if (out) *out = stats;
         return FLS_OK;
     }
+    const NdtMatcher* owner = nullptr;
+    std::unique_ptr<fls_matcher> clone_for_lane() override {
+        auto q = std::make_unique<NdtMatcher>();
+        q->kind = kind; q->p = p; q->device = device;
+        if (q->init() != FLS_OK) return nullptr;
+        q->owner = this;
+        return q;
+    }
+    fls_status prepare_batch() override { FLS_HIP(hipStreamSynchronize(stream)); return have_map ? FLS_OK : FLS_ERR_STATE; }
     fls_status fitness(float max_range, float* score) override {
         if (!p.is_localization_mode) { *score = std::numeric_limits<float>::max(); return FLS_OK; }  // :346-348
         if (!have_fitness_grid || !have_final) return FLS_ERR_STATE;

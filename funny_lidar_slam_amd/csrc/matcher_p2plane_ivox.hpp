@@ -22,11 +22,10 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     HostIvox ivox;
     GridImage image;
     bool image_dirty = true, image_built = false;
-    // batch lanes (fls_match_batch): clones with their own stream / Gauss-Newton state / mailbox / per-point buffers
-    // that READ this handle's resident map image; created on first use, kept for the next batch
-    const GridImage* borrowed = nullptr;
-    std::vector<std::unique_ptr<P2PlaneIvoxMatcher>> lanes;
     size_t n_incremental = 0, n_full_rebuilds = 0;
+    // a batch lane (fls_match_batch) reads its owner's resident map image
+    const GridImage* borrowed = nullptr;
+    bool host_timing = false;  // FLS_HOST_TIMING=1: print the host-side cost of every map update
     PinnedBuf<char> upd_stage;
     DevBuf<unsigned char> d_code;
     DevBuf<float4> d_pw;
@@ -35,7 +34,6 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     DevBuf<unsigned> d_ticket;
     bool use_dense = true; // dense voxel window instead of the hash table when the map extent allows (FLS_IVOX_DENSE=0 disables)
     int xcd_chunk = 8;     // workgroups per XCD chunk of the kNN block re-map (FLS_IVOX_XCD_CHUNK)
-    bool host_timing = false;  // FLS_HOST_TIMING=1: print the host-side cost of every map update
     bool balanced = true;  // equal candidate ranges per lane through an LDS voxel table (FLS_IVOX_BALANCED=0: whole voxels per lane)
     int variant = 4;       // lanes cooperating on one query in ivox_knn_kernel: 4 or 8 (FLS_IVOX_VARIANT)
     bool is_first = true;  // the reference's function-static flag (:62), per handle here
@@ -323,52 +321,21 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
 
     void reset_job_state() override { nn_n = 0; have_final = false; }  // nearest_points_ of a fresh matcher is empty
 
-    // configs[4]: `lanes` registrations in flight on `lanes` streams (one host thread each, spinning on its own
-    // mailbox); all read the same resident map image.  While one job runs its single-workgroup Gauss-Newton tail
-    // or its under-occupied fit kernel, the correspondence kernels of the other jobs fill the machine.
-    fls_status match_batch(size_t n_jobs, const float* const* s0, const size_t* n0, const float* const* s1, const size_t* n1, int stride,
-                           double* T, fls_stats* st, int32_t* status, int n_lanes) override {
-        const size_t L = size_t(std::max(1, std::min(n_lanes, 16)));
-        if (borrowed) return FLS_ERR_STATE;
-        if (L <= 1 || n_jobs <= 1) return fls_matcher::match_batch(n_jobs, s0, n0, s1, n1, stride, T, st, status, 1);
+    std::unique_ptr<fls_matcher> clone_for_lane() override {
+        auto q = std::make_unique<P2PlaneIvoxMatcher>();
+        q->kind = kind; q->p = p; q->device = device;
+        if (q->init() != FLS_OK) return nullptr;
+        q->borrowed = &image;
+        return q;
+    }
+    fls_status prepare_batch() override {
         refresh_image();
         FLS_HIP(hipStreamSynchronize(stream));  // the image is complete before other streams read it
-        while (lanes.size() < L) {
-            auto q = std::make_unique<P2PlaneIvoxMatcher>();
-            q->kind = kind; q->p = p; q->device = device;
-            const fls_status rc = q->init();
-            if (rc != FLS_OK) return rc;
-            q->borrowed = &image;
-            lanes.push_back(std::move(q));
-        }
-        std::vector<fls_status> lane_rc(L, FLS_OK);
-        std::vector<std::thread> th;
-        for (size_t l = 0; l < L; ++l) {
-            P2PlaneIvoxMatcher* q = lanes[l].get();
-            q->use_dense = use_dense; q->variant = variant; q->balanced = balanced; q->xcd_chunk = xcd_chunk; q->expect_iters = expect_iters;
-            th.emplace_back([=, &lane_rc]() {
-                try {
-                    FLS_HIP(hipSetDevice(q->device));
-                    for (size_t j = l; j < n_jobs; j += L) {
-                        q->reset_job_state();
-                        fls_status rc = q->scan_upload(s0[j], n0[j], s1 ? s1[j] : nullptr, n1 ? n1[j] : 0, stride);
-                        if (rc == FLS_OK) rc = q->match_resident(T + 16 * j, 0, st ? &st[j] : nullptr);
-                        if (status) status[j] = int32_t(rc);
-                        if (rc < 0) { lane_rc[l] = rc; return; }
-                    }
-                } catch (const HipError& e) {
-                    std::fprintf(stderr, "[fls_reg] batch lane %zu: %s\n", l, e.what());
-                    lane_rc[l] = FLS_ERR_DEVICE;
-                } catch (const std::bad_alloc&) {
-                    lane_rc[l] = FLS_ERR_NOMEM;
-                } catch (...) {
-                    lane_rc[l] = FLS_ERR_INVALID;
-                }
-            });
-        }
-        for (auto& t : th) t.join();
-        for (const fls_status rc : lane_rc) if (rc < 0) return rc;
         return FLS_OK;
+    }
+    void tune_lane(fls_matcher& l) override {
+        auto& q = static_cast<P2PlaneIvoxMatcher&>(l);
+        q.use_dense = use_dense; q.variant = variant; q.balanced = balanced; q.xcd_chunk = xcd_chunk;
     }
 
     fls_status fitness(float max_range, float* score) override {

@@ -28,6 +28,7 @@ struct IcpMatcher final : fls_matcher {
     std::vector<PtI> local_map, source;
     CellGridImage grid;
     bool have_map = false;
+    const IcpMatcher* owner = nullptr;  // batch lane: reads the owner's map grid
     DevScan scan;
     size_t raw_n = 0;
     hm::KeyframeGate gate;
@@ -75,7 +76,7 @@ struct IcpMatcher final : fls_matcher {
     }
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
         if (raw_n <= 10) return FLS_ERR_INVALID;  // CHECK_GT(ordered_cloud_.size(), 10u) :55
-        if (!have_map) return FLS_ERR_STATE;
+        if (!(owner ? owner->have_map : have_map)) return FLS_ERR_STATE;
         const size_t n = scan.n;
         const int nwg = int((n + 255) / 256);
         stats = fls_stats{};
@@ -86,7 +87,7 @@ struct IcpMatcher final : fls_matcher {
         d_nn_id.reserve(std::max<size_t>(n, 1));
         d_eff.reserve(std::max<size_t>(n, 1));
         d_partials_b.reserve(size_t(std::max(nwg, 1)) * kPartialStride);
-        const CellGridDev cg = cell_dev(grid);
+        const CellGridDev cg = cell_dev(owner ? owner->grid : grid);
         const dim3 knn_grid_dim(unsigned((((n * 8 + 255) / 256) + 63) / 64 * 64));  // multiple of 64: the XCD chunk re-map is a bijection
         Pose16 T0;
         std::memcpy(T0.m, T, sizeof(T0.m));
@@ -112,7 +113,7 @@ struct IcpMatcher final : fls_matcher {
         std::memcpy(stats.last_dx, mb.last_dx, sizeof(stats.last_dx));
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
-        if (has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode && update_map) {  // :154-157
+        if (has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode && update_map && !owner) {  // :154-157
             const fls_status arc = add_cloud_impl(hm::xform_cloud_f(source, final_T));
             if (arc != FLS_OK) rc = arc;
             stats.map_updated = 1;
@@ -120,8 +121,17 @@ struct IcpMatcher final : fls_matcher {
         if (out) *out = stats;
         return rc;
     }
+    void reset_job_state() override { gate = hm::KeyframeGate(); have_final = false; }  // function-static last_T of a fresh process (Q12)
+    std::unique_ptr<fls_matcher> clone_for_lane() override {
+        auto q = std::make_unique<IcpMatcher>();
+        q->kind = kind; q->p = p; q->device = device;
+        if (q->init() != FLS_OK) return nullptr;
+        q->owner = this;
+        return q;
+    }
+    fls_status prepare_batch() override { FLS_HIP(hipStreamSynchronize(stream)); return have_map ? FLS_OK : FLS_ERR_STATE; }
     fls_status fitness(float max_range, float* score) override {
-        if (!have_map || !have_final) return FLS_ERR_STATE;
+        if (owner || !have_map || !have_final) return FLS_ERR_STATE;
         return fitness_score_device(*this, grid, scan, final_T, max_range, score);
     }
     int correspondences(int, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) override {
@@ -179,6 +189,7 @@ struct LoamFullMatcher final : fls_matcher {
     std::vector<PtI> local_corner, local_planar;
     CellGridImage corner_grid, planar_grid;
     bool have_map = false;
+    const LoamFullMatcher* owner = nullptr;  // batch lane: reads the owner's two map grids
     FeatureDev corner, planar;
     hm::KeyframeGate gate;
 
@@ -220,7 +231,7 @@ struct LoamFullMatcher final : fls_matcher {
         return FLS_OK;
     }
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
-        if (!have_map) return FLS_ERR_STATE;
+        if (!(owner ? owner->have_map : have_map)) return FLS_ERR_STATE;
         const size_t np = planar.scan.n, nc = corner.scan.n;
         const int nbp = int((np + 255) / 256), nbc = int((nc + 255) / 256);
         stats = fls_stats{};
@@ -230,7 +241,7 @@ struct LoamFullMatcher final : fls_matcher {
         corner.prepare();
         d_partials_a.reserve(size_t(std::max(nbc, 1)) * kPartialStride);
         d_partials_b.reserve(size_t(std::max(nbp, 1)) * kPartialStride);
-        const CellGridDev cgp = cell_dev(planar_grid), cgc = cell_dev(corner_grid);
+        const CellGridDev cgp = cell_dev(owner ? owner->planar_grid : planar_grid), cgc = cell_dev(owner ? owner->corner_grid : corner_grid);
         const float gate_f = float(p.point_search_thres);
         Pose16 T0;
         std::memcpy(T0.m, T, sizeof(T0.m));
@@ -254,7 +265,7 @@ struct LoamFullMatcher final : fls_matcher {
         std::memcpy(stats.last_dx, mb.last_dx, sizeof(stats.last_dx));
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
-        if (has_converge && gate.need(mb.T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && update_map) {  // :185-193 (no localization switch)
+        if (has_converge && gate.need(mb.T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && update_map && !owner) {  // :185-193 (no localization switch)
             const fls_status arc = add_cloud_impl(hm::xform_cloud_d(planar.scan.host, mb.T), hm::xform_cloud_d(corner.scan.host, mb.T));
             if (arc != FLS_OK) rc = arc;
             stats.map_updated = 1;
@@ -262,6 +273,15 @@ struct LoamFullMatcher final : fls_matcher {
         if (out) *out = stats;
         return rc;
     }
+    void reset_job_state() override { gate = hm::KeyframeGate(); }  // function-static last_T of a fresh process (Q12)
+    std::unique_ptr<fls_matcher> clone_for_lane() override {
+        auto q = std::make_unique<LoamFullMatcher>();
+        q->kind = kind; q->p = p; q->device = device;
+        if (q->init() != FLS_OK) return nullptr;
+        q->owner = this;
+        return q;
+    }
+    fls_status prepare_batch() override { FLS_HIP(hipStreamSynchronize(stream)); return have_map ? FLS_OK : FLS_ERR_STATE; }
     fls_status fitness(float, float* score) override { *score = std::numeric_limits<float>::max(); return FLS_OK; }  // FloatNaN :206-208
     int correspondences(int slot, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) override {
         return (slot == 1 ? corner : planar).fetch(stream, ids, cnt, valid, cap);
@@ -275,6 +295,7 @@ struct P2PlaneKdMatcher final : fls_matcher {
     std::vector<PtI> local_map;
     CellGridImage grid;
     bool have_map = false;
+    const P2PlaneKdMatcher* owner = nullptr;  // batch lane: reads the owner's map grid
     FeatureDev planar;
     hm::KeyframeGate gate;
     double final_T[16]{};
@@ -312,14 +333,14 @@ struct P2PlaneKdMatcher final : fls_matcher {
         return FLS_OK;
     }
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
-        if (!have_map) return FLS_ERR_STATE;
+        if (!(owner ? owner->have_map : have_map)) return FLS_ERR_STATE;
         const size_t n = planar.scan.n;
         const int nblk = int((n + 255) / 256);
         stats = fls_stats{};
         stats.n_source = int(n);
         planar.prepare();
         d_partials_b.reserve(size_t(std::max(nblk, 1)) * kPartialStride);
-        const CellGridDev cg = cell_dev(grid);
+        const CellGridDev cg = cell_dev(owner ? owner->grid : grid);
         Pose16 T0;
         std::memcpy(T0.m, T, sizeof(T0.m));
         const unsigned word = run_mailbox_loop(int(p.max_iterations), n, [&](int it, int first) {
@@ -341,7 +362,7 @@ struct P2PlaneKdMatcher final : fls_matcher {
         std::memcpy(stats.last_dx, mb.last_dx, sizeof(stats.last_dx));
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
-        if (has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode && update_map) {  // :145-149
+        if (has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode && update_map && !owner) {  // :145-149
             const fls_status arc = add_cloud_impl(hm::xform_cloud_f(planar.scan.host, final_T));
             if (arc != FLS_OK) rc = arc;
             stats.map_updated = 1;
@@ -349,8 +370,17 @@ struct P2PlaneKdMatcher final : fls_matcher {
         if (out) *out = stats;
         return rc;
     }
+    void reset_job_state() override { gate = hm::KeyframeGate(); have_final = false; }
+    std::unique_ptr<fls_matcher> clone_for_lane() override {
+        auto q = std::make_unique<P2PlaneKdMatcher>();
+        q->kind = kind; q->p = p; q->device = device;
+        if (q->init() != FLS_OK) return nullptr;
+        q->owner = this;
+        return q;
+    }
+    fls_status prepare_batch() override { FLS_HIP(hipStreamSynchronize(stream)); return have_map ? FLS_OK : FLS_ERR_STATE; }
     fls_status fitness(float max_range, float* score) override {
-        if (!have_map || !have_final) return FLS_ERR_STATE;
+        if (owner || !have_map || !have_final) return FLS_ERR_STATE;
         return fitness_score_device(*this, grid, planar.scan, final_T, max_range, score);
     }
     int correspondences(int, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) override { return planar.fetch(stream, ids, cnt, valid, cap); }

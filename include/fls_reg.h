@@ -136,8 +136,8 @@ fls_status fls_match(fls_handle h, const float* src0, size_t n0, const float* sr
 /* ---- batch of independent registrations against the handle's CURRENT map (BASELINE configs[4]; SURVEY.md 8b "batch",
  * 8e).  Job j is what a fresh reference matcher holding this map returns for Match(src0[j] (, src1[j]), T[16 j ..]):
  * no map update, no state carried between jobs (the reference's function-static / per-instance state is per job,
- * SURVEY Q12).  `lanes` (1..16) registrations are kept in flight on separate HIP streams (P2PLANE_IVOX; the other
- * kinds run the jobs back to back).  T is n_jobs x 16 doubles, column-major, in/out; stats / status (per-job
+ * SURVEY Q12).  `lanes` (1..16) registrations are kept in flight on separate HIP streams (clones of the handle that
+ * read its resident map; every kind).  T is n_jobs x 16 doubles, column-major, in/out; stats / status (per-job
  * fls_status) may be NULL; src1 and n1 are both NULL unless the kind takes a second cloud.  Returns the first
  * error (< 0) or FLS_OK.  The handle's own Match state (nearest_points_, last pose) is left untouched when lanes > 1. */
 fls_status fls_match_batch(fls_handle h, size_t n_jobs, const float* const* src0, const size_t* n0, const float* const* src1,

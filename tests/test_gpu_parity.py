@@ -192,20 +192,29 @@ def test_match_batch_equals_fresh_matchers():
     m.close()
 
 
-def test_match_batch_default_path_other_kind():
-    """Kinds without stream lanes run the jobs back to back; same contract (fresh state per job)."""
-    cfgs = [synth.make_config(0, job=j) for j in range(3)]
-    y = reg.YAML_NCLT_ICP
-    m = reg.make_matcher("IcpOptimized", y, is_localization_mode=True)
-    m.AddCloudToLocalMap([cfgs[0]["map"]])
-    clusters = [reg.PointcloudCluster(ordered_cloud_=c["scan"]) for c in cfgs]
-    oks, Ts, stats = m.MatchBatch(clusters, [np.eye(4)] * 3, lanes=4)
+@pytest.mark.parametrize("mode,y,cid,scale,loc", [("IcpOptimized", reg.YAML_NCLT_ICP, 0, 1.0, True), ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, 0.05, False),
+                                                  ("LoamFull_KdTree", reg.YAML_NCLT_LOAM_FULL, 3, 0.05, False),
+                                                  ("PointToPlane_KdTree", reg.YAML_NCLT_LOC_KDTREE, 1, 0.04, True)])
+def test_match_batch_other_kinds(mode, y, cid, scale, loc):
+    """Stream lanes for every kind: each job equals, bit for bit, what a fresh handle computes (fresh per-job state:
+    keyframe gate, valid flags), on 3 lanes and back to back."""
+    cfgs = [synth.make_config(cid, job=j, scale=scale) for j in range(4)]
+    maps = [cfgs[0]["map"]] + ([cfgs[0]["corner_map"]] if "corner_map" in cfgs[0] else [])
+    m = reg.make_matcher(mode, y, is_localization_mode=loc)
+    m.AddCloudToLocalMap(maps)
+    clusters = [util.cluster_for(mode, c["scan"], c.get("corner_scan")) for c in cfgs]
+    oks, Ts, stats = m.MatchBatch(clusters, [np.eye(4)] * 4, lanes=3)
+    oks1, Ts1, stats1 = m.MatchBatch(clusters, [np.eye(4)] * 4, lanes=1)
     for j, c in enumerate(cfgs):
-        f = reg.make_matcher("IcpOptimized", y, is_localization_mode=True)
-        f.AddCloudToLocalMap([c["map"]])
+        f = reg.make_matcher(mode, y, is_localization_mode=loc)
+        f.AddCloudToLocalMap(maps)
         T = np.eye(4)
         ok = f.Match(clusters[j], T, update_map=False)
-        assert ok == oks[j] and np.array_equal(T, Ts[j]) and f.stats.iterations == stats[j].iterations
+        assert ok == oks[j] == oks1[j], (mode, j)
+        assert np.array_equal(T, Ts[j]) and np.array_equal(T, Ts1[j]), (mode, j)
+        assert f.stats.iterations == stats[j].iterations == stats1[j].iterations and f.stats.n_valid == stats[j].n_valid
+        f.close()
+    m.close()
 
 
 @pytest.mark.parametrize("job", list(range(1, 9)))
