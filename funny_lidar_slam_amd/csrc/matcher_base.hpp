@@ -64,6 +64,7 @@ struct fls_matcher {
     // correspondence kernels of the other jobs fill the machine.  lanes <= 1: one after the other on this handle.
     std::vector<std::unique_ptr<fls_matcher>> lanes;
     bool is_lane = false;
+    bool upload_keep_host = true;  // fls_match sets this to "the map may be updated": a Match-only call skips the per-point host copy
     virtual std::unique_ptr<fls_matcher> clone_for_lane() { return nullptr; }  // same kind, borrowing this handle's map
     virtual fls_status prepare_batch() { return FLS_OK; }                     // map image current and complete on the device
     virtual void tune_lane(fls_matcher&) {}                                    // copy run-time switches to a lane
@@ -232,10 +233,17 @@ namespace fls {
 
 // SoA device copy of a source cloud
 struct DevScan {
-    DevBuf<float> x, y, z;
+    struct View { float* p = nullptr; };
+    DevBuf<float> xyz;  // x[n] | y[n] | z[n] in one allocation: one host-to-device copy per upload
+    View x, y, z;
     PinnedBuf<float> stage;
     size_t n = 0;
     std::vector<PtI> host;  // kept for map updates / fitness
+    void push(hipStream_t s) {
+        xyz.reserve(3 * n);
+        x.p = xyz.p; y.p = xyz.p + n; z.p = xyz.p + 2 * n;
+        FLS_HIP(hipMemcpyAsync(xyz.p, stage.p, 3 * n * sizeof(float), hipMemcpyHostToDevice, s));
+    }
     // straight from the caller's strided AoS into the pinned SoA staging buffer (no temporary cloud; the
     // per-point host copy is kept only when the caller needs intensities / points later)
     void upload_raw(const float* p, size_t count, int stride, hipStream_t s, bool keep_host) {
@@ -247,24 +255,18 @@ struct DevScan {
             host.clear();
         }
         if (n == 0) return;
-        x.reserve(n); y.reserve(n); z.reserve(n);
         stage.reserve(3 * n);
         float* sx = stage.p; float* sy = stage.p + n; float* sz = stage.p + 2 * n;
         for (size_t i = 0; i < n; ++i) { sx[i] = p[i * stride]; sy[i] = p[i * stride + 1]; sz[i] = p[i * stride + 2]; }
-        FLS_HIP(hipMemcpyAsync(x.p, sx, n * sizeof(float), hipMemcpyHostToDevice, s));
-        FLS_HIP(hipMemcpyAsync(y.p, sy, n * sizeof(float), hipMemcpyHostToDevice, s));
-        FLS_HIP(hipMemcpyAsync(z.p, sz, n * sizeof(float), hipMemcpyHostToDevice, s));
+        push(s);
     }
     void upload(const std::vector<PtI>& c, hipStream_t s) {
         host = c;
         n = c.size();
         if (n == 0) return;
-        x.reserve(n); y.reserve(n); z.reserve(n);
         stage.reserve(3 * n);
         for (size_t i = 0; i < n; ++i) { stage.p[i] = c[i].x; stage.p[n + i] = c[i].y; stage.p[2 * n + i] = c[i].z; }
-        FLS_HIP(hipMemcpyAsync(x.p, stage.p, n * sizeof(float), hipMemcpyHostToDevice, s));
-        FLS_HIP(hipMemcpyAsync(y.p, stage.p + n, n * sizeof(float), hipMemcpyHostToDevice, s));
-        FLS_HIP(hipMemcpyAsync(z.p, stage.p + 2 * n, n * sizeof(float), hipMemcpyHostToDevice, s));
+        push(s);
     }
 };
 
