@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "fls_features_create", "fls_features_destroy", "fls_features_project", "fls_features_extract", "fls_features_get", "fls_features_get_time",
 ]
 
-FLS_OK, FLS_NOT_CONVERGED = 0, 1
+FLS_OK, FLS_NOT_CONVERGED, FLS_SKIPPED = 0, 1, 2
 FLS_ERR_INVALID, FLS_ERR_DEVICE, FLS_ERR_RANGE, FLS_ERR_NOMEM, FLS_ERR_STATE = -1, -2, -3, -4, -5
 
 ICP_OPTIMIZED, P2PLANE_IVOX, INCREMENTAL_NDT, LOAM_FULL, P2PLANE_KDTREE = range(5)

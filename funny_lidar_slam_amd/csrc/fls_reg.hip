@@ -49,6 +49,7 @@ const char* fls_status_string(int s) {
     switch (s) {
         case FLS_OK: return "ok (Match returned true)";
         case FLS_NOT_CONVERGED: return "not converged (Match returned false)";
+        case FLS_SKIPPED: return "batch job not run";
         case FLS_ERR_INVALID: return "invalid argument or unset parameter";
         case FLS_ERR_DEVICE: return "HIP error or no gfx950 device";
         case FLS_ERR_RANGE: return "coordinate outside the voxel key range";
@@ -127,9 +128,7 @@ fls_status fls_match(fls_handle h, const float* s0, size_t n0, const float* s1, 
     if (!h || !T || (!s0 && n0) || stride < 3) return FLS_ERR_INVALID;
     return guarded([&]() -> fls_status {
         FLS_HIP(hipSetDevice(h->device));
-        h->upload_keep_host = update_map != 0;  // intensities / host points are only needed by the map update
         const fls_status rc = h->scan_upload(s0, n0, s1, n1, stride);
-        h->upload_keep_host = true;
         if (rc != FLS_OK) return rc;
         return h->match_resident(T, update_map, stats);
     });

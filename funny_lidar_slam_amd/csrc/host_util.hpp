@@ -42,7 +42,9 @@ struct DevBuf {
         FLS_HIP(hipMalloc(&q, nc * sizeof(T)));
         if (zero_new) FLS_HIP(hipMemsetAsync(q, 0, nc * sizeof(T), s));
         if (keep && p && cap) FLS_HIP(hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s));
-        if (p) { FLS_HIP(hipStreamSynchronize(s)); FLS_HIP(hipFree(p)); }
+        // growth is rare (buffers only grow): wait for the WHOLE device before the old allocation goes away -- kernels still
+        // queued on any of the handle's streams (e.g. exit-at-once launches behind a converged Match) may hold the pointer
+        if (p) { FLS_HIP(hipDeviceSynchronize()); FLS_HIP(hipFree(p)); }
         p = q;
         cap = nc;
     }

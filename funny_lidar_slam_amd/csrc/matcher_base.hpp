@@ -61,38 +61,30 @@ struct fls_matcher {
     // from job to job.  With lanes > 1 the jobs run on `lanes` clones of this handle (own stream, own
     // Gauss-Newton state, mailbox and per-point buffers; one host thread each, spinning on its own mailbox) that READ
     // this handle's resident map: while one job runs its single-workgroup tail or an under-occupied fit kernel, the
-    // correspondence kernels of the other jobs fill the machine.  lanes <= 1: one after the other on this handle.
+    // correspondence kernels of the other jobs fill the machine.  lanes <= 1: one clone, jobs one after the other.
     std::vector<std::unique_ptr<fls_matcher>> lanes;
     bool is_lane = false;
-    bool upload_keep_host = true;  // fls_match sets this to "the map may be updated": a Match-only call skips the per-point host copy
     virtual std::unique_ptr<fls_matcher> clone_for_lane() { return nullptr; }  // same kind, borrowing this handle's map
     virtual fls_status prepare_batch() { return FLS_OK; }                     // map image current and complete on the device
     virtual void tune_lane(fls_matcher&) {}                                    // copy run-time switches to a lane
     fls_status match_batch(size_t n_jobs, const float* const* s0, const size_t* n0, const float* const* s1, const size_t* n1, int stride,
                            double* T, fls_stats* st, int32_t* status, int n_lanes) {
         if (is_lane) return FLS_ERR_STATE;
-        size_t L = size_t(std::max(1, std::min(n_lanes, 16)));
-        if (L > 1 && n_jobs > 1) {
-            const fls_status prc = prepare_batch();
-            if (prc != FLS_OK) return prc;
-            while (lanes.size() < L) {
-                std::unique_ptr<fls_matcher> q = clone_for_lane();
-                if (!q) break;
-                q->is_lane = true;
-                lanes.push_back(std::move(q));
-            }
-            if (lanes.size() < L) L = 1;  // the kind cannot clone itself (or the clone failed): sequential
+        if (status) for (size_t j = 0; j < n_jobs; ++j) status[j] = FLS_SKIPPED;  // overwritten by every job that runs
+        if (n_jobs == 0) return FLS_OK;
+        size_t L = std::min(size_t(std::max(1, std::min(n_lanes, 16))), n_jobs);
+        // Jobs never run on the owner itself: its Match state (nearest_points_, keyframe gate, resident scan, final pose)
+        // belongs to the SLAM thread's next fls_match.  lanes <= 1 (or a single job) = one lane clone, back to back.
+        const fls_status prc = prepare_batch();
+        if (prc != FLS_OK) return prc;
+        while (lanes.size() < L) {
+            std::unique_ptr<fls_matcher> q = clone_for_lane();
+            if (!q) break;
+            q->is_lane = true;
+            lanes.push_back(std::move(q));
         }
-        if (L <= 1 || n_jobs <= 1) {
-            for (size_t j = 0; j < n_jobs; ++j) {
-                reset_job_state();
-                fls_status rc = scan_upload(s0[j], n0[j], s1 ? s1[j] : nullptr, n1 ? n1[j] : 0, stride);
-                if (rc == FLS_OK) rc = match_resident(T + 16 * j, 0, st ? &st[j] : nullptr);
-                if (status) status[j] = int32_t(rc);
-                if (rc < 0) return rc;
-            }
-            return FLS_OK;
-        }
+        if (lanes.empty()) return FLS_ERR_NOMEM;  // the clone could not be set up
+        L = std::min(L, lanes.size());
         std::vector<fls_status> lane_rc(L, FLS_OK);
         std::vector<std::thread> th;
         for (size_t l = 0; l < L; ++l) {
@@ -244,22 +236,23 @@ struct DevScan {
         x.p = xyz.p; y.p = xyz.p + n; z.p = xyz.p + 2 * n;
         FLS_HIP(hipMemcpyAsync(xyz.p, stage.p, 3 * n * sizeof(float), hipMemcpyHostToDevice, s));
     }
-    // straight from the caller's strided AoS into the pinned SoA staging buffer (no temporary cloud; the
-    // per-point host copy is kept only when the caller needs intensities / points later)
-    void upload_raw(const float* p, size_t count, int stride, hipStream_t s, bool keep_host) {
+    // straight from the caller's strided AoS into the pinned SoA staging buffer x[n] | y[n] | z[n] | intensity[n] (no
+    // temporary cloud, no per-point host copy).  The first 3 n floats go to the device; the staged intensities stay valid
+    // until the next upload, which is all a map update of THIS resident scan needs (fls_match == fls_scan_upload +
+    // fls_match_resident for either value of update_map).
+    void upload_raw(const float* p, size_t count, int stride, hipStream_t s) {
         n = count;
-        if (keep_host) {
-            host.resize(n);
-            for (size_t i = 0; i < n; ++i) host[i] = PtI{p[i * stride], p[i * stride + 1], p[i * stride + 2], intensity_of(p + i * stride, stride)};
-        } else {
-            host.clear();
-        }
+        host.clear();
         if (n == 0) return;
-        stage.reserve(3 * n);
-        float* sx = stage.p; float* sy = stage.p + n; float* sz = stage.p + 2 * n;
-        for (size_t i = 0; i < n; ++i) { sx[i] = p[i * stride]; sy[i] = p[i * stride + 1]; sz[i] = p[i * stride + 2]; }
+        stage.reserve(4 * n);
+        float* sx = stage.p; float* sy = stage.p + n; float* sz = stage.p + 2 * n; float* si = stage.p + 3 * n;
+        for (size_t i = 0; i < n; ++i) {
+            const float* q = p + i * stride;
+            sx[i] = q[0]; sy[i] = q[1]; sz[i] = q[2]; si[i] = intensity_of(q, stride);
+        }
         push(s);
     }
+    float staged_intensity(size_t i) const { return stage.p[3 * n + i]; }
     void upload(const std::vector<PtI>& c, hipStream_t s) {
         host = c;
         n = c.size();

@@ -257,16 +257,17 @@ struct NdtMatcher final : fls_matcher {
             return FLS_NOT_CONVERGED;
         }
         // has_converge = true unconditionally (:325, Q10)
+        fls_status rc = FLS_OK;
         if (!p.is_localization_mode && update_map && !owner) {
-            add_cloud_impl(hm::xform_cloud_f(source, T_in));  // Q11: transformed with the INPUT T (:327-329)
-            stats.map_updated = 1;
+            const fls_status arc = add_cloud_impl(hm::xform_cloud_f(source, T_in));  // Q11: transformed with the INPUT T (:327-329)
+            if (arc != FLS_OK) rc = arc; else stats.map_updated = 1;
         }
         std::memcpy(T, s.T, sizeof(double) * 16);
         std::memcpy(final_T, s.T, sizeof(final_T));
         have_final = true;
         stats.converged = 1;
         if (out) *out = stats;
-        return FLS_OK;
+        return rc;
     }
     const NdtMatcher* owner = nullptr;
     std::unique_ptr<fls_matcher> clone_for_lane() override {

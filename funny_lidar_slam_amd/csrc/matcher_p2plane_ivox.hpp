@@ -159,7 +159,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
                 FLS_HIP(hipStreamSynchronize(stream));
                 for (size_t i = 0; i < n; ++i) {
                     if (h_code[i] == 0) continue;
-                    const PtI pw{h_pw[i].x, h_pw[i].y, h_pw[i].z, scan.host[i].i};
+                    const PtI pw{h_pw[i].x, h_pw[i].y, h_pw[i].z, scan.staged_intensity(i)};
                     (h_code[i] == 1 ? to_add : no_downsample).push_back(pw);
                 }
             }
@@ -230,7 +230,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     fls_status scan_upload(const float* s0, size_t n0, const float* s1, size_t n1, int stride) override {
         (void)s1; (void)n1;
         // (the pinned staging buffer is free again: fls_scan_upload synchronises, a Match ends after its copies)
-        scan.upload_raw(s0, n0, stride, stream, /*keep_host=*/!borrowed && upload_keep_host);
+        scan.upload_raw(s0, n0, stride, stream);
         return FLS_OK;
     }
 
@@ -311,10 +311,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
         if (has_converge && !p.is_localization_mode && update_map && !borrowed) {  // :205-206
-            if (scan.host.size() != n) return FLS_ERR_STATE;  // the resident scan came from a Match-only fls_match: no host points to insert
             const fls_status arc = add_cloud_impl(scan.host, /*from_resident_scan=*/true);
-            if (arc != FLS_OK) rc = arc;
-            stats.map_updated = 1;
+            if (arc != FLS_OK) rc = arc; else stats.map_updated = 1;
         }
         if (out) *out = stats;
         return rc;

@@ -113,10 +113,12 @@ struct IcpMatcher final : fls_matcher {
         std::memcpy(stats.last_dx, mb.last_dx, sizeof(stats.last_dx));
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
-        if (has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode && update_map && !owner) {  // :154-157
+        // :153 `has_converge_ && IsNeedAddCloud(T) && !is_localization_mode_`: the gate (and its last_T) is evaluated before the mode
+        // switch, as in the reference; update_map == 0 (this ABI's "registration only" switch) skips the whole statement,
+        // so such a call leaves the keyframe gate alone
+        if (update_map && !owner && has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode) {
             const fls_status arc = add_cloud_impl(hm::xform_cloud_f(source, final_T));
-            if (arc != FLS_OK) rc = arc;
-            stats.map_updated = 1;
+            if (arc != FLS_OK) rc = arc; else stats.map_updated = 1;
         }
         if (out) *out = stats;
         return rc;
@@ -265,10 +267,9 @@ struct LoamFullMatcher final : fls_matcher {
         std::memcpy(stats.last_dx, mb.last_dx, sizeof(stats.last_dx));
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
-        if (has_converge && gate.need(mb.T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && update_map && !owner) {  // :185-193 (no localization switch)
+        if (update_map && !owner && has_converge && gate.need(mb.T, p.dist_thre_add_cloud, p.rot_thre_add_cloud)) {  // :185-193 (no localization switch)
             const fls_status arc = add_cloud_impl(hm::xform_cloud_d(planar.scan.host, mb.T), hm::xform_cloud_d(corner.scan.host, mb.T));
-            if (arc != FLS_OK) rc = arc;
-            stats.map_updated = 1;
+            if (arc != FLS_OK) rc = arc; else stats.map_updated = 1;
         }
         if (out) *out = stats;
         return rc;
@@ -362,10 +363,9 @@ struct P2PlaneKdMatcher final : fls_matcher {
         std::memcpy(stats.last_dx, mb.last_dx, sizeof(stats.last_dx));
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
-        if (has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode && update_map && !owner) {  // :145-149
+        if (update_map && !owner && has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode) {  // :145-149
             const fls_status arc = add_cloud_impl(hm::xform_cloud_f(planar.scan.host, final_T));
-            if (arc != FLS_OK) rc = arc;
-            stats.map_updated = 1;
+            if (arc != FLS_OK) rc = arc; else stats.map_updated = 1;
         }
         if (out) *out = stats;
         return rc;

@@ -48,6 +48,7 @@ typedef enum fls_kind {
 typedef enum fls_status {
     FLS_OK = 0,             /* Match() == true                                                   */
     FLS_NOT_CONVERGED = 1,  /* Match() == false (T is still written, as in the reference)        */
+    FLS_SKIPPED = 2,        /* fls_match_batch status[] only: job not run (an earlier job of its lane failed) */
     FLS_ERR_INVALID = -1,   /* bad argument / parameter left at its "unset" sentinel (CHECK_NE)  */
     FLS_ERR_DEVICE = -2,    /* HIP runtime error or no gfx950 device                             */
     FLS_ERR_RANGE = -3,     /* coordinate outside the +-2^20 voxel key range                     */
@@ -137,9 +138,10 @@ fls_status fls_match(fls_handle h, const float* src0, size_t n0, const float* sr
  * 8e).  Job j is what a fresh reference matcher holding this map returns for Match(src0[j] (, src1[j]), T[16 j ..]):
  * no map update, no state carried between jobs (the reference's function-static / per-instance state is per job,
  * SURVEY Q12).  `lanes` (1..16) registrations are kept in flight on separate HIP streams (clones of the handle that
- * read its resident map; every kind).  T is n_jobs x 16 doubles, column-major, in/out; stats / status (per-job
- * fls_status) may be NULL; src1 and n1 are both NULL unless the kind takes a second cloud.  Returns the first
- * error (< 0) or FLS_OK.  The handle's own Match state (nearest_points_, last pose) is left untouched when lanes > 1. */
+ * read its resident map; every kind; lanes <= 1 = one clone, jobs back to back).  T is n_jobs x 16 doubles, column-major,
+ * in/out; stats / status (per-job fls_status, FLS_SKIPPED for a job that was not run because an earlier job of its lane
+ * failed) may be NULL; src1 and n1 are both NULL unless the kind takes a second cloud.  Returns the first error (< 0) or
+ * FLS_OK.  The handle's own Match state (nearest_points_, keyframe gate, resident scan, last pose) is never touched.    */
 fls_status fls_match_batch(fls_handle h, size_t n_jobs, const float* const* src0, const size_t* n0, const float* const* src1,
                            const size_t* n1, int stride_floats, double* T_colmajor, fls_stats* stats, int32_t* status, int lanes);
 
@@ -147,7 +149,10 @@ fls_status fls_match_batch(fls_handle h, size_t n_jobs, const float* const* src0
 fls_status fls_get_fitness_score(fls_handle h, float max_range, float* score);
 
 /* ---- resident-scan variant: the scan is uploaded once (and VoxelGrid-ed for ICP / NDT), then matched
- * from HBM.  fls_match == fls_scan_upload + fls_match_resident.                                          */
+ * from HBM.  fls_match == fls_scan_upload + fls_match_resident, for either value of update_map (the resident scan
+ * keeps what a later map update needs until the next upload).  update_map == 0 skips the reference's whole
+ * "converged && IsNeedAddCloud && !localization -> AddCloudToLocalMap" statement: such a call does not advance the
+ * keyframe gate's last_T either.                                                                          */
 fls_status fls_scan_upload(fls_handle h, const float* src0, size_t n0, const float* src1, size_t n1, int stride_floats);
 fls_status fls_match_resident(fls_handle h, double T_colmajor[16], int update_map, fls_stats* stats);
 

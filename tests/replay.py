@@ -1,0 +1,83 @@
+"""Mapping-mode replay scenarios: a short seeded trajectory through the synthetic
+scene, driven the way FrontEnd does it (src/slam/frontend.cpp:126-139, 207-210): the first cloud(s) go in through
+AddCloudToLocalMap in the world frame, every later scan is Match()-ed with update_map = true from a predicted pose, and
+Match itself decides whether / how the local map grows.
+
+A scenario is built so that the reference rules that only show up over several scans all fire:
+  * IcpOptimized     deque longer than local_map_size (pop_front), frames that fail IsNeedAddCloud, a frame that does not
+                     converge within max_iterations (Q10: returns false, map untouched)        icp_optimized.h:151-189,218-234
+  * IncrementalNDT   voxels crossing min_points (first estimate), pooled mean / cov updates + SVD clamp, voxels beyond
+                     max_points (frozen), LRU eviction at a shrunk capacity, map update with the INPUT pose (Q11)
+                                                                                               incremental_ndt.h:130-227,325-334
+  * LoamFull         corner / planar deques, VoxelGrid once a deque holds more than 5 frames, keyframe gate
+                                                                                               loam_full_kdtree.h:65-104,374-389
+  * LoamPointToPlaneIVOX  down-sampling insert rule + LRU (already covered by test_gpu_parity._replay; here for _ref)
+Used by tests/test_gpu_mapping_replay.py (HIP vs oracle), tests/test_ref_pin.py (oracle vs compiled reference) and
+tests/golden/make_golden.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from funny_lidar_slam_amd import registration as reg, synth
+
+
+def _xform(cloud: np.ndarray, T: np.ndarray) -> np.ndarray:
+    """float world-frame copy of a body-frame cloud (what the frontend hands to the first AddCloudToLocalMap)."""
+    return (cloud.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+
+
+def _step(rng, trans, rot_deg):
+    T = np.eye(4)
+    T[:3, :3] = synth.so3_exp(np.deg2rad(np.asarray(rot_deg, float)))
+    T[:3, 3] = trans
+    return T
+
+
+SCENARIOS = {
+    # mode, yaml overrides, n_frames, lidar az steps, sensor range
+    "icp": dict(mode="IcpOptimized", y=dict(reg.YAML_NCLT_ICP, local_map_size=3, optimization_iter_num=12), frames=11, n_az=90, rng_job=21,
+                max_range=45.0, lidar="v64"),
+    "ndt": dict(mode="IncrementalNDT", y=dict(reg.YAML_NCLT_NDT, ndt_capacity=2600), frames=10, n_az=100, rng_job=22, max_range=40.0, lidar="v64"),
+    "loam": dict(mode="LoamFull_KdTree", y=dict(reg.YAML_NCLT_LOAM_FULL), frames=11, n_az=90, rng_job=23, max_range=45.0, lidar="v64"),
+    "ivox": dict(mode="PointToPlane_IVOX", y=dict(reg.YAML_NCLT_IVOX), frames=7, n_az=60, rng_job=24, max_range=38.0, lidar="v64"),
+}
+
+
+def make_replay(name: str) -> dict:
+    """returns dict(mode, y, init_clouds=[world clouds for the first AddCloudToLocalMap], frames=[dict(scan, corner, guess_step)])
+    Frame k is Match(scan_k, T = T_prev_result @ guess_step_k): guess_step is the nominal motion, the true motion differs a little
+    (what an IMU prediction looks like); `big_jump` frames get a poor prediction on purpose."""
+    sc = SCENARIOS[name]
+    scene = synth.make_scene()
+    rng = synth.rng_for(5, sc["rng_job"])
+    lid = dict(synth.VELODYNE_64 if sc["lidar"] == "v64" else synth.VELODYNE_16, n_az=sc["n_az"])
+    mode = sc["mode"]
+    T = np.eye(4)
+
+    def observe(Tw):
+        scan = synth.cast_scan(scene, Tw, rng=rng, max_range=sc["max_range"], **lid)
+        corner = None
+        if mode == "LoamFull_KdTree":
+            corner = synth.cast_edge_scan(scene, Tw, 700, rng)
+            scan = scan[::2].copy()
+        return scan, corner
+
+    scan0, corner0 = observe(T)
+    init = [_xform(scan0, T)] + ([_xform(corner0, T)] if corner0 is not None else [])
+    if name == "ivox":  # a prior map around the start (localization.cpp:135 loads one; a single sparse scan makes a poor iVox map)
+        init = [synth.sample_map(scene, 60000, synth.rng_for(5, 0, 9), radius=30.0)]
+    frames = []
+    for k in range(sc["frames"]):
+        # alternate long steps (pass the 1.0 m / 0.2 rad keyframe gate) and short ones (fail it)
+        long_step = (k % 3) != 1
+        nominal = _step(rng, [1.25 if long_step else 0.25, 0.1 * (k % 2), 0.0], [0.0, 0.0, 4.0 if long_step else 0.5])
+        noise = synth.random_pose(rng, 0.4, 0.06)
+        guess_step = nominal
+        if name == "icp" and k == 6:
+            # a prediction that is off by ~0.9 m / 5 deg: 12 iterations are not enough -> Match returns false (Q10)
+            noise = _step(rng, [0.8, -0.45, 0.0], [0.0, 0.0, 5.0])
+        T = T @ nominal @ noise
+        scan, corner = observe(T)
+        frames.append(dict(scan=scan, corner=corner, guess_step=guess_step, T_gt=T.copy()))
+    return dict(name=name, mode=mode, y=sc["y"], init_clouds=init, frames=frames)

@@ -1,0 +1,133 @@
+"""Mapping-mode replay parity on the GPU (SURVEY.md 8a rows a15, a17, a19 + a7): HIP path through the C ABI vs the CPU
+oracle over a multi-scan trajectory with update_map = true -- the call the reference's FrontEnd actually issues.
+
+Compared after EVERY scan: return value, iteration count, n_valid and pose after every Gauss-Newton iteration,
+valid flags / neighbour counts / correspondence ids of every source point (ids are map cloud indices for the kd-tree
+kinds, so they also pin the ORDER of the rebuilt local map), the map_updated decision, the map sizes of every slot.
+The scenarios (tests/replay.py) are asserted to actually reach the rules they are there for.
+"""
+import numpy as np
+import pytest
+
+from funny_lidar_slam_amd import _lib, registration as reg, synth
+from tests import replay, util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(built):
+    assert _lib.device_count() >= 1, "gpu tests need an MI355X (gfx950): the HIP path has no CPU fallback"
+
+
+def run_replay(name, monkeypatch=None):
+    r = replay.make_replay(name)
+    mode, y = r["mode"], r["y"]
+    m = reg.make_matcher(mode, y)
+    o = util.oracle_for(mode, y)
+    m.AddCloudToLocalMap(r["init_clouds"])
+    o.AddCloudToLocalMap(*r["init_clouds"])
+    slots = (0, 1) if mode == "LoamFull_KdTree" else (0,)
+    for s in slots:
+        assert m.map_size(s) == o.map_size(s), ("init", s)
+    Tprev = np.eye(4)
+    hist = []
+    for k, f in enumerate(r["frames"]):
+        guess = Tprev @ f["guess_step"]
+        T = guess.copy()
+        ok = m.Match(util.cluster_for(mode, f["scan"], f["corner"]), T, update_map=True)
+        ok_ref, T_ref = o.Match(f["scan"], guess, src1=f["corner"], update_map=True)
+        ties = int(o.counters().tie_queries)
+        util.assert_same_registration(m, o, ok, T, ok_ref, T_ref, slots=slots, sets_only_tail=(mode == "PointToPlane_IVOX"), max_tie_rows=ties)
+        assert m.stats.map_updated == o.stats.map_updated, (name, k)
+        assert m.stats.n_source == o.stats.n_source and m.stats.n_source_corner == o.stats.n_source_corner, (name, k)
+        for s in slots:
+            assert m.map_size(s) == o.map_size(s), (name, k, s, m.map_size(s), o.map_size(s))
+        hist.append(dict(ok=ok_ref, upd=int(o.stats.map_updated), size=o.map_size(0), iters=int(o.stats.iterations)))
+        Tprev = T_ref
+    m.close()
+    return r, hist
+
+
+def test_icp_mapping_replay():
+    """IcpOptimized in mapping mode: deque + pop_front, Q13 VoxelGrid of the concatenated deque, IsNeedAddCloud, Q10."""
+    r, h = run_replay("icp")
+    assert sum(x["upd"] for x in h) > r["y"]["local_map_size"], "the deque must overflow (pop_front)"
+    assert any(x["ok"] and not x["upd"] for x in h[1:]), "a converged frame must fail the keyframe gate"
+    assert any(not x["ok"] for x in h), "a frame must run out of iterations (Q10)"
+    assert all(x["upd"] == 0 for x in h if not x["ok"]), "Q10: no map update without convergence"
+
+
+def test_ndt_mapping_replay():
+    """IncrementalNDT in mapping mode: non-first-scan UpdateVoxel (min / max points, pooled mean + covariance, SVD clamp),
+    LRU eviction at the (shrunk) capacity, Q11 (map update with the input pose -- every guess differs from the result)."""
+    r, h = run_replay("ndt")
+    cap = r["y"]["ndt_capacity"]
+    assert all(x["upd"] == 1 for x in h)
+    assert h[-1]["size"] == cap - 1 and sum(1 for x in h if x["size"] == cap - 1) >= 4, "the LRU list must sit at capacity for several scans"
+
+
+def test_loam_full_mapping_replay():
+    """LoamFull: corner + planar deques, VoxelGrid once a deque holds more than five frames, keyframe gate."""
+    r, h = run_replay("loam")
+    n_upd = sum(x["upd"] for x in h)
+    assert n_upd >= 6, "more than five keyframes so that the VoxelGrid branch (loam_full_kdtree.h:92-100) fires"
+    assert any(not x["upd"] for x in h[1:]), "some frame must fail the keyframe gate"
+    sizes = [x["size"] for x in h]
+    assert any(b < a for a, b in zip(sizes, sizes[1:])), "the planar map must shrink when the VoxelGrid switches on"
+    assert h[-1]["iters"] > 0
+
+
+def test_ivox_mapping_replay_prior_map():
+    """LoamPointToPlaneIVOX on the shared scenario (same one the compiled-reference pin uses)."""
+    r, h = run_replay("ivox")
+    assert all(x["upd"] == 1 for x in h) and h[-1]["size"] > h[0]["size"]
+
+
+def test_update_map_after_match_only_upload():
+    """fls_match(update_map=0) uploads the scan without its host copy; a later
+    fls_match_resident(update_map=1) on that resident scan must either work or refuse BEFORE touching T."""
+    cfg = synth.make_config(1, scale=0.03)
+    m = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+    m.AddCloudToLocalMap([cfg["map"]])
+    cl = reg.PointcloudCluster(planar_cloud_=cfg["scan"])
+    T = np.eye(4)
+    m.Match(cl, T, update_map=False)
+    n0 = m.map_size()
+    T2 = np.eye(4)
+    ok = m.MatchResident(T2, update_map=True)  # header contract: fls_match == fls_scan_upload + fls_match_resident
+    assert ok and m.stats.map_updated == 1 and m.map_size() > n0
+    # same end state as the two fls_match calls on another handle (the second Match differs from the first one:
+    # nearest_points_ persists across Matches, Q15)
+    f = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+    f.AddCloudToLocalMap([cfg["map"]])
+    T3 = np.eye(4)
+    f.Match(cl, T3, update_map=False)
+    assert np.array_equal(T3, T)
+    T4 = np.eye(4)
+    f.Match(cl, T4, update_map=True)
+    assert np.array_equal(T4, T2) and f.map_size() == m.map_size() and f.map_size(102) == m.map_size(102)
+    m.close(); f.close()
+
+
+def test_update_map_zero_leaves_keyframe_gate_alone():
+    """a Match with update_map = 0 must not consume the keyframe gate (IsNeedAddCloud's last_T)."""
+    r = replay.make_replay("icp")
+    mode, y = r["mode"], r["y"]
+    a = reg.make_matcher(mode, y)
+    b = reg.make_matcher(mode, y)
+    for m in (a, b):
+        m.AddCloudToLocalMap(r["init_clouds"])
+    Tprev = np.eye(4)
+    for k, f in enumerate(r["frames"][:5]):
+        guess = Tprev @ f["guess_step"]
+        cl = util.cluster_for(mode, f["scan"], None)
+        Tb0 = guess.copy()
+        b.Match(cl, Tb0, update_map=False)  # an extra look without map update (e.g. a relocalisation probe) ...
+        Ta, Tb = guess.copy(), guess.copy()
+        oka = a.Match(cl, Ta, update_map=True)
+        okb = b.Match(cl, Tb, update_map=True)  # ... must not change what the real call does
+        assert oka == okb and np.array_equal(Ta, Tb), k
+        assert a.stats.map_updated == b.stats.map_updated and a.map_size() == b.map_size(), k
+        Tprev = Ta
+    a.close(); b.close()
