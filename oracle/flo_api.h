@@ -116,6 +116,8 @@ int flo_feat_extract(void* h); /* 1 = ran, 0 = fewer than 12 ordered points */
 /* copy one result array (element = 16 B xyzi, float, int32 or uint8 depending on `what`); returns its element count */
 size_t flo_feat_get(void* h, int what, void* out, size_t cap_elems);
 uint64_t flo_feat_tie_pairs(void* h);
+/* 0 (default): equal-roughness points keep index order; 1: plain std::sort = the order libstdc++ gives the reference */
+void flo_feat_set_sort_mode(void* h, int mode);
 int flo_col_index(float x, float y, float h_res, int cols);
 float flo_fast_atan2f(float y, float x);
 

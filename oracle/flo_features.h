@@ -78,6 +78,8 @@ struct FeatState {
     std::vector<uint8_t> is_corner;
     std::vector<int> corner_idx, planar_idx;  // ordered-cloud indices in emission order
     uint64_t tie_pairs = 0;
+    int sort_mode = 0;  // 0: ties keep index order (the oracle's documented choice, what the HIP kernel reproduces); 1: plain std::sort on the
+                        // same 8-byte records = the permutation libstdc++ gives the reference (pinned against oracle/_ref, tests/test_ref_pin.py)
 };
 
 // Project: pointcloud_projector.cpp:32-133.  pts: byte-strided raw points, ring per point.
@@ -180,7 +182,8 @@ static inline bool feat_extract(FeatState& s) {
             const int t = (s.row_end[size_t(scan)] - s.row_start[size_t(scan)]) / 6;
             const int b0 = s.row_start[size_t(scan)] + i * t, b1 = s.row_start[size_t(scan)] + (i + 1) * t;
             if (b0 >= b1) continue;
-            std::stable_sort(pf.begin() + b0, pf.begin() + b1, [](const PF& l, const PF& r) { return l.rough < r.rough; });
+            if (s.sort_mode == 1) std::sort(pf.begin() + b0, pf.begin() + b1, [](const PF& l, const PF& r) -> bool { return l.rough < r.rough; });
+            else std::stable_sort(pf.begin() + b0, pf.begin() + b1, [](const PF& l, const PF& r) { return l.rough < r.rough; });
             for (int j = b0 + 1; j < b1; ++j) if (pf[size_t(j)].rough == pf[size_t(j - 1)].rough) ++s.tie_pairs;
             int large = 0;
             for (int j = b1; j >= b0; --j) {  // inclusive upper bound: element b1 belongs to the next block (:151)

@@ -15,10 +15,12 @@
 // index-order loop.  Function-static state of the reference (is_first, last_T;
 // Q12) is per-instance here: parity for a job is against a fresh process.
 //
-// The reference itself cannot be compiled in this container (Eigen, PCL, FLANN,
-// glog absent) -> "parity unpinned" for everything except SO3Hat/SO3Exp/RPY,
-// which are pinned by the reference's own known-answer tests
-// (test/math_function_ut.cpp:9-133,160-192; see tests/test_oracle_so3.py).
+// Pinned by the reference's own code: oracle/ref_shim compiles the reference's registration / iVox / LOAM sources
+// verbatim against an include-shadow shim (oracle/_ref/libref.so) and tests/test_ref_pin.py compares this file with
+// it over multi-scan replays of every kind -- exact on every integer / float-only output, <= 2e-14 on FP64 ones.
+// What stays unpinned is third-party arithmetic only (Eigen's association order, PCL / FLANN internals: restated in
+// flo_linalg.h / flo_kdtree.h / flo_common.h and SHARED with the shim).  SO3Hat/SO3Exp/RPY are additionally pinned by the
+// reference's known-answer tests (test/math_function_ut.cpp:9-133,160-192; tests/test_oracle_so3.py).
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use this.
 // ============================================================================
 #include "flo_api.h"
@@ -1076,6 +1078,7 @@ int64_t flo_feat_project(void* h, const void* raw, size_t n, size_t stride, size
 }
 int flo_feat_extract(void* h) { return flo::feat_extract(*static_cast<flo::FeatState*>(h)) ? 1 : 0; }
 uint64_t flo_feat_tie_pairs(void* h) { return static_cast<flo::FeatState*>(h)->tie_pairs; }
+void flo_feat_set_sort_mode(void* h, int mode) { static_cast<flo::FeatState*>(h)->sort_mode = mode; }
 int flo_col_index(float x, float y, float h_res, int cols) { return flo::col_index(x, y, h_res, cols); }
 float flo_fast_atan2f(float y, float x) { return flo::fast_atan2f(y, x); }
 size_t flo_feat_get(void* h, int what, void* out, size_t cap) {

@@ -135,6 +135,10 @@ class OracleFeatures:
     def tie_pairs(self) -> int:
         return int(lib().flo_feat_tie_pairs(self._h))
 
+    def set_sort_mode(self, mode: int) -> None:
+        """0: ties keep index order (default, what the HIP kernel reproduces); 1: libstdc++ std::sort order (= the reference's)."""
+        lib().flo_feat_set_sort_mode(self._h, int(mode))
+
     def close(self):
         if self._h:
             lib().flo_feat_destroy(self._h)
@@ -198,6 +202,8 @@ def lib():
         L.flo_feat_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.flo_feat_tie_pairs.restype = C.c_uint64
         L.flo_feat_tie_pairs.argtypes = [C.c_void_p]
+        L.flo_feat_set_sort_mode.restype = None
+        L.flo_feat_set_sort_mode.argtypes = [C.c_void_p, C.c_int]
         L.flo_col_index.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
         L.flo_fast_atan2f.restype = C.c_float
         L.flo_fast_atan2f.argtypes = [C.c_float, C.c_float]

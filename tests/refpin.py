@@ -1,0 +1,281 @@
+"""Oracle <-> compiled-reference pin (test infrastructure).
+
+`run(engine, scenario)` drives one replay scenario (tests/replay.py) through either
+  * engine "ref":    oracle/_ref/libref.so -- the reference's own classes compiled verbatim from /root/reference
+                     against the include-shadow shim (oracle/ref_shim); must run in a FRESH process per scenario because
+                     of the reference's function-static state: use `run_ref_subprocess`;
+  * engine "oracle": oracle/liboracle.so, the CPU restatement every GPU parity test is measured against;
+and returns a per-frame record in one canonical form so the two can be compared field by field:
+  exact (integers / floats that come out of float-only arithmetic): return value, iteration count, n_valid (planar,
+      corner), n_source, map sizes, voxel count, valid flags of every point, the five neighbours of every point
+      (coordinates, in slot order), the whole local map (kd kinds: in cloud order = kd-tree index order; iVox: as a sorted
+      set), NDT voxel keys / estimated flags / point counts;
+  to a tolerance (FP64 that went through Eigen-style arithmetic, association order unpinned): pose, H, g, residual sums,
+      NDT mean / information matrices.
+Golden form (tests/golden/ref_*.npz): the tolerance fields as arrays, the exact fields as SHA-1 digests, plus a digest of
+the scenario inputs -- small enough to commit, and checkable where /root/reference (hence libref.so) is absent.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SCENARIOS = ("ivox", "ivox_lru", "icp", "ndt", "loam", "icp_loc", "kd_loc", "ivox_loc", "ndt_loc")
+IVOX_LRU_CAPACITY = 9000
+
+
+def _sha(*arrays) -> str:
+    h = hashlib.sha1()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def _sorted_rows(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a)
+    if a.shape[0] == 0:
+        return a
+    return a[np.lexsort(a.T[::-1])]
+
+
+def make_scenario(name: str) -> dict:
+    from funny_lidar_slam_amd import registration as reg, synth
+    from tests import replay
+    if name in replay.SCENARIOS:
+        r = replay.make_replay(name)
+        r["loc"] = False
+        return r
+    if name == "ivox_lru":
+        r = replay.make_replay("ivox")
+        r.update(name=name, loc=False, ivox_capacity=IVOX_LRU_CAPACITY)
+        return r
+    # localization mode: one prior map, a few scans, GetFitnessScore after every Match
+    base = {"icp_loc": ("IcpOptimized", reg.YAML_NCLT_ICP, 0, 1.0), "kd_loc": ("PointToPlane_KdTree", reg.YAML_NCLT_LOC_KDTREE, 1, 0.03),
+            "ivox_loc": ("PointToPlane_IVOX", reg.YAML_NCLT_IVOX, 1, 0.03), "ndt_loc": ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, 0.03)}[name]
+    mode, y, cid, scale = base
+    frames, init = [], None
+    for job in range(3):
+        cfg = synth.make_config(cid, job=job, scale=scale)
+        init = [cfg["map"]]
+        frames.append(dict(scan=cfg["scan"], corner=None, guess_step=np.eye(4), T_gt=cfg["T_gt"], absolute_guess=np.eye(4)))
+    return dict(name=name, mode=mode, y=y, init_clouds=init, frames=frames, loc=True)
+
+
+def scenario_digest(sc: dict) -> str:
+    arrs = list(sc["init_clouds"])
+    for f in sc["frames"]:
+        arrs += [f["scan"], f["guess_step"]] + ([f["corner"]] if f["corner"] is not None else [])
+    return _sha(*arrs)
+
+
+def run(engine: str, name: str) -> dict:
+    """Per-frame canonical records of one scenario on one engine (see module doc).  engine 'ref' only in a fresh process."""
+    from oracle import oracle as O
+    from tests import util
+    sc = make_scenario(name)
+    mode, y, loc = sc["mode"], sc["y"], sc["loc"]
+    o = util.oracle_for(mode, y, loc)  # also the source of the Params struct for the reference
+    if engine == "ref":
+        from oracle import ref as R
+        m = R.RefMatcher(o.kind, o.params)
+        o.close()
+    else:
+        m = o
+    kind = m.kind
+    if "ivox_capacity" in sc:
+        m.set_ivox_capacity(sc["ivox_capacity"])
+    m.AddCloudToLocalMap(*sc["init_clouds"])
+    slots = (0, 1) if kind == O.LOAM_FULL else (0,)
+    out = dict(digest=scenario_digest(sc), n_frames=len(sc["frames"]), init_map=[m.map_size(s) for s in slots])
+    Tprev = np.eye(4)
+    for k, f in enumerate(sc["frames"]):
+        guess = f["absolute_guess"] if "absolute_guess" in f else Tprev @ f["guess_step"]
+        if engine == "ref":
+            ok, T = m.Match(f["scan"], guess, src1=f["corner"])
+        else:
+            ok, T = m.Match(f["scan"], guess, src1=f["corner"], update_map=True)
+        rec = dict(ok=bool(ok), T=T, iters=int(m.stats.iterations), n_source=int(m.stats.n_source))
+        if kind in (O.P2PLANE_IVOX, O.LOAM_FULL, O.P2PLANE_KDTREE):
+            rec.update(n_valid=int(m.stats.n_valid), n_valid_corner=int(m.stats.n_valid_corner))
+            H, g = m.last_system()
+            rec.update(H=H, g=g, sum_res=float(m.stats.sum_res), sum_res_corner=float(m.stats.sum_res_corner))
+            for s in slots:
+                rec[f"valid{s}"] = (m.flags(s)[0] if engine == "ref" else m.correspondences(s)[2]).astype(np.uint8)
+        rec["map_size"] = [m.map_size(s) for s in slots]
+        if kind == O.P2PLANE_IVOX:
+            rec["voxels"] = m.map_voxels()
+            if engine == "ref":
+                xyzi, _ = m.map_dump(0)
+                rec["map_sorted"] = _sorted_rows(xyzi[:, :3])
+                nn, cnt, total = m.nearest()
+                rec["nn_xyz"], rec["nn_cnt"] = nn, cnt
+            else:
+                mp = m.map_dump(0)
+                rec["map_sorted"] = _sorted_rows(mp)
+                ids, cnt, _ = m.correspondences(0)
+                if "ivox_capacity" not in sc:  # insertion ids are dump rows only while nothing has been evicted
+                    nn = np.zeros((ids.shape[0], 5, 3), np.float32)
+                    sel = ids >= 0
+                    nn[sel] = mp[ids[sel]]
+                    rec["nn_xyz"] = nn
+                rec["nn_cnt"] = cnt
+        elif kind in (O.ICP_OPTIMIZED, O.P2PLANE_KDTREE, O.LOAM_FULL):
+            for s in slots:
+                rec[f"map{s}"] = (m.map_dump(s)[0][:, :3] if engine == "ref" else m.map_dump(s)).astype(np.float32)
+        elif kind == O.INCREMENTAL_NDT:
+            if engine == "ref":
+                d = m.ndt_dump()
+                order = np.lexsort(d["keys"].T[::-1])
+                rec.update(ndt_keys=d["keys"][order], ndt_mu=d["mu"][order], ndt_info=d["info"][order], ndt_est=d["est"][order], ndt_npts=d["npts"][order])
+            else:
+                keys, mu, info, est, npts = m.ndt_dump()
+                order = np.lexsort(keys.T[::-1])
+                rec.update(ndt_keys=keys[order], ndt_mu=mu[order], ndt_info=info[order], ndt_est=est[order], ndt_npts=npts[order])
+        if loc:
+            rec["fitness"] = float(m.GetFitnessScore(2.0))
+        out[k] = rec
+        Tprev = T
+    m.close()
+    return out
+
+
+EXACT_FIELDS = ("ok", "iters", "n_source", "n_valid", "n_valid_corner", "map_size", "voxels", "valid0", "valid1", "nn_xyz", "nn_cnt", "map_sorted",
+                "map0", "map1", "ndt_keys", "ndt_est", "ndt_npts")
+TOL_FIELDS = {"T": 1e-9, "H": 1e-9, "g": 1e-9, "sum_res": 1e-9, "sum_res_corner": 1e-9, "ndt_mu": 1e-9, "ndt_info": 1e-7, "fitness": 1e-6}
+
+
+def compare(a: dict, b: dict, name: str = "") -> dict:
+    """a, b: outputs of run().  Raises AssertionError on the first mismatch; returns the largest relative deviation per tolerance field."""
+    assert a["digest"] == b["digest"], f"{name}: scenario inputs differ"
+    assert a["n_frames"] == b["n_frames"] and a["init_map"] == b["init_map"], (name, a["init_map"], b["init_map"])
+    worst = {}
+    for k in range(a["n_frames"]):
+        ra, rb = a[k], b[k]
+        for fld in EXACT_FIELDS:
+            if fld in ra and fld in rb:
+                va, vb = ra[fld], rb[fld]
+                if isinstance(va, str) or isinstance(vb, str):
+                    va = va if isinstance(va, str) else _sha(va)
+                    vb = vb if isinstance(vb, str) else _sha(vb)
+                    assert va == vb, f"{name} frame {k}: {fld} digests differ"
+                elif isinstance(va, np.ndarray):
+                    assert va.shape == vb.shape and np.array_equal(va, vb), f"{name} frame {k}: {fld} differs ({int((va != vb).sum()) if va.shape == vb.shape else 'shape'})"
+                else:
+                    assert va == vb, f"{name} frame {k}: {fld} {va} != {vb}"
+        for fld, tol in TOL_FIELDS.items():
+            if fld in ra and fld in rb:
+                va, vb = np.asarray(ra[fld], float), np.asarray(rb[fld], float)
+                scale = max(1.0, float(np.abs(vb).max()) if vb.size else 1.0)
+                dev = float(np.abs(va - vb).max()) / scale if va.size else 0.0
+                worst[fld] = max(worst.get(fld, 0.0), dev)
+                assert va.shape == vb.shape and dev <= tol, f"{name} frame {k}: {fld} deviates by {dev:.3e} (tol {tol})"
+    return worst
+
+
+def to_golden(out: dict) -> dict:
+    """Flatten run() output for np.savez: tolerance fields as arrays, exact array fields as digests."""
+    g = dict(digest=np.array(out["digest"]), n_frames=np.array(out["n_frames"]), init_map=np.array(out["init_map"]))
+    for k in range(out["n_frames"]):
+        for fld, v in out[k].items():
+            if fld in ("ndt_mu", "ndt_info") and k != out["n_frames"] - 1:
+                continue  # the voxel statistics of the last frame carry every earlier update
+            if isinstance(v, np.ndarray) and fld in EXACT_FIELDS:
+                v = np.array(_sha(v))
+            g[f"f{k}_{fld}"] = np.asarray(v)
+    return g
+
+
+def from_golden(g) -> dict:
+    out = dict(digest=str(g["digest"]), n_frames=int(g["n_frames"]), init_map=[int(x) for x in g["init_map"]])
+    for k in range(out["n_frames"]):
+        rec = {}
+        pre = f"f{k}_"
+        for key in g.files if hasattr(g, "files") else g.keys():
+            if key.startswith(pre):
+                v = g[key]
+                fld = key[len(pre):]
+                if v.dtype.kind in "US":
+                    rec[fld] = str(v)
+                elif v.ndim == 0:
+                    rec[fld] = v.item()
+                elif fld == "map_size":
+                    rec[fld] = [int(x) for x in v]
+                else:
+                    rec[fld] = v
+        out[k] = rec
+    return out
+
+
+# ---- LOAM feature front-end: PointcloudProjector::Project + FeatureExtractor::ExtractFeatures ---------------------------
+FEATURE_CASES = {"velodyne64": dict(lidar="VELODYNE_64", job=3, rot=8.0, trans=1.5), "velodyne16": dict(lidar="VELODYNE_16", job=4, rot=10.0, trans=2.0),
+                 "velodyne64_shuffled": dict(lidar="VELODYNE_64", job=5, rot=3.0, trans=0.5, shuffle=True)}
+FEATURE_FIELDS = ("ordered", "depth", "col", "row_start", "row_end", "corner", "planar", "is_corner", "valid_post")
+
+
+def make_feature_case(name: str):
+    from funny_lidar_slam_amd import synth
+    c = FEATURE_CASES[name]
+    lid = getattr(synth, c["lidar"])
+    scene = synth.make_scene()
+    raw = synth.cast_raw_scan(scene, synth.random_pose(synth.rng_for(6, c["job"]), c["rot"], c["trans"]), rng=synth.rng_for(6, c["job"], 1), **lid)
+    if c.get("shuffle"):
+        raw = raw[synth.rng_for(6, c["job"], 2).permutation(raw.shape[0])]
+    params = dict(vertical_scan=lid["n_rings"], horizontal_scan=1800, horizontal_resolution=float(np.float32(0.2) / 180.0 * np.pi), min_distance=4.0,
+                  max_distance=100.0, corner_thres=1.0, planar_thres=0.1)
+    return raw, params
+
+
+def run_features(engine: str, name: str, sort_mode: int = 1) -> dict:
+    """sort_mode (oracle only): 1 = libstdc++ std::sort order inside a sector (what the compiled reference does), 0 = ties in index order."""
+    raw, params = make_feature_case(name)
+    if engine == "ref":
+        from oracle import ref as R
+        f = R.RefFeatures(**params)
+    else:
+        from oracle import oracle as O
+        f = O.OracleFeatures(**params)
+        f.set_sort_mode(sort_mode)
+    n = f.Project(raw)
+    ok = f.ExtractFeatures()
+    out = dict(digest=_sha(*[np.ascontiguousarray(raw[fn]) for fn in raw.dtype.names]), n_ordered=n, extracted=bool(ok))  # (padding bytes excluded)
+    for fld in FEATURE_FIELDS:
+        a = f.get(fld)
+        if fld in ("depth", "col"):
+            a = a[:n]  # the reference's vectors are sized rows x cols; only the first n_ordered entries are defined
+        if fld in ("is_corner", "valid_post"):
+            a = a[:n]
+        out[fld] = a
+    f.close()
+    return out
+
+
+def run_features_subprocess(name: str) -> dict:
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "out.npz")
+        subprocess.check_call([sys.executable, "-m", "tests.refpin", "features:" + name, path], cwd=ROOT)
+        with np.load(path, allow_pickle=True) as z:
+            return z["out"].item()
+
+
+def run_ref_subprocess(name: str) -> dict:
+    """engine 'ref' in a fresh interpreter (function-static state of the reference), result through a temporary .npz."""
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "out.npz")
+        subprocess.check_call([sys.executable, "-m", "tests.refpin", name, path], cwd=ROOT)
+        with np.load(path, allow_pickle=True) as z:
+            return z["out"].item()
+
+
+if __name__ == "__main__":
+    res = run_features("ref", sys.argv[1][9:]) if sys.argv[1].startswith("features:") else run("ref", sys.argv[1])
+    np.savez(sys.argv[2], out=np.array(res, dtype=object))
