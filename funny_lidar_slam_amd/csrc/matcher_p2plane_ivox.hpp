@@ -36,6 +36,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     int xcd_chunk = 8;     // workgroups per XCD chunk of the kNN block re-map (FLS_IVOX_XCD_CHUNK)
     bool balanced = true;  // equal candidate ranges per lane through an LDS voxel table (FLS_IVOX_BALANCED=0: whole voxels per lane)
     int variant = 4;       // lanes cooperating on one query in ivox_knn_kernel: 4 or 8 (FLS_IVOX_VARIANT)
+    bool prof_fit = false; // FLS_PROF_FIT=1 (diagnosis): the profiling events bracket the fit+solve kernel instead of the kNN kernel
     bool is_first = true;  // the reference's function-static flag (:62), per handle here
     const double filter_size_map_min = 0.5;  // :351
 
@@ -61,6 +62,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         init_common();
         if (const char* e = std::getenv("FLS_IVOX_VARIANT")) { const int v = std::atoi(e); if (v == 4 || v == 8) variant = v; }
         if (const char* e = std::getenv("FLS_IVOX_DENSE")) use_dense = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_PROF_FIT")) prof_fit = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_BALANCED")) balanced = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_HOST_TIMING")) host_timing = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_XCD_CHUNK")) { const int c = std::atoi(e); if (c >= 1 && c <= 4096) xcd_chunk = c; }
@@ -288,9 +290,11 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         std::memcpy(T0.m, T, sizeof(T0.m));
         const unsigned word = run_mailbox_loop(iters, n, [&](int it, int first) {
             hipEvent_t e0 = profiling ? ev[2 * it] : nullptr, e1 = profiling ? ev[2 * it + 1] : nullptr;
+            hipEvent_t f0 = nullptr, f1 = nullptr;
+            if (prof_fit) { f0 = e0; f1 = e1; e0 = e1 = nullptr; }
             if (variant == 4) launch_knn<4>(n, first, T0, g, win, e0, e1); else launch_knn<8>(n, first, T0, g, win, e0, e1);
 #define FLS_FIT(F)                                                                                                                   \
-    hipLaunchKernelGGL(p2plane_fit_solve_kernel<F>, dim3(nwg), dim3(kFitThreads), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),  \
+    hipExtLaunchKernelGGL(p2plane_fit_solve_kernel<F>, dim3(nwg), dim3(kFitThreads), 0, stream, f0, f1, 0, scan.x.p, scan.y.p, scan.z.p, int(n),  \
                        d_state.p, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,     \
                        d_ticket.p, mb_dev, match_id, p.point_to_planar_thres, p.rotation_converge_thres, p.position_converge_thres)
             if (first) FLS_FIT(true); else FLS_FIT(false);
@@ -334,7 +338,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     }
     void tune_lane(fls_matcher& l) override {
         auto& q = static_cast<P2PlaneIvoxMatcher&>(l);
-        q.use_dense = use_dense; q.variant = variant; q.balanced = balanced; q.xcd_chunk = xcd_chunk;
+        q.use_dense = use_dense; q.variant = variant; q.balanced = balanced; q.xcd_chunk = xcd_chunk; q.prof_fit = prof_fit;
     }
 
     fls_status fitness(float max_range, float* score) override {
