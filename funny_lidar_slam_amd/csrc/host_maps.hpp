@@ -180,6 +180,27 @@ public:
         return FLS_OK;
     }
 
+    // Rebuild the mirror from a downloaded device image (the device was authoritative: kernels_ivox_update.hpp).  Voxels are
+    // given in any order with their LRU stamp; the list is re-linked so that larger stamps sit nearer the head.
+    struct ImageVoxel { unsigned long long key; unsigned begin, count, cap, stamp; };
+    void rebuild_from_image(std::vector<ImageVoxel>& vox, const Pt4* pts, size_t n_points_total, int next_id_now) {
+        clear();
+        std::sort(vox.begin(), vox.end(), [](const ImageVoxel& a, const ImageVoxel& b) { return a.stamp < b.stamp; });
+        pool.resize(vox.size());
+        for (size_t i = 0; i < vox.size(); ++i) {  // ascending stamp: every link_front puts a more recent voxel in front
+            Voxel& v = pool[i];
+            v.key = vox[i].key;
+            v.pts.assign(pts + vox[i].begin, pts + vox[i].begin + vox[i].count);
+            v.alive = true; v.dirty = false;
+            v.img_begin = vox[i].begin; v.img_cap = vox[i].cap; v.img_cnt = vox[i].count;
+            link_front(int(i));
+            index.insert(v.key, int(i));
+        }
+        n_alive = vox.size();
+        n_points = n_points_total;
+        next_id = next_id_now;
+    }
+
 private:
     void link_front(int v) {
         pool[v].prev = -1; pool[v].next = head;
@@ -269,6 +290,10 @@ struct GridImage {
     DevBuf<CellUpd> d_cell_upd;
     size_t garbage = 0, n_pts_live = 0;
     bool want_hash = true;  // build the hash table too (fallback / FLS_IVOX_DENSE=0)
+    // per-cell arrays of the device-side AddPoints (kernels_ivox_update.hpp): region capacity, LRU stamp, two scratch words
+    DevBuf<unsigned char> d_cap_log2;
+    DevBuf<unsigned> d_stamp, d_pend, d_rank_mm;
+    size_t n_cells_alloc = 0;
 
     static unsigned cap_for(size_t n) {
         unsigned c = 4;
@@ -353,6 +378,36 @@ struct GridImage {
         FLS_HIP(hipStreamSynchronize(s));
         std::vector<uint2>().swap(cells);  // the device copy is authoritative from here on
         std::vector<Pt4>().swap(pts);
+    }
+
+    // Per-cell arrays of the device-side AddPoints, regenerated from the mirror (which must be in sync with the image: right after
+    // build_from_ivox or a journal update).  LRU stamps 1..n_alive from the tail (oldest) to the head.  Returns the stamp base.
+    unsigned long long upload_update_meta(const HostIvox& m, hipStream_t s) {
+        const size_t ncell = size_t(win_n[0]) * size_t(win_n[1]) * size_t(win_n[2]);
+        std::vector<unsigned char> cap(ncell, 0);
+        std::vector<unsigned> stamp(ncell, 0u);
+        unsigned long long t = 0;
+        for (int v = m.tail; v >= 0; v = m.pool[v].prev) {
+            int x, y, z;
+            unpack_key(m.pool[v].key, x, y, z);
+            size_t idx;
+            if (!cell_index(x, y, z, idx)) continue;
+            unsigned l = 0;
+            while ((1u << l) < m.pool[v].img_cap) ++l;
+            cap[idx] = (unsigned char)l;
+            stamp[idx] = unsigned(++t);
+        }
+        d_cap_log2.reserve(ncell);
+        d_stamp.reserve(ncell);
+        d_pend.reserve(ncell);
+        d_rank_mm.reserve(ncell);
+        n_cells_alloc = ncell;
+        FLS_HIP(hipMemcpyAsync(d_cap_log2.p, cap.data(), ncell, hipMemcpyHostToDevice, s));
+        FLS_HIP(hipMemcpyAsync(d_stamp.p, stamp.data(), ncell * sizeof(unsigned), hipMemcpyHostToDevice, s));
+        FLS_HIP(hipMemsetAsync(d_pend.p, 0, ncell * sizeof(unsigned), s));
+        FLS_HIP(hipMemsetAsync(d_rank_mm.p, 0xff, ncell * sizeof(unsigned), s));
+        FLS_HIP(hipStreamSynchronize(s));  // (the host vectors go out of scope)
+        return t;
     }
 
     // Collect the journal of `m` into update records.  Returns false when a full rebuild is required.

@@ -1,0 +1,312 @@
+// kernels_ivox_update.hpp -- IVoxMap::AddPoints (src/ivox_map/ivox_map.cpp:122-143) on the device, for the map update that
+// LoamPointToPlaneIVOX::Match performs in mapping mode (loam_point_to_plane_ivox.h:60-139, 205-206).  SURVEY.md 8f rank 1.
+//
+// The reference inserts sequentially: first every "points_to_add" point in source order, then every
+// "point_no_need_downsample" point in source order; a point either creates its voxel at the LRU front or is appended to it
+// (and moves it to the front); a creation that brings the voxel count to the capacity evicts the LRU tail.
+// As long as no eviction happens inside a batch, the final state is a function of the per-point SEQUENCE RANK only:
+//   * a point's insertion id            = next_id + rank
+//   * the order of points in a voxel    = rank order
+//   * the LRU order of the voxels       = order of the rank of their LAST inserted point (older voxels keep theirs): a stamp
+//   * where a grown / new voxel's slot region goes = order of the rank of its FIRST inserted point (the order in which the
+//     round-1 host mirror relocated regions, kept so that the image -- and every exact-tie decision of the kNN kernel
+//     -- is the one the host path builds)
+// so the batch is applied with prefix sums over the sequence and per-voxel atomics whose arbitrary arrival order is erased again
+// (min / max / count are order free; the slots a voxel's new points land in are sorted by id afterwards).  Deterministic.
+// Anything this path cannot do exactly -- an eviction inside the batch (voxel count reaching the capacity), a point outside
+// the dense voxel window, the point array running out of room -- is detected BEFORE any map state is touched; the batch is
+// then not applied, the status word says so and the host takes the exact sequential path (matcher_p2plane_ivox.hpp).
+//
+// Launch sequence (one stream, no host round trip; n = source points, A = points to insert):
+//   ivox_upd_count      <n>   per-block counts of the two decision codes
+//   ivox_upd_scan1      <1>   block offsets, totals
+//   ivox_upd_seq        <n>   rank, voxel cell, sequence arrays; pending count / first rank per cell (atomics)
+//   ivox_upd_plan       <A>   first-toucher flags; per touched voxel: new total, region growth, creation -> block scans
+//   ivox_upd_scan2      <1>   block offsets, totals, the all-or-nothing checks
+//   ivox_upd_last       <A>   first rank -> last rank per cell (atomicMax on the same word)
+//   ivox_upd_regions    <A>   per touched voxel: relocate if grown, new {begin, count}, capacity, touched list
+//   ivox_upd_points     <A>   write the new points
+//   ivox_upd_finish     <T>   per touched voxel: order its new points by id, stamp, reset the temporaries
+//   ivox_upd_commit     <1>   counters, status to the host-mapped word
+#pragma once
+#include "device_common.hpp"
+
+namespace fls {
+
+constexpr unsigned kUpdInvalidCell = 0xFFFFFFFFu;
+constexpr unsigned kUpdNoRank = 0xFFFFFFFFu;
+constexpr int kUpdBlock = 256;
+constexpr int kUpdMaxBlocks = 1024;  // one-workgroup scan of the block totals: n <= 262,144 source points per batch
+
+enum : unsigned { kUpdOk = 0u, kUpdNeedHost = 1u };
+
+// persistent device-side bookkeeping of the map image + the per-batch scratch words
+struct IvoxUpdState {
+    unsigned long long n_points, used, garbage, stamp_base, pts_capacity;
+    unsigned n_alive, lru_capacity;
+    int next_id;
+    unsigned status;          // of the batch in flight: kUpdOk / kUpdNeedHost (sticky inside one batch)
+    unsigned n1, n2;          // batch: points of code 1 / code 2
+    unsigned alloc, creations, touched, relocated_garbage;  // batch totals (ivox_upd_scan2)
+    unsigned apply;           // 1: the batch passes every check and is applied
+    unsigned pad;
+};
+// what the host reads back (host-mapped pinned memory, written by ivox_upd_commit)
+struct IvoxUpdMailbox {
+    unsigned long long n_points, used, garbage;
+    unsigned n_alive, status, added, touched;
+    int next_id;
+    unsigned seq;
+};
+
+struct IvoxUpdArrays {
+    uint2* cells;            // {begin, count} per window cell (the image the kNN kernel reads)
+    float4* pts;
+    unsigned char* cap_log2;  // per cell: log2 of its slot region's capacity (0: no region)
+    unsigned* stamp;         // per cell: LRU stamp of the last insertion (larger = more recent)
+    unsigned* pend;          // per cell scratch: points of this batch (0 between batches)
+    unsigned* rank_mm;       // per cell scratch: first, later last, rank of this batch (kUpdNoRank between batches)
+    int ox, oy, oz, nx, ny, nz;
+    float inv_res;
+};
+struct IvoxUpdBatch {
+    const unsigned char* code;  // [n] 0 drop, 1 points_to_add, 2 point_no_need_downsample (ivox_add_decide_kernel)
+    const float4* pw;           // [n] world points
+    int n;
+    uint2* lx;                  // [n] block-local exclusive counts {code 1, code 2}
+    uint2* bt;                  // [blocks] block totals, then block offsets
+    unsigned* seq_src;          // [A] source index of sequence rank r
+    unsigned* seq_cell;         // [A] window cell of rank r (kUpdInvalidCell: outside)
+    unsigned* jj;               // [A] arrival number of rank r inside its cell
+    uint4* px;                  // [A] block-local exclusive {alloc, creations, touched, relocated capacity} of first-touchers
+    uint4* bt2;                 // [blocks]
+    unsigned char* fbit;        // [A] 1: rank r is the first point of this batch in its cell
+    unsigned* tlist;            // [T] touched cells in first-touch order
+};
+
+__device__ __forceinline__ unsigned upd_cap_for(const unsigned n) {  // GridImage::cap_for
+    unsigned c = 4;
+    while (c < n) c <<= 1;
+    return c;
+}
+__device__ __forceinline__ unsigned upd_log2(unsigned c) { return 31u - (unsigned)__clz((int)c); }
+
+// exclusive block scan of a small vector of counters (wave shuffles + one LDS hop); returns the exclusive prefix, total in `tot`
+template <int NV>
+__device__ __forceinline__ void block_excl_scan(unsigned (&v)[NV], unsigned (&tot)[NV], unsigned (*wsum)[NV] /* LDS [waves][NV] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    unsigned inc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        unsigned x = v[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        inc[k] = x;
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) wsum[w][k] = inc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        unsigned base = 0, t = 0;
+        for (int q = 0; q < nw; ++q) { const unsigned s = wsum[q][k]; if (q < w) base += s; t += s; }
+        v[k] = base + inc[k] - v[k];
+        tot[k] = t;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_count(const IvoxUpdBatch b) {
+    __shared__ unsigned wsum[kUpdBlock / 64][2];
+    const int i = blockIdx.x * kUpdBlock + threadIdx.x;
+    const unsigned c = i < b.n ? b.code[i] : 0u;
+    unsigned v[2] = {c == 1u ? 1u : 0u, c == 2u ? 1u : 0u}, tot[2];
+    block_excl_scan<2>(v, tot, wsum);
+    if (i < b.n) b.lx[i] = make_uint2(v[0], v[1]);
+    if (threadIdx.x == 0) b.bt[blockIdx.x] = make_uint2(tot[0], tot[1]);
+}
+
+// one workgroup: exclusive scan of the block totals in place; batch totals into the state
+__global__ void __launch_bounds__(kUpdMaxBlocks)
+ivox_upd_scan1(const IvoxUpdBatch b, const int nblocks, IvoxUpdState* __restrict__ st) {
+    __shared__ unsigned wsum[kUpdMaxBlocks / 64][2];
+    const uint2 t = (int)threadIdx.x < nblocks ? b.bt[threadIdx.x] : make_uint2(0u, 0u);
+    unsigned v[2] = {t.x, t.y}, tot[2];
+    block_excl_scan<2>(v, tot, wsum);
+    if ((int)threadIdx.x < nblocks) b.bt[threadIdx.x] = make_uint2(v[0], v[1]);
+    if (threadIdx.x == 0) { st->n1 = tot[0]; st->n2 = tot[1]; st->status = kUpdOk; st->apply = 0u; }
+}
+
+// rank of every inserted point, its window cell, the sequence arrays, and the per-cell scratch (count, first rank)
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_seq(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st) {
+    const int i = blockIdx.x * kUpdBlock + threadIdx.x;
+    if (i >= b.n) return;
+    const unsigned c = b.code[i];
+    if (c == 0u) return;
+    const uint2 l = b.lx[i], base = b.bt[blockIdx.x];
+    const unsigned r = c == 1u ? base.x + l.x : st->n1 + base.y + l.y;
+    const float4 p = b.pw[i];
+    // IVoxMap::Pos2Grid (ivox_map.cpp:145-147): round half away from zero of the float product
+    const float fx = roundf(p.x * a.inv_res), fy = roundf(p.y * a.inv_res), fz = roundf(p.z * a.inv_res);
+    unsigned cell = kUpdInvalidCell;
+    if (fabsf(fx) < (float)kKeyLimit && fabsf(fy) < (float)kKeyLimit && fabsf(fz) < (float)kKeyLimit) {
+        const int cx = (int)fx - a.ox, cy = (int)fy - a.oy, cz = (int)fz - a.oz;
+        if ((unsigned)cx < (unsigned)a.nx && (unsigned)cy < (unsigned)a.ny && (unsigned)cz < (unsigned)a.nz)
+            cell = (unsigned)((cz * a.ny + cy) * a.nx + cx);
+    }
+    b.seq_src[r] = (unsigned)i;
+    b.seq_cell[r] = cell;
+    if (cell == kUpdInvalidCell) { atomicOr(&st->status, kUpdNeedHost); b.jj[r] = 0u; return; }
+    b.jj[r] = atomicAdd(&a.pend[cell], 1u);
+    atomicMin(&a.rank_mm[cell], r);
+}
+
+// first-toucher flags and, per touched voxel, what the batch does to it; block-local scans of the four counters
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_plan(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState* __restrict__ st) {
+    __shared__ unsigned wsum[kUpdBlock / 64][4];
+    const unsigned A = st->n1 + st->n2;
+    const unsigned r = blockIdx.x * kUpdBlock + threadIdx.x;
+    unsigned v[4] = {0u, 0u, 0u, 0u}, tot[4];
+    bool first = false;
+    if (r < A) {
+        const unsigned cell = b.seq_cell[r];
+        if (cell != kUpdInvalidCell && a.rank_mm[cell] == r) {
+            first = true;
+            const uint2 old = a.cells[cell];
+            const unsigned total = old.y + a.pend[cell];
+            const unsigned cl = a.cap_log2[cell];
+            const unsigned cap = cl ? (1u << cl) : 0u;
+            const bool grow = total > cap;
+            v[0] = grow ? upd_cap_for(total) : 0u;
+            v[1] = old.y == 0u ? 1u : 0u;
+            v[2] = 1u;
+            v[3] = grow ? cap : 0u;
+        }
+        b.fbit[r] = first ? 1 : 0;
+    }
+    block_excl_scan<4>(v, tot, wsum);
+    if (r < A) b.px[r] = make_uint4(v[0], v[1], v[2], v[3]);
+    if (threadIdx.x == 0) b.bt2[blockIdx.x] = make_uint4(tot[0], tot[1], tot[2], tot[3]);
+}
+
+__global__ void __launch_bounds__(kUpdMaxBlocks)
+ivox_upd_scan2(const IvoxUpdBatch b, IvoxUpdState* __restrict__ st) {
+    __shared__ unsigned wsum[kUpdMaxBlocks / 64][4];
+    const unsigned A = st->n1 + st->n2;
+    const int nblocks = (int)((A + kUpdBlock - 1) / kUpdBlock);
+    const uint4 t = (int)threadIdx.x < nblocks ? b.bt2[threadIdx.x] : make_uint4(0u, 0u, 0u, 0u);
+    unsigned v[4] = {t.x, t.y, t.z, t.w}, tot[4];
+    block_excl_scan<4>(v, tot, wsum);
+    if ((int)threadIdx.x < nblocks) b.bt2[threadIdx.x] = make_uint4(v[0], v[1], v[2], v[3]);
+    if (threadIdx.x == 0) {
+        st->alloc = tot[0]; st->creations = tot[1]; st->touched = tot[2]; st->relocated_garbage = tot[3];
+        unsigned status = st->status;
+        // all-or-nothing: room in the point array, and no LRU eviction inside the batch (ivox_map.cpp:133-136 evicts when the
+        // count REACHES the capacity after a creation)
+        if (st->used + (unsigned long long)tot[0] > st->pts_capacity) status |= kUpdNeedHost;
+        if ((unsigned long long)st->n_alive + tot[1] >= (unsigned long long)st->lru_capacity) status |= kUpdNeedHost;
+        st->status = status;
+        st->apply = status == kUpdOk ? 1u : 0u;
+    }
+}
+
+// the scratch word of every touched cell turns from the FIRST into the LAST rank of the batch (max >= min: one atomicMax);
+// a batch that is not applied only resets its scratch
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_last(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState* __restrict__ st) {
+    const unsigned A = st->n1 + st->n2;
+    const unsigned r = blockIdx.x * kUpdBlock + threadIdx.x;
+    if (r >= A) return;
+    const unsigned cell = b.seq_cell[r];
+    if (cell == kUpdInvalidCell) return;
+    if (st->apply) atomicMax(&a.rank_mm[cell], r);
+    else { a.pend[cell] = 0u; a.rank_mm[cell] = kUpdNoRank; }  // (the same values from every point of the cell)
+}
+
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_regions(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState* __restrict__ st) {
+    if (!st->apply) return;
+    const unsigned A = st->n1 + st->n2;
+    const unsigned r = blockIdx.x * kUpdBlock + threadIdx.x;
+    if (r >= A || !b.fbit[r]) return;
+    const unsigned cell = b.seq_cell[r];
+    const uint4 loc = b.px[r], base = b.bt2[blockIdx.x];
+    const uint2 old = a.cells[cell];
+    const unsigned total = old.y + a.pend[cell];
+    const unsigned cl = a.cap_log2[cell];
+    const unsigned cap = cl ? (1u << cl) : 0u;
+    unsigned begin = old.x;
+    if (total > cap) {  // grown past its region (or new): a fresh region at the end of the array, in first-touch order
+        const unsigned ncap = upd_cap_for(total);
+        begin = (unsigned)st->used + base.x + loc.x;
+        for (unsigned k = 0; k < old.y; ++k) a.pts[begin + k] = a.pts[old.x + k];
+        for (unsigned k = total; k < ncap; ++k) a.pts[begin + k] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // slack
+        a.cap_log2[cell] = (unsigned char)upd_log2(ncap);
+    }
+    a.cells[cell] = make_uint2(begin, total);
+    b.tlist[base.z + loc.z] = cell;
+}
+
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_points(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState* __restrict__ st) {
+    if (!st->apply) return;
+    const unsigned A = st->n1 + st->n2;
+    const unsigned r = blockIdx.x * kUpdBlock + threadIdx.x;
+    if (r >= A) return;
+    const unsigned cell = b.seq_cell[r];
+    const uint2 e = a.cells[cell];
+    const float4 p = b.pw[b.seq_src[r]];
+    a.pts[e.x + (e.y - a.pend[cell]) + b.jj[r]] = make_float4(p.x, p.y, p.z, __int_as_float(st->next_id + (int)r));
+}
+
+// per touched voxel: its new points into insertion (id) order, LRU stamp, scratch reset
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_finish(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState* __restrict__ st) {
+    if (!st->apply) return;
+    const unsigned t = blockIdx.x * kUpdBlock + threadIdx.x;
+    if (t >= st->touched) return;
+    const unsigned cell = b.tlist[t];
+    const uint2 e = a.cells[cell];
+    const unsigned k = a.pend[cell];
+    float4* const q = a.pts + e.x + (e.y - k);
+    for (unsigned i = 1; i < k; ++i) {  // insertion sort by id (k is the handful of points one scan adds to one voxel)
+        const float4 x = q[i];
+        const int id = __float_as_int(x.w);
+        unsigned j = i;
+        while (j > 0 && __float_as_int(q[j - 1].w) > id) { q[j] = q[j - 1]; --j; }
+        q[j] = x;
+    }
+    a.stamp[cell] = (unsigned)(st->stamp_base + a.rank_mm[cell] + 1ull);
+    a.pend[cell] = 0u;
+    a.rank_mm[cell] = kUpdNoRank;
+}
+
+__global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* __restrict__ mb, const unsigned seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned A = st->n1 + st->n2;
+    if (st->apply) {
+        st->n_alive += st->creations;
+        st->n_points += A;
+        st->next_id += (int)A;
+        st->used += st->alloc;
+        st->garbage += st->relocated_garbage;
+        st->stamp_base += A;
+    }
+    __hip_atomic_store(&mb->n_points, st->n_points, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mb->used, st->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mb->garbage, st->garbage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mb->n_alive, st->n_alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mb->status, st->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mb->added, st->apply ? A : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mb->touched, st->touched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mb->next_id, st->next_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace fls

@@ -11,6 +11,7 @@
 #include "kernels_p2plane.hpp"
 #include "kernels_knn.hpp"
 #include "kernels_ivox_coop.hpp"
+#include "kernels_ivox_update.hpp"
 #include "fitness_host.hpp"
 #include <thread>
 #include <chrono>
@@ -26,6 +27,21 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     // a batch lane (fls_match_batch) reads its owner's resident map image
     const GridImage* borrowed = nullptr;
     bool host_timing = false;  // FLS_HOST_TIMING=1: print the host-side cost of every map update
+    // ---- device-side AddPoints (kernels_ivox_update.hpp): while `device_map` is set the DEVICE image is the authoritative map
+    // (points, voxel table, LRU stamps, counters) and the host mirror `ivox` is stale; sync_host_from_device() brings it back.
+    bool device_map = false;
+    bool allow_device_map = true;  // FLS_IVOX_DEVICE_UPDATE=0: always the host path (A/B)
+    size_t device_margin = 4096;   // voxels of head-room below the LRU capacity required to (re-)enter device mode (FLS_IVOX_DEVICE_MARGIN: test hook)
+    size_t n_device_updates = 0, n_host_fallbacks = 0;
+    DevBuf<IvoxUpdState> d_upd_state;
+    IvoxUpdMailbox* upd_mb_host = nullptr;
+    IvoxUpdMailbox* upd_mb_dev = nullptr;
+    unsigned upd_seq = 0;
+    size_t dev_n_points = 0, dev_n_alive = 0;  // mirrored from the update mailbox
+    DevBuf<uint2> d_lx, d_bt;
+    DevBuf<unsigned> d_seq_src, d_seq_cell, d_jj, d_tlist;
+    DevBuf<uint4> d_px, d_bt2;
+    DevBuf<unsigned char> d_fbit;
     PinnedBuf<char> upd_stage;
     DevBuf<unsigned char> d_code;
     DevBuf<float4> d_pw;
@@ -56,6 +72,10 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     std::vector<Pt4> h_nn;
     std::vector<unsigned char> h_cnt, h_flag;
 
+    ~P2PlaneIvoxMatcher() override {
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (upd_mb_host) (void)hipHostFree(upd_mb_host);
+    }
     fls_status init() {
         if (unset_d(p.point_to_planar_thres) || unset_d(p.position_converge_thres) || unset_d(p.rotation_converge_thres))
             return FLS_ERR_INVALID;  // CHECK_NE(..., max()) at :45-48
@@ -65,6 +85,12 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (const char* e = std::getenv("FLS_PROF_FIT")) prof_fit = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_BALANCED")) balanced = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_HOST_TIMING")) host_timing = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_IVOX_DEVICE_UPDATE")) allow_device_map = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_IVOX_DEVICE_MARGIN")) { const long c = std::atol(e); if (c >= 0) device_margin = size_t(c); }
+        d_upd_state.reserve(1);
+        FLS_HIP(hipHostMalloc((void**)&upd_mb_host, sizeof(IvoxUpdMailbox), hipHostMallocMapped));
+        std::memset(upd_mb_host, 0, sizeof(IvoxUpdMailbox));
+        FLS_HIP(hipHostGetDevicePointer((void**)&upd_mb_dev, upd_mb_host, 0));
         if (const char* e = std::getenv("FLS_IVOX_XCD_CHUNK")) { const int c = std::atoi(e); if (c >= 1 && c <= 4096) xcd_chunk = c; }
         d_ticket.reserve(1);
         FLS_HIP(hipMemsetAsync(d_ticket.p, 0, sizeof(unsigned), stream));
@@ -104,6 +130,101 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             ++n_full_rebuilds;
         }
         image_dirty = false;
+        enter_device_mode();
+    }
+
+    // Hand the map over to the device-side AddPoints when that path can be exact: dense voxel window, and the LRU capacity far
+    // enough away that the next batches will not evict (a batch that would is refused by the device and replayed on the host).
+    void enter_device_mode() {
+        device_map = false;
+        if (!allow_device_map || borrowed || !use_dense || !image.have_window || image.want_hash || p.is_localization_mode) return;
+        if (ivox.n_alive + device_margin >= ivox.capacity) return;  // evictions are near: the host path is the exact one
+        const unsigned long long stamp_base = image.upload_update_meta(ivox, stream);
+        IvoxUpdState st{};
+        st.n_points = ivox.n_points; st.used = image.used; st.garbage = image.garbage; st.stamp_base = stamp_base;
+        st.pts_capacity = image.d_pts.cap; st.n_alive = unsigned(ivox.n_alive); st.lru_capacity = unsigned(std::min<size_t>(ivox.capacity, 0xffffffffu));
+        st.next_id = ivox.next_id;
+        FLS_HIP(hipMemcpyAsync(d_upd_state.p, &st, sizeof(st), hipMemcpyHostToDevice, stream));
+        FLS_HIP(hipStreamSynchronize(stream));
+        dev_n_points = ivox.n_points; dev_n_alive = ivox.n_alive;
+        device_map = true;
+    }
+
+    // The device image back into the host mirror (device mode ends): voxel table, points, LRU order from the stamps.
+    void sync_host_from_device() {
+        if (!device_map) return;
+        IvoxUpdState st{};
+        FLS_HIP(hipMemcpyAsync(&st, d_upd_state.p, sizeof(st), hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipStreamSynchronize(stream));
+        const size_t ncell = image.n_cells_alloc;
+        std::vector<uint2> cells(ncell);
+        std::vector<unsigned> stamp(ncell);
+        std::vector<unsigned char> cap(ncell);
+        std::vector<Pt4> pts(st.used);
+        FLS_HIP(hipMemcpyAsync(cells.data(), image.d_cells.p, ncell * sizeof(uint2), hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipMemcpyAsync(stamp.data(), image.d_stamp.p, ncell * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipMemcpyAsync(cap.data(), image.d_cap_log2.p, ncell, hipMemcpyDeviceToHost, stream));
+        if (st.used) FLS_HIP(hipMemcpyAsync(pts.data(), image.d_pts.p, st.used * sizeof(Pt4), hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipStreamSynchronize(stream));
+        std::vector<HostIvox::ImageVoxel> vox;
+        vox.reserve(st.n_alive);
+        const int nx = image.win_n[0], ny = image.win_n[1];
+        for (size_t idx = 0; idx < ncell; ++idx) {
+            if (cells[idx].y == 0u) continue;
+            const int cx = int(idx % size_t(nx)), cy = int((idx / size_t(nx)) % size_t(ny)), cz = int(idx / (size_t(nx) * size_t(ny)));
+            vox.push_back(HostIvox::ImageVoxel{pack_key(cx + image.win_o[0], cy + image.win_o[1], cz + image.win_o[2]), cells[idx].x, cells[idx].y,
+                                               cap[idx] ? (1u << cap[idx]) : 0u, stamp[idx]});
+        }
+        const float res = ivox.resolution, inv = ivox.inv_resolution;
+        const size_t capacity = ivox.capacity;
+        ivox.rebuild_from_image(vox, pts.data(), size_t(st.n_points), st.next_id);
+        ivox.resolution = res; ivox.inv_resolution = inv; ivox.capacity = capacity;
+        image.used = size_t(st.used);
+        image.garbage = size_t(st.garbage);
+        image.n_pts_live = size_t(st.n_points);
+        device_map = false;
+    }
+
+    // One batch of the resident scan through the device-side AddPoints.  Returns true when the device applied it.
+    bool device_add_points(const size_t n) {
+        const int nb = int((n + kUpdBlock - 1) / kUpdBlock);
+        if (nb > kUpdMaxBlocks) return false;
+        d_lx.reserve(n); d_bt.reserve(size_t(nb)); d_seq_src.reserve(n); d_seq_cell.reserve(n); d_jj.reserve(n); d_tlist.reserve(n);
+        d_px.reserve(n); d_bt2.reserve(size_t(nb)); d_fbit.reserve(n);
+        const IvoxUpdBatch b{d_code.p, d_pw.p, int(n), d_lx.p, d_bt.p, d_seq_src.p, d_seq_cell.p, d_jj.p, d_px.p, d_bt2.p, d_fbit.p, d_tlist.p};
+        const IvoxUpdArrays a{image.d_cells.p, image.d_pts.p, image.d_cap_log2.p, image.d_stamp.p, image.d_pend.p, image.d_rank_mm.p,
+                              image.win_o[0], image.win_o[1], image.win_o[2], image.win_n[0], image.win_n[1], image.win_n[2], ivox.inv_resolution};
+        upd_seq = (upd_seq + 1u) & 0x7fffffffu;
+        if (upd_seq == 0u) upd_seq = 1u;
+        const dim3 g{unsigned(nb), 1u, 1u}, t{unsigned(kUpdBlock), 1u, 1u};
+        hipLaunchKernelGGL(ivox_upd_count, g, t, 0, stream, b);
+        hipLaunchKernelGGL(ivox_upd_scan1, dim3(1), dim3(kUpdMaxBlocks), 0, stream, b, nb, d_upd_state.p);
+        hipLaunchKernelGGL(ivox_upd_seq, g, t, 0, stream, b, a, d_upd_state.p);
+        hipLaunchKernelGGL(ivox_upd_plan, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
+        hipLaunchKernelGGL(ivox_upd_scan2, dim3(1), dim3(kUpdMaxBlocks), 0, stream, b, d_upd_state.p);
+        hipLaunchKernelGGL(ivox_upd_last, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
+        hipLaunchKernelGGL(ivox_upd_regions, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
+        hipLaunchKernelGGL(ivox_upd_points, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
+        hipLaunchKernelGGL(ivox_upd_finish, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
+        hipLaunchKernelGGL(ivox_upd_commit, dim3(1), dim3(64), 0, stream, d_upd_state.p, upd_mb_dev, upd_seq);
+        FLS_HIP(hipGetLastError());
+        // the verdict of the batch (a few words in host-mapped memory; no copy, no stream synchronisation)
+        for (unsigned long long spin = 1;; ++spin) {
+            if (__atomic_load_n(&upd_mb_host->seq, __ATOMIC_ACQUIRE) == upd_seq) break;
+            if ((spin & 0x3fffu) == 0) {
+                const hipError_t q = hipStreamQuery(stream);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) FLS_HIP(q);
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (upd_mb_host->status != kUpdOk) return false;
+        dev_n_points = size_t(upd_mb_host->n_points);
+        dev_n_alive = size_t(upd_mb_host->n_alive);
+        ++n_device_updates;
+        return true;
     }
 
     // pcl::transformPoint with Affine3d(T_): double evaluation, float result
@@ -133,8 +254,9 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     }
 
     fls_status add_cloud_impl(const std::vector<PtI>& planar_cloud, const bool from_resident_scan = false) {
-        if (p.is_localization_mode) { is_first = true; ivox.clear(); image_built = false; }
+        if (p.is_localization_mode) { device_map = false; is_first = true; ivox.clear(); image_built = false; }
         fls_status rc = FLS_OK;
+        if (!(from_resident_scan && !is_first)) sync_host_from_device();  // every other branch works on the host mirror
         if (is_first) {
             rc = ivox.add_points(planar_cloud.data(), planar_cloud.size());
             if (rc != FLS_OK) return rc;
@@ -156,6 +278,18 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
                                    int(n), Tw, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, int(nn_n), filter_size_map_min,
                                    d_code.p, d_pw.p);
                 FLS_HIP(hipGetLastError());
+                if (device_map) {
+                    if (device_add_points(n)) {
+                        if (host_timing)
+                            std::fprintf(stderr, "[fls host] device AddPoints: %u points into %u voxels, %.3f ms\n", upd_mb_host->added, upd_mb_host->touched,
+                                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count());
+                        return FLS_OK;
+                    }
+                    // refused (an eviction inside the batch, a point outside the voxel window, the point array full): nothing was
+                    // applied; the exact sequential path below replays the batch on the host mirror
+                    ++n_host_fallbacks;
+                    sync_host_from_device();
+                }
                 FLS_HIP(hipMemcpyAsync(h_code.data(), d_code.p, n, hipMemcpyDeviceToHost, stream));
                 FLS_HIP(hipMemcpyAsync(h_pw.data(), d_pw.p, n * sizeof(float4), hipMemcpyDeviceToHost, stream));
                 FLS_HIP(hipStreamSynchronize(stream));
@@ -365,8 +499,10 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     size_t map_size(int slot) const override {
         if (slot == 100) return n_incremental;    // introspection: image updates applied as scatter lists
         if (slot == 101) return n_full_rebuilds;  //                ... as full re-flatten + upload
-        if (slot == 102) return ivox.n_alive;     // occupied voxels
-        return ivox.n_points;
+        if (slot == 103) return n_device_updates;  //                ... by the device-side AddPoints
+        if (slot == 104) return n_host_fallbacks;  //                batches the device refused (replayed on the host)
+        if (slot == 102) return device_map ? dev_n_alive : ivox.n_alive;     // occupied voxels
+        return device_map ? dev_n_points : ivox.n_points;
     }
 };
 

@@ -113,19 +113,23 @@ def test_pcl_layout_stride8_equals_packed():
     assert np.array_equal(res[0], res[1])
 
 
-def _replay(n_scans, capacity=None, monkeypatch=None):
+def _replay(n_scans, capacity=None, monkeypatch=None, capacity_over_initial=None):
     """Mapping-mode replay along a short trajectory: Match -> AddCloudToLocalMap rule -> next Match."""
     scene = synth.make_scene()
     rng = synth.rng_for(1, 11)
     radius = 30.0
     mp = synth.sample_map(scene, 60000, synth.rng_for(1, 0, 5), radius=radius)
     lid = dict(synth.VELODYNE_64, n_az=60)
+    o = util.oracle_for("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+    if capacity_over_initial is not None:  # LRU capacity = voxels of the initial map + this many (the reference hard-codes 1e6)
+        probe = util.oracle_for("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+        probe.AddCloudToLocalMap(mp)
+        capacity = probe.map_voxels() + capacity_over_initial
+        probe.close()
     if capacity is not None:
         monkeypatch.setenv("FLS_IVOX_CAPACITY", str(capacity))
-    m = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
-    o = util.oracle_for("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
-    if capacity is not None:
         o.set_ivox_capacity(capacity)
+    m = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
     m.AddCloudToLocalMap([mp])
     o.AddCloudToLocalMap(mp)
     assert m.map_size() == o.map_size() and m.map_size(102) == o.map_voxels()
@@ -145,12 +149,32 @@ def _replay(n_scans, capacity=None, monkeypatch=None):
 
 
 def test_mapping_replay_incremental_image_updates():
-    """8 scans with map growth: the device image is maintained by scatter updates (no full re-flatten after the
-    first build) and every Match still agrees with the oracle bit-for-bit in its correspondences."""
+    """8 scans with map growth: IVoxMap::AddPoints runs on the device (kernels_ivox_update.hpp: no per-scan read-back of
+    decisions, no host insert, no re-flatten after the first build) and every Match still agrees with the oracle bit for bit
+    in its correspondences -- ids included, i.e. the device assigns the reference's insertion order."""
     m, o = _replay(8)
-    assert m.map_size(100) >= 7, "map updates should be incremental"
+    assert m.map_size(103) >= 7, "every map update should run on the device"
+    assert m.map_size(104) == 0, "no batch refused by the device"
     assert m.map_size(101) == 1, "only the initial build is a full flatten"
     assert m.map_size() > 60000
+
+
+def test_mapping_replay_host_path_ab(monkeypatch):
+    """The exact sequential host path (FLS_IVOX_DEVICE_UPDATE=0, the round-1 path and the fallback of the device path)."""
+    monkeypatch.setenv("FLS_IVOX_DEVICE_UPDATE", "0")
+    m, o = _replay(4)
+    assert m.map_size(103) == 0 and m.map_size(100) >= 3
+
+
+def test_mapping_replay_device_refuses_batch_that_would_evict(monkeypatch):
+    """LRU capacity a little above the initial map: the first scans are applied by the device; the batch whose voxel creations
+    would reach the capacity is refused BEFORE any state changes, the device image (points, voxel table, LRU stamps) is read back
+    into the host mirror and the exact sequential path -- with evictions -- takes over.  Parity with the oracle throughout."""
+    monkeypatch.setenv("FLS_IVOX_DEVICE_MARGIN", "64")  # (head-room below the capacity needed to run on the device; default 4096)
+    m, o = _replay(8, monkeypatch=monkeypatch, capacity_over_initial=64 + 250)  # the scenario creates 86, 145, 190, ... 473 voxels
+    assert m.map_size(103) >= 1, "some batches must have run on the device"
+    assert m.map_size(104) >= 1, "a batch must have been refused and replayed on the host"
+    assert m.map_size(102) == o.map_voxels()
 
 
 def test_mapping_replay_with_lru_eviction(monkeypatch):

@@ -18,7 +18,7 @@ for k in range(6):
     ms, nl, pi = m.kernel_time(); m.set_profiling(False)
     print(f'   first call {1e6*t_match0:.1f} us; second call {1e6*t_match:.1f} us; knn kernel avg {1e3*ms/max(nl,1):.1f} us over {nl} launches')
     T = guess.copy(); t = time.perf_counter(); ok = m.MatchResident(T, update_map=True); t_both = time.perf_counter() - t
-    print(f"scan {k}: match {1e6*t_match:8.1f} us, match+map update {1e6*t_both:9.1f} us, iters {m.stats.iterations}, map pts {m.map_size()}, "
-          f"incremental {m.map_size(100)}, full rebuilds {m.map_size(101)}")
+    print(f"scan {k}: match {1e6*t_match:8.1f} us, match+map update {1e6*t_both:9.1f} us, iters {m.stats.iterations}, map pts {m.map_size()}, voxels {m.map_size(102)}, "
+          f"device updates {m.map_size(103)}, refused {m.map_size(104)}, host incremental {m.map_size(100)}, full rebuilds {m.map_size(101)}")
     guess = T
     Tgt = Tgt @ synth.random_pose(rng, 0.5, 0.5)
