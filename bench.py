@@ -10,24 +10,32 @@ against the 1e6-point iVox map with ``LoamPointToPlaneIVOX`` semantics = BASELIN
 configs[1].  The scan and the map are resident in HBM before the timed region.  With N GPUs
 every rank registers the SAME scan against a replica of the map (identical work per GPU, so
 that value(N) / N is comparable with value(1); independent jobs, no data-path collective;
-"scaling": "weak"); the only collectives are the start/stop barriers, the MAX of the
-per-rank times and the gather of the poses.
+"scaling": "weak"); rank 0 builds the map once, its image is broadcast (RCCL) and imported by
+the other ranks; the only other collectives are the start/stop barriers, the MAX
+of the per-rank times and the gather of the poses.
 
-Extra objects on the line:
-  roofline      HBM-bound correspondence kernel: algorithmic bytes per launch (SURVEY.md 8d
-                formula, counters counted on the device) / average launch duration measured
-                with hipEvents on the handle's own stream during the timed region.
-  c5_batch      BASELINE configs[4] shape: 64 independent scan-to-map jobs per GPU (8 distinct scans cycled)
-                through fls_match_batch on 4 stream lanes, host-to-device scan upload and the gather of the
-                result table (RCCL all_gather for N > 1) inside the timed region.
-  cpu_baseline  the CPU oracle (a port of the reference algorithm, the reference itself needs
-                Eigen/PCL/ROS and cannot be built here) timed on this box's host cores on the
-                same workload, rank 0, N=1 only.
+Extra objects on the line (SURVEY.md 8d):
+  roofline      the correspondence kernel of the headline path: algorithmic bytes per launch (8d formula, counters
+                counted on the device and checked against the oracle's) / average launch duration measured with
+                hipEvents attached to the kernel's own dispatch packet during the timed region; `traffic` = HBM
+                bytes per launch from the committed rocprofv3 PMC passes; `detail` = what actually limits the kernel.
+  pose_err_vs_oracle   |dt| [m], |dR| [rad] of the GPU result against the CPU oracle's on the same inputs.
+  configs       BASELINE configs[0], [2], [3] (Optimized-ICP, Incremental-NDT, LOAM line + plane) at full size:
+                scans/s, iterations, 8d roofline of their correspondence launches, CPU oracle next to them.
+  mapping_mode  what the plug-in actually issues (Match + the map update inside it): ms per scan with the
+                device-side AddPoints, and with the exact host path.
+  inclusive_h2d fls_match from host buffers (de-interleave + PCIe copy inside the call).
+  c5_batch      BASELINE configs[4]: 512 independent scan-to-map jobs (64 per GPU at 8 GPUs; distinct scans, one per job)
+                block-partitioned over the ranks, fls_match_batch on 4 stream lanes, host-to-device scan upload and the
+                gather of the result table inside the timed region.
+  cpu_baseline  the CPU oracle (a port of the reference algorithm, pinned against the reference's own compiled code:
+                tests/test_ref_pin.py) timed on this box's host cores on the headline workload, rank 0, N = 1 only.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import multiprocessing as mp
 import os
 import sys
 import time
@@ -45,13 +53,47 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def algorithmic_bytes(point_iters, probes, hits, cand):
-    """12 (src xyz) + 16/probe + 8/hit voxel + 12/candidate point + 24 (5 idx + flag)."""
-    return 12 * point_iters + 16 * probes + 8 * hits + 12 * cand + 24 * point_iters
+def algorithmic_bytes(point_iters, probes, hits, cand, per_probe=16, per_hit=8, per_cand=12, out=24):
+    """12 (src xyz) + per_probe/probe + per_hit/hit voxel + per_cand/candidate + out (indices / flags) per point-iteration."""
+    return 12 * point_iters + per_probe * probes + per_hit * hits + per_cand * cand + out * point_iters
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[4] scans: one distinct seeded scan per job, ray-cast on the host cores in parallel BEFORE HIP initialises
+# ---------------------------------------------------------------------------------------------------------------------
+def _cast_job(job: int):
+    from funny_lidar_slam_amd import synth
+    scene = synth.make_scene()
+    T_gt = synth.random_pose(synth.rng_for(4, job))
+    return synth.cast_scan(scene, T_gt, rng=synth.rng_for(4, job, salt=7), **synth.VELODYNE_64)
+
+
+def make_batch_scans(job_ids):
+    if not len(job_ids):
+        return []
+    workers = max(1, min(len(job_ids), (os.cpu_count() or 8) // 2, 64))
+    if workers == 1:
+        return [_cast_job(j) for j in job_ids]
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(_cast_job, list(job_ids), chunksize=max(1, len(job_ids) // (4 * workers)))
+
+
+def timed_oracle(make, run, budget_s, max_reps=40):
+    """median seconds of run(o) over a bounded number of repetitions on a fresh oracle from make()."""
+    o = make()
+    times = []
+    t_start = time.perf_counter()
+    for rep in range(max_reps):
+        t0 = time.perf_counter()
+        run(o)
+        times.append(time.perf_counter() - t0)
+        if rep >= 2 and time.perf_counter() - t_start > budget_s:
+            break
+    return float(np.median(times[1:] if len(times) > 1 else times)), len(times), o
 
 
 def cpu_baseline(cfg, y, budget_s=20.0):
-    """Time the CPU oracle on the same scan/map (bounded: a few Match calls)."""
+    """Time the CPU oracle on the headline scan / map (bounded), instrumentation off, best thread count."""
     from oracle import oracle as O
 
     ncpu = os.cpu_count() or 1
@@ -60,30 +102,158 @@ def cpu_baseline(cfg, y, budget_s=20.0):
     # allocations cap the scaling, so a few thread counts are tried and the best is reported
     for thr in sorted({min(ncpu, t) for t in (16, 32, 64, ncpu)}):
         O.set_threads(thr)
-        o = O.OracleMatcher(O.P2PLANE_IVOX, O.Params(max_iterations=y["optimization_iter_num"],
-                                                      point_to_planar_thres=y["point_to_planar_thres"],
-                                                      position_converge_thres=y["position_converge_thres"],
-                                                      rotation_converge_thres=y["rotation_converge_thres"]))
-        o.AddCloudToLocalMap(cfg["map"])
-        times = []
-        t_start = time.perf_counter()
-        for rep in range(40):
-            # nearest_points_ persists across Match calls in the reference (quirk), so a fresh
-            # instance per repetition would re-insert the map; the stale lists only matter for
-            # points without any candidate, keep one instance and accept that (same work).
-            t0 = time.perf_counter()
-            o.Match(cfg["scan"], cfg["T_init"], update_map=False)
-            times.append(time.perf_counter() - t0)
-            if rep >= 3 and time.perf_counter() - t_start > budget_s / 4:  # about budget_s of CPU work over the four thread counts
-                break
-        t = float(np.median(times[1:] if len(times) > 1 else times))
+
+        def make():
+            o = O.OracleMatcher(O.P2PLANE_IVOX, O.Params(max_iterations=y["optimization_iter_num"], point_to_planar_thres=y["point_to_planar_thres"],
+                                                          position_converge_thres=y["position_converge_thres"],
+                                                          rotation_converge_thres=y["rotation_converge_thres"]))
+            o.AddCloudToLocalMap(cfg["map"])
+            o.set_instrumentation(False)  # no traffic / tie bookkeeping inside the timed kNN stage
+            return o
+
+        # (nearest_points_ persists across Match calls in the reference, so one instance is re-used: same work per call)
+        t, reps, o = timed_oracle(make, lambda o: o.Match(cfg["scan"], cfg["T_init"], update_map=False), budget_s / 4)
         if best is None or t < best[0]:
-            best = (t, thr, o.stats.iterations, len(times))
+            best = (t, thr, o.stats.iterations, reps)
         o.close()
+    O.set_threads(0)
     t, thr, iters, reps = best
     return {"value": 1.0 / t, "unit": "scans/s", "cores": thr, "kind": "port",
             "sample": f"{reps} Match calls (median; {budget_s:.0f} s budget over the thread counts tried) of the full 115,200-pt scan into the 1e6-pt iVox map ({iters} GN iterations each), "
-                      f"OpenMP per-point stage + sequential reduction, best of thread counts up to {ncpu}"}
+                      f"OpenMP per-point stage + sequential reduction, traffic instrumentation off, best of thread counts up to {ncpu} (best: {thr})"}
+
+
+def grid_counters(map_xyz, query_xyz, cell):
+    """8d counters of a 27-cell uniform grid (cell = sqrt of the squared-distance gate) for kd-tree kinds: probes, hit cells, candidates."""
+    inv = 1.0 / cell
+    mk = np.floor(map_xyz.astype(np.float64) * inv).astype(np.int64)
+    lo = mk.min(0) - 2
+    span = (mk.max(0) - lo + 3).astype(np.int64)
+    key = lambda k: ((k[:, 2] - lo[2]) * span[1] + (k[:, 1] - lo[1])) * span[0] + (k[:, 0] - lo[0])
+    uk, cnt = np.unique(key(mk), return_counts=True)
+    qk = np.floor(query_xyz.astype(np.float64) * inv).astype(np.int64)
+    ok = np.all((qk >= lo + 1) & (qk < lo + span - 1), axis=1)
+    qk = qk[ok]
+    hits = cand = 0
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                k = key(qk + np.array([dx, dy, dz]))
+                pos = np.searchsorted(uk, k)
+                pos[pos >= uk.size] = uk.size - 1
+                found = uk[pos] == k
+                hits += int(found.sum())
+                cand += int(cnt[pos][found].sum())
+    return 27 * int(query_xyz.shape[0]), hits, cand
+
+
+def bench_other_configs(reg, synth, util, O, budget_s=6.0):
+    """BASELINE configs[0], [2], [3] at full size: GPU resident Match, 8d roofline of the correspondence launches, CPU oracle."""
+    out = {}
+    cases = [("configs[0] Optimized-ICP (16x900 scan, 50k-pt fixed map, localization)", 0, "IcpOptimized", reg.YAML_NCLT_ICP, True),
+             ("configs[2] Incremental-NDT (64x1800 scan, 1.0 m voxels, 1e6-pt map)", 2, "IncrementalNDT", reg.YAML_NCLT_NDT, False),
+             ("configs[3] LOAM frontend (57,600 surf + 7,680 corner points, point-to-line + point-to-plane)", 3, "LoamFull_KdTree", reg.YAML_NCLT_LOAM_FULL, False)]
+    for name, cid, mode, y, loc in cases:
+        cfg = synth.make_config(cid)
+        maps = [cfg["map"]] + ([cfg["corner_map"]] if "corner_map" in cfg else [])
+        corner = cfg.get("corner_scan")
+        m = reg.make_matcher(mode, y, is_localization_mode=loc)
+        m.AddCloudToLocalMap(maps)
+        cl = util.cluster_for(mode, cfg["scan"], corner)
+        m.UploadScan(cl)
+        run, Tv = m.resident_call(np.eye(4))
+        for _ in range(5):
+            run()
+        ts = []
+        for _ in range(30):
+            t = time.perf_counter(); run(); ts.append(time.perf_counter() - t)
+        m.set_profiling(True)
+        for _ in range(10):
+            run()
+        ms, nl, _ = m.kernel_time()
+        m.set_profiling(False)
+        iters = int(m.stats.iterations)
+        T_gpu = np.array(Tv)
+        # CPU oracle: result (pose error, counters) + bounded timing
+        O.set_threads(min(os.cpu_count() or 1, 64))
+
+        def make():
+            o = util.oracle_for(mode, y, loc)
+            o.AddCloudToLocalMap(*maps)
+            return o
+
+        t_cpu, reps, o = timed_oracle(make, lambda o: o.Match(cfg["scan"], np.eye(4), src1=corner, update_map=False), budget_s, max_reps=12)
+        ok_ref, T_ref = o.Match(cfg["scan"], np.eye(4), src1=corner, update_map=False)
+        cnt = o.counters()
+        dt, dr = synth.pose_error(T_gpu, T_ref)
+        n_pts = int(m.stats.n_source) + int(m.stats.n_source_corner)
+        # 8d algorithmic bytes of ONE iteration at the final pose (kd-tree kinds: the 27-cell grid of the survey's formula)
+        if mode == "IncrementalNDT":
+            pi = int(cnt.point_iters) // max(int(o.stats.iterations), 1)
+            bytes_iter = algorithmic_bytes(pi, int(cnt.probes) // max(int(o.stats.iterations), 1), int(cnt.hit_voxels) // max(int(o.stats.iterations), 1), 0,
+                                           per_probe=16, per_hit=24 + 48 + 4, per_cand=0, out=4)
+        else:
+            gate = float(np.sqrt(y["point_search_thres"]))
+            q = (cfg["scan"].astype(np.float64) @ T_ref[:3, :3].T + T_ref[:3, 3]).astype(np.float32)
+            if mode == "IcpOptimized":  # Match VoxelGrids the scan (icp_optimized.h:57) and the map (:187) first
+                src = np.asarray(O.voxel_grid(cfg["scan"], y["source_cloud_filter_size"]))[:, :3]
+                q = (src.astype(np.float64) @ T_ref[:3, :3].T + T_ref[:3, 3]).astype(np.float32)
+                pr, hi, ca = grid_counters(np.asarray(O.voxel_grid(cfg["map"], y["local_map_cloud_filter_size"]))[:, :3], q, gate)
+                bytes_iter = algorithmic_bytes(q.shape[0], pr, hi, ca, out=8)
+            else:
+                pr, hi, ca = grid_counters(cfg["map"], q, gate)
+                qc = (corner.astype(np.float64) @ T_ref[:3, :3].T + T_ref[:3, 3]).astype(np.float32)
+                pr2, hi2, ca2 = grid_counters(cfg["corner_map"], qc, gate)
+                bytes_iter = algorithmic_bytes(q.shape[0] + qc.shape[0], pr + pr2, hi + hi2, ca + ca2)
+        avg_launch_s = (ms / 1e3) / max(nl, 1)
+        ach = bytes_iter / avg_launch_s / 1e9 if nl else 0.0
+        out[f"configs[{cid}]"] = {
+            "workload": name, "scans_per_s": 1.0 / float(np.median(ts)), "match_us": 1e6 * float(np.median(ts)), "gn_iterations": iters,
+            "converged": bool(m.stats.converged), "source_points": n_pts, "pose_err_vs_oracle_m_rad": [dt, dr],
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_iteration": bytes_iter, "correspondence_launch_us": 1e6 * avg_launch_s,
+                         "note": "8d formula; kd-tree kinds: counters of the survey's 27-cell grid (cell = sqrt(gate)) at the final pose, the bracket covers one "
+                                 "iteration's correspondence launch(es)"},
+            "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "scans/s", "cores": min(os.cpu_count() or 1, 64), "kind": "port",
+                             "sample": f"{reps} oracle Match calls (median), {int(o.stats.iterations)} iterations each"},
+        }
+        o.close()
+        m.close()
+    O.set_threads(0)
+    return out
+
+
+def bench_mapping_mode(reg, synth, cfg, n_scans=6):
+    """Match + the map update the reference performs inside Match (what the adapter issues), device path and host path."""
+    scene = cfg["scene"]
+    rng = synth.rng_for(1, 123)
+    Tgt = cfg["T_gt"].copy()
+    scans = []
+    for k in range(n_scans):
+        scans.append(synth.cast_scan(scene, Tgt, rng=rng, **synth.VELODYNE_64))
+        Tgt = Tgt @ synth.random_pose(rng, 0.5, 0.5)
+    res = {}
+    for label, env in (("device_addpoints", "1"), ("host_addpoints", "0")):
+        os.environ["FLS_IVOX_DEVICE_UPDATE"] = env
+        m = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+        m.AddCloudToLocalMap([cfg["map"]])
+        guess = np.eye(4)
+        t_match, t_both = [], []
+        for k, scan in enumerate(scans):
+            cl = reg.PointcloudCluster(planar_cloud_=scan)
+            m.UploadScan(cl)
+            T = guess.copy(); m.MatchResident(T, update_map=False)  # warm (buffers), Match only
+            T = guess.copy(); t = time.perf_counter(); m.MatchResident(T, update_map=False); t_match.append(time.perf_counter() - t)
+            T = guess.copy(); t = time.perf_counter(); m.MatchResident(T, update_map=True); t_both.append(time.perf_counter() - t)
+            guess = T
+        res[label] = {"ms_per_scan_match_plus_update": 1e3 * float(np.median(t_both[1:])), "ms_map_update_only": 1e3 * float(np.median(np.array(t_both[1:]) - np.array(t_match[1:]))),
+                      "ms_match_only": 1e3 * float(np.median(t_match[1:])), "device_batches": m.map_size(103), "refused_batches": m.map_size(104),
+                      "map_points_after": m.map_size()}
+        m.close()
+    os.environ.pop("FLS_IVOX_DEVICE_UPDATE", None)
+    res["note"] = (f"{n_scans} consecutive scans (0.5 m / 0.5 deg steps), scan resident; medians over scans 1..; the scans that follow a map update run more "
+                   "iterations against a map the insert rule has densified near the sensor, so ms_match_only here is not the headline step")
+    return res
 
 
 def main():
@@ -93,21 +263,36 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the configs[4] batch measurement")
-    ap.add_argument("--batch-jobs", type=int, default=64, help="configs[4] jobs per GPU")
+    ap.add_argument("--no-extras", action="store_true", help="skip configs[0,2,3], mapping_mode, inclusive_h2d (N = 1 extras)")
+    ap.add_argument("--batch-jobs", type=int, default=512, help="configs[4] jobs in total at 8 GPUs (64 per GPU); scaled by n_gpus / 8 below 8 GPUs unless --batch-jobs-total")
+    ap.add_argument("--batch-jobs-total", type=int, default=0, help="configs[4]: total number of jobs (default: 512 at N = 1 and at N = 8, 64 * N otherwise)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl == RCCL; gloo + FLS_BENCH_SHARE_DEVICE=1 exercises the N > 1 code path on a 1-GPU box)")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    n_gpus = world if distributed else 1
+
+    from funny_lidar_slam_amd import batch, synth
+
+    # configs[4] inputs first (host cores, forked workers: nothing GPU-side may be initialised yet)
+    n_jobs = args.batch_jobs_total or (512 if n_gpus in (1, 8) else 64 * n_gpus)
+    my_scans, job_range = [], (0, 0)
+    if not args.no_batch:
+        job_range = batch.partition(n_jobs, n_gpus, rank)
+        t_gen = time.perf_counter()
+        my_scans = make_batch_scans(range(*job_range))
+        t_gen = time.perf_counter() - t_gen
+
+    import torch
+    import torch.distributed as dist
+
     share = os.environ.get("FLS_BENCH_SHARE_DEVICE", "0") == "1"  # test hook: every rank on device 0 (1-GPU box)
     dev = 0 if (share or not distributed) else local_rank
-    coll_dev = "cuda" if args.backend == "nccl" else "cpu"  # where the tiny collective payloads live
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"  # where the collective payloads live
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev)
@@ -115,20 +300,33 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend="gloo")
-    n_gpus = world if distributed else 1
     if args.gpus != n_gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
 
-    from funny_lidar_slam_amd import _lib, registration as reg, synth
+    from funny_lidar_slam_amd import _lib, registration as reg
 
     if _lib.device_count() < 1:
         raise RuntimeError("bench.py needs an MI355X (gfx950); the HIP path has no CPU fallback")
     torch.cuda.set_device(dev)
 
     y = reg.YAML_NCLT_IVOX
-    cfg = synth.make_config(1, job=0)  # identical scan / map on every rank (fixed per-GPU work)
+    cfg = synth.make_config(1, job=0, with_map=(rank == 0))  # identical scan on every rank; the map is built once, on rank 0
     m = reg.make_matcher("PointToPlane_IVOX", y, device_id=dev)
-    m.AddCloudToLocalMap([cfg["map"]])
+    t_map = time.perf_counter()
+    if rank == 0:
+        m.AddCloudToLocalMap([cfg["map"]])
+    map_bcast = None
+    if distributed:
+        # rank 0 builds the map, its image travels in one broadcast, every other GPU imports it
+        blob = m.ExportMap() if rank == 0 else None
+        tb0 = time.perf_counter()
+        blob = batch.broadcast_blob(blob, src=0, device=coll_dev)
+        tb1 = time.perf_counter()
+        if rank != 0:
+            m.ImportMap(blob)
+        map_bcast = {"blob_MB": blob.size / 1e6, "broadcast_ms": 1e3 * (tb1 - tb0), "import_ms_nonzero_ranks": 1e3 * (time.perf_counter() - tb1)}
+        del blob
+    t_map = time.perf_counter() - t_map
     cluster = reg.PointcloudCluster(planar_cloud_=cfg["scan"])
     m.UploadScan(cluster)  # inputs resident in HBM before the timed region
 
@@ -140,6 +338,8 @@ def main():
             raise RuntimeError(f"fls_match_resident failed: {rc}")
         return rc == 0, T_work
 
+    ok_first, T_first = step()  # the first Match of the handle: what the oracle's first Match is compared with
+    T_first = np.array(T_first)
     for _ in range(args.warmup):
         step()
     # start / stop hipEvents are attached to every correspondence-kernel launch of every EVENT_EVERY-th step of the
@@ -163,44 +363,42 @@ def main():
     elapsed = time.perf_counter() - t0
     ms_kernel, launches, point_iters = m.kernel_time()
     iters = m.stats.iterations
+    T_head = np.array(T)
     # algorithmic-traffic counters: one extra (untimed) Match with the counting kernel variant
     m.set_profiling(False, counters=True)
     step()
     probes, hits, cand = m.traffic_counters()
+    m.set_profiling(False, counters=False)
     assert m.stats.iterations == iters
 
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        from funny_lidar_slam_amd import batch
-        row = batch.pack_result(T, ok, m.stats.iterations, m.stats.n_valid, m.stats.sum_res)
+        row = batch.pack_result(T_head, ok, m.stats.iterations, m.stats.n_valid, m.stats.sum_res)
         table = batch.gather_results(row[None, :], world, batch.RESULT_WIDTH, device=coll_dev)  # one job per rank per step
         assert table.shape == (world, batch.RESULT_WIDTH)
-        assert bool(np.all(table == table[0])), "identical jobs on identical GPUs must give bit-identical results"
+        assert bool(np.all(table == table[0])), "identical jobs on identical GPUs (imported map image) must give bit-identical results"
 
     c5 = None
     if not args.no_batch:
-        # configs[4]: jobs_per_gpu independent jobs per rank (job ids block-partitioned, batch.partition), 4 stream lanes
-        from funny_lidar_slam_amd import batch
-        jpg, lanes = args.batch_jobs, 4
-        n_jobs = jpg * n_gpus
-        b_, e_ = batch.partition(n_jobs, n_gpus, rank)
-        scans = [cfg["scan"]] + [synth.cast_scan(
-            cfg["scene"], synth.random_pose(synth.rng_for(1, j)), rng=synth.rng_for(1, j, salt=7), max_range=cfg["radius"],
-            **synth.VELODYNE_64) for j in range(1, 8)]
-        clusters = [reg.PointcloudCluster(planar_cloud_=scans[j % 8]) for j in range(b_, e_)]
+        # configs[4]: job ids block-partitioned (batch.partition), every job its own scan, 4 stream lanes per GPU
+        lanes = 4
+        clusters = [reg.PointcloudCluster(planar_cloud_=s) for s in my_scans]
         T0s = [np.eye(4)] * len(clusters)
-        for _ in range(3):  # warm-up: lane creation, buffer growth, clocks back up after the host-side scan generation
-            m.MatchBatch(clusters, T0s, lanes=lanes)
+        warm = clusters[: min(len(clusters), 16)]
+        for _ in range(2):  # warm-up: lane creation, buffer growth, clocks back up after the host-side preparation
+            if warm:
+                m.MatchBatch(warm, T0s[: len(warm)], lanes=lanes)
         reps = []
-        for _ in range(5):  # median of five passes over the whole batch
+        for _ in range(3):  # median of three passes over the whole batch
             if distributed:
                 dist.barrier()
             torch.cuda.synchronize()
             tb = time.perf_counter()
-            oks, Tb, sb = m.MatchBatch(clusters, T0s, lanes=lanes)
-            rows = np.stack([batch.pack_result(Tb[k], oks[k], sb[k].iterations, sb[k].n_valid, sb[k].sum_res) for k in range(len(clusters))])
+            oks, Tb, sb = m.MatchBatch(clusters, T0s, lanes=lanes) if clusters else ([], np.zeros((0, 4, 4)), [])
+            rows = (np.stack([batch.pack_result(Tb[k], oks[k], sb[k].iterations, sb[k].n_valid, sb[k].sum_res) for k in range(len(clusters))])
+                    if clusters else np.zeros((0, batch.RESULT_WIDTH)))
             tab = batch.gather_results(rows, n_jobs, batch.RESULT_WIDTH, device=coll_dev if distributed else None)
             torch.cuda.synchronize()
             if distributed:
@@ -212,24 +410,36 @@ def main():
                 tb = float(tm.item())
             reps.append(tb)
         tb = float(np.median(reps))
-        assert tab.shape == (n_jobs, batch.RESULT_WIDTH) and bool(np.all(tab[:, 16] == 1.0))
-        c5 = {"jobs": n_jobs, "jobs_per_gpu": jpg, "lanes_per_gpu": lanes, "scans_per_s": n_jobs / tb, "ms_total": 1e3 * tb, "ms_passes": [1e3 * t for t in reps],
-              "gn_iterations": sorted({int(v) for v in tab[:, 17]}),
-              "note": "fls_match_batch: per-job scan upload from host memory and the result gather are inside the timed region"}
+        assert tab.shape == (n_jobs, batch.RESULT_WIDTH)
+        c5 = {"jobs": n_jobs, "jobs_per_gpu": n_jobs // n_gpus, "lanes_per_gpu": lanes, "scans_per_s": n_jobs / tb, "ms_total": 1e3 * tb,
+              "ms_passes": [1e3 * t for t in reps], "converged_jobs": int(np.sum(tab[:, 16] == 1.0)),
+              "gn_iterations_hist": {str(int(v)): int(c) for v, c in zip(*np.unique(tab[:, 17], return_counts=True))},
+              "distinct_poses": int(len({tuple(np.round(r[:16], 9)) for r in tab})), "scan_generation_s": t_gen,
+              "note": "one distinct seeded scan per job (seed 20241022 + 4000 + job), all against ONE map; fls_match_batch: per-job scan upload from host "
+                      "memory and the result gather are inside the timed region"}
+        if map_bcast is not None:
+            c5["map_image_broadcast"] = map_bcast
 
     if rank == 0:
+        from oracle import oracle as O
+        from tests import util
         total_scans = args.steps * n_gpus
         value = total_scans / elapsed
         per_launch_bytes = algorithmic_bytes(point_iters=cfg["scan"].shape[0] * iters, probes=probes, hits=hits, cand=cand) / max(iters, 1)
         avg_launch_s = (ms_kernel / 1e3) / max(launches, 1)
         achieved = per_launch_bytes / avg_launch_s / 1e9 if launches else 0.0
-        dt, dr = synth.pose_error(T, cfg["T_gt"])
-        # HBM bytes per launch of the same kernel from the committed PMC passes (rocprofv3 cannot collect counters from
+        dt, dr = synth.pose_error(T_head, cfg["T_gt"])
+        # HBM bytes per launch / what limits the kernel, from the committed PMC passes (rocprofv3 cannot collect counters from
         # inside this process; gpurun keeps --pmc runs separate from everything else): profiles/traffic_ivox_knn.json
-        traffic = None
+        traffic, detail = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "traffic_ivox_knn.json")) as f:
-                traffic = float(json.load(f)["hbm_bytes_per_launch"])
+                tj = json.load(f)
+            traffic = float(tj["hbm_bytes_per_launch"])
+            detail = {k: tj[k] for k in ("l2_read_bytes_per_launch", "valu_busy_pct", "wave_wait_pct", "valu_wave_instructions_per_launch",
+                                         "instruction_floor_us", "source") if k in tj}
+            if traffic and avg_launch_s:
+                detail["measured_hbm_GBs"] = traffic / avg_launch_s / 1e9
         except (OSError, KeyError, ValueError):
             traffic = None
         line = {
@@ -240,18 +450,54 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Velodyne-64 synthetic scan (64x1800 = 115,200 pts), point-to-plane "
                                    "(LoamPointToPlaneIVOX semantics, YAML config_nclt.yaml) into a 1e6-pt iVox map, 1 scan per GPU per step "
                                    "(the same scan on every GPU)",
-                       "scan_points": int(cfg["scan"].shape[0]), "map_points": int(cfg["map"].shape[0]),
+                       "scan_points": int(cfg["scan"].shape[0]), "map_points": int(m.map_size()),
                        "gn_iterations": int(iters), "converged": bool(ok), "pose_err_vs_gt_m_rad": [dt, dr]},
             "roofline": {"bound": "hbm", "kernel": "ivox_knn_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/traffic_ivox_knn.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
+                         "traffic_source": "profiles/traffic_ivox_knn.json (separate rocprofv3 --pmc passes, bytes per launch)",
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_us": 1e6 * avg_launch_s,
-                         "launches_timed": int(launches)},
+                         "launches_timed": int(launches), "device_counters": {"probes": int(probes), "hit_voxels": int(hits), "cand_points": int(cand)}},
         }
+        if detail:
+            line["roofline"]["detail"] = detail
         if c5 is not None:
             line["c5_batch"] = c5
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, y)
+        if n_gpus == 1:
+            # the CPU oracle on the same inputs: pose error of the headline result, and the device counters against the oracle's
+            # (the timed steps re-register the same scan on ONE handle, and nearest_points_ persists from Match to Match in the
+            # reference -- Q15: a point without candidates keeps its previous list -- so the steady-state step equals the oracle's
+            # SECOND and later calls on one instance, not its first; the first-call parity is what the gpu tests check)
+            o = util.oracle_for("PointToPlane_IVOX", y)
+            o.AddCloudToLocalMap(cfg["map"])
+            ok_ref, T_ref = o.Match(cfg["scan"], cfg["T_init"], update_map=False)
+            edt, edr = synth.pose_error(T_first, T_ref)
+            for _ in range(2):
+                ok_ref3, T_ref3 = o.Match(cfg["scan"], cfg["T_init"], update_map=False)
+            oc = o.counters()
+            sdt, sdr = synth.pose_error(T_head, T_ref3)
+            line["pose_err_vs_oracle"] = {"dt_m": edt, "dR_rad": edr, "same_iterations": bool(o.stats.iterations == iters), "same_return": bool(ok_ref == ok_first),
+                                          "what": "first Match of the handle vs the oracle's first Match (identical inputs and state)",
+                                          "steady_state_step_vs_oracle_third_call": {"dt_m": sdt, "dR_rad": sdr},
+                                          "oracle_counters_third_call": {"probes": int(oc.probes), "hit_voxels": int(oc.hit_voxels), "cand_points": int(oc.cand_points)}}
+            o.close()
+            if not args.no_extras:
+                t = time.perf_counter()
+                try:
+                    line["configs"] = bench_other_configs(reg, synth, util, O)
+                    line["mapping_mode"] = bench_mapping_mode(reg, synth, cfg)
+                    # the boundary handing over host buffers: de-interleave into pinned staging + one H2D copy inside the call
+                    ts = []
+                    for _ in range(5):
+                        Th = np.eye(4); m.Match(cluster, Th, update_map=False)
+                    for _ in range(50):
+                        Th = np.eye(4); t1 = time.perf_counter(); m.Match(cluster, Th, update_map=False); ts.append(time.perf_counter() - t1)
+                    line["inclusive_h2d"] = {"match_us": 1e6 * float(np.median(ts)), "scans_per_s": 1.0 / float(np.median(ts)),
+                                             "note": "fls_match with the scan as a host buffer (12 B / point): never `value`"}
+                except Exception as e:  # the extras must never cost the headline line
+                    line["extras_error"] = repr(e)[:300]
+                line["extras_wall_s"] = time.perf_counter() - t
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(cfg, y)
         print(json.dumps(line))
     m.close()
     if distributed:

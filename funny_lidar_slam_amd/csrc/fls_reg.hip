@@ -146,6 +146,18 @@ fls_status fls_match_batch(fls_handle h, size_t n_jobs, const float* const* src0
     });
 }
 
+size_t fls_map_export(fls_handle h, void* blob, size_t cap) {
+    if (!h) return 0;
+    size_t n = 0;
+    (void)guarded([&]() -> fls_status { FLS_HIP(hipSetDevice(h->device)); n = h->map_export(blob, cap); return FLS_OK; });
+    return n;
+}
+
+fls_status fls_map_import(fls_handle h, const void* blob, size_t n) {
+    if (!h || !blob) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status { FLS_HIP(hipSetDevice(h->device)); return h->map_import(blob, n); });
+}
+
 fls_status fls_get_fitness_score(fls_handle h, float max_range, float* score) {
     if (!h || !score) return FLS_ERR_INVALID;
     return guarded([&]() -> fls_status {

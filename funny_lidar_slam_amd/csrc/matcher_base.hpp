@@ -54,6 +54,8 @@ struct fls_matcher {
     virtual fls_status fitness(float max_range, float* score) = 0;
     virtual int correspondences(int slot, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) = 0;
     virtual size_t map_size(int slot) const = 0;
+    virtual size_t map_export(void*, size_t) { return 0; }                       // 0: this kind has no exportable image
+    virtual fls_status map_import(const void*, size_t) { return FLS_ERR_STATE; }
     // state a FRESH reference matcher would not have (e.g. nearest_points_ of an earlier Match): cleared per batch job
     virtual void reset_job_state() {}
     // Batch of independent registrations against the CURRENT map (BASELINE configs[4]): every job is what a

@@ -458,6 +458,70 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
 
     void reset_job_state() override { nn_n = 0; have_final = false; }  // nearest_points_ of a fresh matcher is empty
 
+    // ---- map image export / import (fls_reg.h): header, voxels from the LRU tail (oldest) to the head {key, count}, then the
+    // points {x, y, z, id} of the voxels in the same order
+    struct BlobHeader {
+        char magic[8];
+        unsigned version, kind;
+        float resolution;
+        unsigned is_first;
+        unsigned long long capacity, n_voxels, n_points;
+        long long next_id;
+    };
+    struct BlobVoxel { unsigned long long key; unsigned count, pad; };
+    size_t map_export(void* blob, size_t cap) override {
+        if (borrowed) return 0;
+        const bool was_device = device_map;
+        sync_host_from_device();
+        const size_t need = sizeof(BlobHeader) + ivox.n_alive * sizeof(BlobVoxel) + ivox.n_points * sizeof(Pt4);
+        if (blob && cap >= need) {
+            char* w = static_cast<char*>(blob);
+            BlobHeader hd{};
+            std::memcpy(hd.magic, "FLSIVOX1", 8);
+            hd.version = 1; hd.kind = unsigned(kind); hd.resolution = ivox.resolution; hd.is_first = is_first ? 1u : 0u;
+            hd.capacity = ivox.capacity; hd.n_voxels = ivox.n_alive; hd.n_points = ivox.n_points; hd.next_id = ivox.next_id;
+            std::memcpy(w, &hd, sizeof(hd));
+            BlobVoxel* bv = reinterpret_cast<BlobVoxel*>(w + sizeof(hd));
+            Pt4* bp = reinterpret_cast<Pt4*>(w + sizeof(hd) + ivox.n_alive * sizeof(BlobVoxel));
+            size_t k = 0, q = 0;
+            for (int v = ivox.tail; v >= 0; v = ivox.pool[v].prev) {
+                const HostIvox::Voxel& vx = ivox.pool[v];
+                bv[k++] = BlobVoxel{vx.key, unsigned(vx.pts.size()), 0u};
+                std::memcpy(bp + q, vx.pts.data(), vx.pts.size() * sizeof(Pt4));
+                q += vx.pts.size();
+            }
+        }
+        if (was_device) enter_device_mode();
+        return need;
+    }
+    fls_status map_import(const void* blob, size_t n) override {
+        if (borrowed || n < sizeof(BlobHeader)) return FLS_ERR_INVALID;
+        const char* r = static_cast<const char*>(blob);
+        BlobHeader hd;
+        std::memcpy(&hd, r, sizeof(hd));
+        if (std::memcmp(hd.magic, "FLSIVOX1", 8) != 0 || hd.version != 1 || hd.kind != unsigned(kind)) return FLS_ERR_INVALID;
+        if (n != sizeof(BlobHeader) + hd.n_voxels * sizeof(BlobVoxel) + hd.n_points * sizeof(Pt4)) return FLS_ERR_INVALID;
+        const BlobVoxel* bv = reinterpret_cast<const BlobVoxel*>(r + sizeof(hd));
+        const Pt4* bp = reinterpret_cast<const Pt4*>(r + sizeof(hd) + hd.n_voxels * sizeof(BlobVoxel));
+        std::vector<HostIvox::ImageVoxel> vox(size_t(hd.n_voxels));
+        size_t q = 0;
+        for (size_t k = 0; k < vox.size(); ++k) {  // stamp = position in the LRU order (tail first)
+            vox[k] = HostIvox::ImageVoxel{bv[k].key, unsigned(q), bv[k].count, 0u, unsigned(k + 1)};
+            q += bv[k].count;
+        }
+        if (q != hd.n_points) return FLS_ERR_INVALID;
+        device_map = false;
+        const size_t capacity = ivox.capacity;
+        ivox.rebuild_from_image(vox, bp, size_t(hd.n_points), int(hd.next_id));
+        ivox.resolution = hd.resolution; ivox.inv_resolution = 1.0f / hd.resolution; ivox.capacity = capacity;
+        is_first = hd.is_first != 0;
+        nn_n = 0; have_final = false;
+        image_built = false;  // the slot layout is rebuilt from the mirror (window order), like the first build of the exporter
+        image_dirty = true;
+        refresh_image();
+        return FLS_OK;
+    }
+
     std::unique_ptr<fls_matcher> clone_for_lane() override {
         auto q = std::make_unique<P2PlaneIvoxMatcher>();
         q->kind = kind; q->p = p; q->device = device;

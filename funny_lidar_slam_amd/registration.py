@@ -198,6 +198,23 @@ class RegistrationInterface:
                 raise FlsError(_lib.FLS_ERR_DEVICE, "fls_get_correspondences")
         return ids, cnt, valid
 
+    def ExportMap(self) -> np.ndarray:
+        """fls_map_export: the map image as a self-contained byte blob (uint8 array), e.g. to broadcast it to other GPUs."""
+        n = _lib.lib().fls_map_export(self._h, None, 0)
+        if n == 0:
+            raise FlsError(_lib.FLS_ERR_STATE, "fls_map_export (this kind has no exportable image)")
+        blob = np.empty(n, np.uint8)
+        m = _lib.lib().fls_map_export(self._h, blob.ctypes.data, n)
+        if m != n:
+            raise FlsError(_lib.FLS_ERR_STATE, "fls_map_export")
+        return blob
+
+    def ImportMap(self, blob: np.ndarray) -> None:
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        rc = _lib.lib().fls_map_import(self._h, blob.ctypes.data, blob.size)
+        if rc != _lib.FLS_OK:
+            raise FlsError(rc, "fls_map_import")
+
     def map_size(self, slot: int = 0) -> int:
         return int(_lib.lib().fls_map_size(self._h, slot))
 

@@ -317,10 +317,11 @@ VELODYNE_64 = dict(n_rings=64, n_az=1800, elev0_deg=-24.9, elev_step_deg=0.4)   
 VELODYNE_16 = dict(n_rings=16, n_az=900, elev0_deg=-15.0, elev_step_deg=2.0)    # lidar_model.cpp:24-30 (900 az: config 1)
 
 
-def make_config(config_id: int, job: int = 0, scale: float = 1.0) -> dict:
+def make_config(config_id: int, job: int = 0, scale: float = 1.0, with_map: bool = True) -> dict:
     """Inputs of BASELINE.json configs[config_id] (0-based).  `scale` < 1 shrinks N and M for CPU tests.
 
-    returns dict(scan, map, T_gt, T_init [, corner_scan, corner_map])
+    returns dict(scan, map, T_gt, T_init [, corner_scan, corner_map]); with_map = False leaves the (expensive) map clouds out
+    (ranks that receive the map image from rank 0).
     """
     scene = make_scene()
     rng = rng_for(config_id, job)
@@ -339,10 +340,12 @@ def make_config(config_id: int, job: int = 0, scale: float = 1.0) -> dict:
         radius = max(18.0, MAX_RANGE * float(np.sqrt(scale)))
     out["radius"] = radius
     out["scan"] = cast_scan(scene, T_gt, rng=rng, max_range=radius, **lid)
-    out["map"] = sample_map(scene, m, rng_for(config_id, 0, salt=1), radius=radius)  # the map is shared by all jobs of a config
+    if with_map:
+        out["map"] = sample_map(scene, m, rng_for(config_id, 0, salt=1), radius=radius)  # the map is shared by all jobs of a config
     if config_id == 3:
         n_corner = max(64, int(7680 * scale))
         out["corner_scan"] = cast_edge_scan(scene, T_gt, n_corner, rng)
-        out["corner_map"] = sample_edges(scene, max(2000, int(100000 * scale)), rng_for(config_id, 0, salt=2))
+        if with_map:
+            out["corner_map"] = sample_edges(scene, max(2000, int(100000 * scale)), rng_for(config_id, 0, salt=2))
         out["scan"] = out["scan"][::2].copy()  # 57,600 surf points
     return out

@@ -145,6 +145,14 @@ fls_status fls_match(fls_handle h, const float* src0, size_t n0, const float* sr
 fls_status fls_match_batch(fls_handle h, size_t n_jobs, const float* const* src0, const size_t* n0, const float* const* src1,
                            const size_t* n1, int stride_floats, double* T_colmajor, fls_stats* stats, int32_t* status, int lanes);
 
+/* ---- map image export / import (BASELINE configs[4], SURVEY.md 8e: rank 0 builds the map, the image is broadcast, every
+ * GPU imports it instead of re-inserting 1e6 points).  The blob is self-contained host memory (voxel keys in LRU order, the
+ * points with their insertion ids, counters): import into a handle of the same kind created with the same parameters gives a
+ * handle whose Match / AddCloudToLocalMap results are identical to the exporter's from then on.  FLS_P2PLANE_IVOX only
+ * (other kinds: export returns 0, import FLS_ERR_STATE).  fls_map_export(h, NULL, 0) returns the size needed.            */
+size_t fls_map_export(fls_handle h, void* blob, size_t cap_bytes);
+fls_status fls_map_import(fls_handle h, const void* blob, size_t n_bytes);
+
 /* ---- RegistrationInterface::GetFitnessScore  (registration_interface.h:19) ---------------------- */
 fls_status fls_get_fitness_score(fls_handle h, float max_range, float* score);
 

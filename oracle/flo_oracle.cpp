@@ -45,6 +45,7 @@ struct MatcherBase {
     flo_counters counters{};
     std::vector<IterLog> log;
     double last_H[36]{}, last_g[6]{};
+    bool instrument = true;  // traffic / tie counters of the kNN stage (flo_set_instrumentation: off for timing runs)
     virtual ~MatcherBase() = default;
     virtual int AddCloud(const Cloud& c0, const Cloud& c1) = 0;
     virtual bool Match(const Cloud& s0, const Cloud& s1, double* T, bool update_map) = 0;
@@ -243,7 +244,7 @@ struct P2PlaneIvox final : MatcherBase {
             const P4 tp = transform_point_d(sp, T_);
             std::vector<Near>& pv = nearest_points[size_t(i)];
             KnnCounters kc;
-            ivox->GetClosestPoint(tp, pv, &kc, 5);
+            ivox->GetClosestPoint(tp, pv, instrument ? &kc : nullptr, 5);
             probes += kc.probes; hits += kc.hits; cand += kc.cand; ties += kc.ties;
             if (pv.size() < 5) continue;
             P4 nn[5];
@@ -1036,6 +1037,7 @@ int flo_get_last_system(void* h, double* H36, double* g6) {
     std::memcpy(g6, m->last_g, sizeof(m->last_g));
     return 0;
 }
+void flo_set_instrumentation(void* h, int on) { static_cast<MatcherBase*>(h)->instrument = on != 0; }
 size_t flo_map_size(void* h, int slot) { return static_cast<MatcherBase*>(h)->MapSize(slot); }
 void flo_set_ivox_capacity(void* h, size_t cap) {  /* test hook: the reference hard-codes 1,000,000 (ivox_map.h:35) */
     auto* m = dynamic_cast<P2PlaneIvox*>(static_cast<MatcherBase*>(h));

@@ -169,6 +169,8 @@ def lib():
         L.flo_get_iteration_log.argtypes = [C.c_void_p, dp, ip, dp, C.c_int]
         L.flo_get_correspondences.argtypes = [C.c_void_p, C.c_int, ip, bp, bp, C.c_size_t]
         L.flo_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.flo_set_instrumentation.restype = None
+        L.flo_set_instrumentation.argtypes = [C.c_void_p, C.c_int]
         L.flo_get_last_system.argtypes = [C.c_void_p, dp, dp]
         L.flo_map_size.restype = C.c_size_t
         L.flo_map_size.argtypes = [C.c_void_p, C.c_int]
@@ -294,6 +296,10 @@ class OracleMatcher:
                                           cnt.ctypes.data_as(C.POINTER(C.c_uint8)),
                                           valid.ctypes.data_as(C.POINTER(C.c_uint8)), n)
         return ids, cnt, valid
+
+    def set_instrumentation(self, on: bool) -> None:
+        """False: no traffic / tie counters in the kNN stage (timing runs: cpu_baseline)."""
+        lib().flo_set_instrumentation(self._h, 1 if on else 0)
 
     def counters(self) -> Counters:
         c = Counters()

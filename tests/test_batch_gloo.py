@@ -31,6 +31,10 @@ def worker(job):
     o.AddCloudToLocalMap(cfg["map"])
     ok, T = o.Match(cfg["scan"], cfg["T_init"], update_map=False)
     return batch.pack_result(T, ok, o.stats.iterations, o.stats.n_valid, o.stats.sum_res)
+# map image broadcast (rank 0 "exports", everybody receives the same bytes): the payload here is a stand-in blob
+blob = np.frombuffer(bytes(range(256)) * 4099, dtype=np.uint8).copy() if rank == 0 else None
+got = batch.broadcast_blob(blob, src=0)
+assert got.dtype == np.uint8 and got.size == 256 * 4099 and int(got[1000:1256].astype(np.int64).sum()) == sum(range(256)), got.size
 b, e = batch.partition(n_jobs, world, rank)
 local = batch.run_block(worker, b, e)
 table = batch.gather_results(local, n_jobs, batch.RESULT_WIDTH)

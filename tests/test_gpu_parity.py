@@ -42,6 +42,29 @@ def test_config2_p2plane_ivox(scale):
     assert dt < 0.05 and dr < 0.005  # it actually registers (not only agrees with the oracle)
 
 
+def test_device_traffic_counters_equal_the_oracles():
+    """The roofline inputs (probes, hit voxels, candidate points of every iteration) counted by the kNN kernel's
+    counting variant equal the oracle's instrumentation exactly -- on a fresh handle, and again on the steady state bench.py times
+    (the same scan re-registered on one handle: nearest_points_ persists, Q15, so later calls differ from the first one)."""
+    cfg = synth.make_config(1, scale=0.1)
+    m = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+    o = util.oracle_for("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+    m.AddCloudToLocalMap([cfg["map"]])
+    o.AddCloudToLocalMap(cfg["map"])
+    m.set_profiling(False, counters=True)
+    cl = reg.PointcloudCluster(planar_cloud_=cfg["scan"])
+    for call in range(3):
+        T = np.eye(4)
+        ok = m.Match(cl, T, update_map=False)
+        ok_ref, T_ref = o.Match(cfg["scan"], np.eye(4), update_map=False)
+        c = o.counters()
+        assert m.traffic_counters() == (c.probes, c.hit_voxels, c.cand_points), (call, m.traffic_counters(), (c.probes, c.hit_voxels, c.cand_points))
+        assert c.point_iters == cfg["scan"].shape[0] * o.stats.iterations and m.stats.iterations == o.stats.iterations
+        good, dt, dr = util.pose_close(T, T_ref)
+        assert good and ok == ok_ref, (call, dt, dr)
+    m.close()
+
+
 def test_config1_icp_localization():
     """BASELINE configs[0]: 16x900 scan, Optimized-ICP vs the 50k-pt fixed map (localization mode), + GetFitnessScore."""
     cfg = synth.make_config(0)
@@ -182,6 +205,56 @@ def test_mapping_replay_with_lru_eviction(monkeypatch):
     evicts voxels during the replay; evicted cells must disappear from the device image."""
     m, o = _replay(6, capacity=9000, monkeypatch=monkeypatch)
     assert o.map_voxels() <= 9000
+
+
+def test_map_export_import_gives_an_identical_handle():
+    """fls_map_export / fls_map_import (rank 0 builds the map, the image is broadcast): after a few mapping-mode
+    scans handle A exports its map (which lives on the device by then), a fresh handle B imports the blob, and both are then driven
+    through the same further scans: identical poses, ids and map sizes -- B is A, including the LRU order and the insertion ids."""
+    scene = synth.make_scene()
+    rng = synth.rng_for(1, 31)
+    mp = synth.sample_map(scene, 50000, synth.rng_for(1, 0, 6), radius=28.0)
+    lid = dict(synth.VELODYNE_64, n_az=50)
+    y = reg.YAML_NCLT_IVOX
+    a = reg.make_matcher("PointToPlane_IVOX", y)
+    a.AddCloudToLocalMap([mp])
+    Tgt, guess, scans = np.eye(4), np.eye(4), []
+    for k in range(6):
+        Tgt = Tgt @ synth.random_pose(rng, 1.0, 0.5)
+        scans.append(synth.cast_scan(scene, Tgt, rng=rng, max_range=34.0, **lid))
+    for k in range(3):
+        T = guess.copy()
+        a.Match(reg.PointcloudCluster(planar_cloud_=scans[k]), T, update_map=True)
+        guess = T
+    blob = a.ExportMap()
+    assert blob.size > 16 * a.map_size()
+    b = reg.make_matcher("PointToPlane_IVOX", y)
+    b.ImportMap(blob)
+    assert b.map_size() == a.map_size() and b.map_size(102) == a.map_size(102)
+    # (1) the imported map IS the exporter's map: jobs with fresh per-job state (fls_match_batch) against both give identical results
+    #     (A's own next Match would not: its nearest_points_ of the last scan persist -- Q15 -- and B has none)
+    probe = [reg.PointcloudCluster(planar_cloud_=scans[k]) for k in (3, 4)]
+    oka, Ta, sa = a.MatchBatch(probe, [guess, guess], lanes=2)
+    okb, Tb, sb = b.MatchBatch(probe, [guess, guess], lanes=2)
+    assert oka == okb and np.array_equal(Ta, Tb)
+    assert [s.n_valid for s in sa] == [s.n_valid for s in sb] and [s.iterations for s in sa] == [s.iterations for s in sb]
+    # (2) and it carries everything the map update needs (insertion ids, LRU order, counters): A re-imports its own blob (which clears
+    #     its nearest_points_, like B's), then both run the same further mapping-mode scans -- bit-identical poses, ids, map sizes
+    a.ImportMap(blob)
+    for k in range(3, 6):
+        Ta, Tb = guess.copy(), guess.copy()
+        oka = a.Match(reg.PointcloudCluster(planar_cloud_=scans[k]), Ta, update_map=True)
+        okb = b.Match(reg.PointcloudCluster(planar_cloud_=scans[k]), Tb, update_map=True)
+        assert oka == okb and np.array_equal(Ta, Tb), k
+        ia, ca, va = a.correspondences()
+        ib, cb, vb = b.correspondences()
+        assert np.array_equal(va, vb) and np.array_equal(ca, cb) and np.array_equal(ia, ib), k
+        assert a.map_size() == b.map_size() and a.map_size(102) == b.map_size(102) and a.map_size(103) >= 1, k
+        guess = Ta
+    with pytest.raises(_lib.FlsError):
+        k2 = reg.make_matcher("IcpOptimized", reg.YAML_NCLT_ICP)
+        k2.ImportMap(blob)  # wrong kind
+    a.close(); b.close()
 
 
 def test_match_batch_equals_fresh_matchers():
