@@ -343,8 +343,10 @@ def main():
     for _ in range(args.warmup):
         step()
     # start / stop hipEvents are attached to every correspondence-kernel launch of every EVENT_EVERY-th step of the
-    # timed region (hipExtLaunchKernelGGL: the kernel's own execution time); they are settled after the region.
-    EVENT_EVERY = 4
+    # timed region (hipExtLaunchKernelGGL: the kernel's own execution time); they are settled after the region.  A bracketed step
+    # costs ~36 us more than a plain one (measured, tools/loop_overhead.py: 125 us / step without events, 134 with every 4th, 128 with
+    # every 16th), so the sampling is kept sparse: every 8th step = at least 3 steps / 9 launches at the driver's K = 20.
+    EVENT_EVERY = 8
     m.kernel_time()  # reset the accumulators
     if distributed:
         dist.barrier()

@@ -219,6 +219,22 @@ fls_status fls_get_debug_stamps(fls_handle h, int64_t out[16]) {
     return FLS_OK;
 }
 
+fls_status fls_debug_fullpiv_qr6(int device_id, const double* H, const double* g, int n, double* x) {
+    if (!H || !g || !x || n < 0) return FLS_ERR_INVALID;
+    if (n == 0) return FLS_OK;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(device_id));
+        DevBuf<double> dH, dg, dx;
+        dH.reserve(size_t(n) * 36); dg.reserve(size_t(n) * 6); dx.reserve(size_t(n) * 6);
+        FLS_HIP(hipMemcpy(dH.p, H, size_t(n) * 36 * sizeof(double), hipMemcpyHostToDevice));
+        FLS_HIP(hipMemcpy(dg.p, g, size_t(n) * 6 * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(debug_fullpiv_qr6_kernel, dim3(unsigned(n)), dim3(64), 0, nullptr, (const double*)dH.p, (const double*)dg.p, n, dx.p);
+        FLS_HIP(hipGetLastError());
+        FLS_HIP(hipMemcpy(x, dx.p, size_t(n) * 6 * sizeof(double), hipMemcpyDeviceToHost));
+        return FLS_OK;
+    });
+}
+
 fls_status fls_get_traffic_counters(fls_handle h, uint64_t* probes, uint64_t* hit_voxels, uint64_t* cand_points) {
     if (!h) return FLS_ERR_INVALID;
     if (probes) *probes = h->last_tc.probes;

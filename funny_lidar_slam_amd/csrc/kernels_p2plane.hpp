@@ -217,6 +217,20 @@ __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem
     }
 }
 
+// test hook (fls_debug_fullpiv_qr6): one wave per 6x6 system, the Gauss-Newton tail's solver on caller-supplied matrices
+__global__ void __launch_bounds__(64)
+debug_fullpiv_qr6_kernel(const double* __restrict__ H, const double* __restrict__ g, const int n, double* __restrict__ x) {
+    const int s = blockIdx.x;
+    if (s >= n) return;
+    __shared__ double Hs[36], gs[6], xs[6], hc[6];
+    __shared__ int tr[6], ctr[6];
+    if (threadIdx.x < 36) Hs[threadIdx.x] = H[(size_t)s * 36 + threadIdx.x];
+    if (threadIdx.x < 6) gs[threadIdx.x] = g[(size_t)s * 6 + threadIdx.x];
+    __builtin_amdgcn_wave_barrier();
+    fullpiv_qr_solve6_wave(Hs, gs, xs, hc, tr, ctr);
+    if (threadIdx.x < 6) x[(size_t)s * 6 + threadIdx.x] = xs[threadIdx.x];
+}
+
 __global__ void __launch_bounds__(kSolveThreads)
 gn_solve_loam_kernel(GnState* __restrict__ st, const int first, const Pose16 T0, const double* __restrict__ partials_a,
                      const int nrows_a, const double* __restrict__ partials_b, const int nrows_b, const double rot_thr,

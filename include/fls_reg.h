@@ -187,6 +187,11 @@ fls_status fls_get_traffic_counters(fls_handle h, uint64_t* probes, uint64_t* hi
 /* shader-clock stamps of the solve kernel's phases of the last iteration (only filled by -DFLS_TIMING builds) */
 fls_status fls_get_debug_stamps(fls_handle h, int64_t out[16]);
 
+/* test hook: the Gauss-Newton tail's 6x6 solver (Eigen FullPivHouseholderQR::solve semantics, one wave per system) on n
+ * caller-supplied systems: H (n x 36, column-major), g (n x 6) -> x (n x 6).  tests/test_gpu_solver.py checks it bit for bit
+ * against the oracle's restatement, rank-deficient systems included.                                                      */
+fls_status fls_debug_fullpiv_qr6(int device_id, const double* H, const double* g, int n, double* x);
+
 const char* fls_status_string(int status);
 int fls_abi_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => every compute call fails with FLS_ERR_DEVICE) */
