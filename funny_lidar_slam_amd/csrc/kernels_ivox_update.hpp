@@ -26,7 +26,7 @@
 //   ivox_upd_last       <A>   first rank -> last rank per cell (atomicMax on the same word)
 //   ivox_upd_regions    <A>   per touched voxel: relocate if grown, new {begin, count}, capacity, touched list
 //   ivox_upd_points     <A>   write the new points
-//   ivox_upd_finish     <T>   per touched voxel: order its new points by id, stamp, reset the temporaries
+//   ivox_upd_finish     <T waves>  per touched voxel: order its new points by id (rank count in LDS), stamp, reset the temporaries
 //   ivox_upd_commit     <1>   counters, status to the host-mapped word
 #pragma once
 #include "device_common.hpp"
@@ -264,26 +264,48 @@ ivox_upd_points(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState*
     a.pts[e.x + (e.y - a.pend[cell]) + b.jj[r]] = make_float4(p.x, p.y, p.z, __int_as_float(st->next_id + (int)r));
 }
 
-// per touched voxel: its new points into insertion (id) order, LRU stamp, scratch reset
+// per touched voxel: its new points into insertion (id) order, LRU stamp, scratch reset.  ONE WAVE per voxel: the new points are
+// staged in LDS, every lane counts for its points how many of the voxel's new ids are smaller (= the point's final position) and
+// writes them back in place.  (A voxel next to the sensor receives hundreds of points from one scan: the first version, one thread
+// per voxel with an insertion sort in global memory, took up to 1.2 ms.)
+constexpr int kUpdFinishMaxK = 1024;  // new points of one voxel staged per wave; more than that: serial fallback by lane 0
 __global__ void __launch_bounds__(kUpdBlock)
 ivox_upd_finish(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState* __restrict__ st) {
     if (!st->apply) return;
-    const unsigned t = blockIdx.x * kUpdBlock + threadIdx.x;
+    __shared__ float4 s_pts[kUpdBlock / 64][kUpdFinishMaxK];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned t = blockIdx.x * (kUpdBlock / 64) + w;  // one wave per touched voxel
     if (t >= st->touched) return;
     const unsigned cell = b.tlist[t];
     const uint2 e = a.cells[cell];
     const unsigned k = a.pend[cell];
     float4* const q = a.pts + e.x + (e.y - k);
-    for (unsigned i = 1; i < k; ++i) {  // insertion sort by id (k is the handful of points one scan adds to one voxel)
-        const float4 x = q[i];
-        const int id = __float_as_int(x.w);
-        unsigned j = i;
-        while (j > 0 && __float_as_int(q[j - 1].w) > id) { q[j] = q[j - 1]; --j; }
-        q[j] = x;
+    if (k > 1u && k <= (unsigned)kUpdFinishMaxK) {
+        for (unsigned i = lane; i < k; i += 64) s_pts[w][i] = q[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (unsigned i = lane; i < k; i += 64) {
+            const float4 x = s_pts[w][i];
+            const int id = __float_as_int(x.w);
+            unsigned pos = 0;
+            for (unsigned j = 0; j < k; ++j) pos += __float_as_int(s_pts[w][j].w) < id ? 1u : 0u;  // ids are distinct
+            q[pos] = x;
+        }
+    } else if (k > (unsigned)kUpdFinishMaxK && lane == 0) {
+        for (unsigned i = 1; i < k; ++i) {  // (never seen: > 1024 points of one scan in one 0.5 m voxel)
+            const float4 x = q[i];
+            const int id = __float_as_int(x.w);
+            unsigned j = i;
+            while (j > 0 && __float_as_int(q[j - 1].w) > id) { q[j] = q[j - 1]; --j; }
+            q[j] = x;
+        }
     }
-    a.stamp[cell] = (unsigned)(st->stamp_base + a.rank_mm[cell] + 1ull);
-    a.pend[cell] = 0u;
-    a.rank_mm[cell] = kUpdNoRank;
+    if (lane == 0) {
+        a.stamp[cell] = (unsigned)(st->stamp_base + a.rank_mm[cell] + 1ull);
+        a.pend[cell] = 0u;
+        a.rank_mm[cell] = kUpdNoRank;
+    }
 }
 
 __global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* __restrict__ mb, const unsigned seq) {

@@ -205,7 +205,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         hipLaunchKernelGGL(ivox_upd_last, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_regions, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_points, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
-        hipLaunchKernelGGL(ivox_upd_finish, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
+        hipLaunchKernelGGL(ivox_upd_finish, dim3(unsigned((n + kUpdBlock / 64 - 1) / (kUpdBlock / 64))), t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_commit, dim3(1), dim3(64), 0, stream, d_upd_state.p, upd_mb_dev, upd_seq);
         FLS_HIP(hipGetLastError());
         // the verdict of the batch (a few words in host-mapped memory; no copy, no stream synchronisation)
