@@ -235,6 +235,24 @@ fls_status fls_debug_fullpiv_qr6(int device_id, const double* H, const double* g
     });
 }
 
+fls_status fls_debug_voxel_grid(int device_id, const float* pts, size_t n, int stride, float leaf, float* out, size_t cap, size_t* n_out) {
+    if (!pts || !n_out || stride < 3 || !(leaf > 0.f) || (cap && !out)) return FLS_ERR_INVALID;
+    *n_out = 0;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(device_id));
+        DevScan raw;
+        DeviceVoxelGrid vg;
+        raw.upload_raw(pts, n, stride, nullptr, true);
+        if (n == 0 || !vg.run(raw.x.p, raw.y.p, raw.z.p, raw.xyz.p + 3 * n, n, leaf, nullptr)) return FLS_ERR_STATE;
+        *n_out = vg.n_out;
+        if (vg.n_out > cap) return FLS_ERR_INVALID;
+        std::vector<float> tmp;
+        const std::vector<PtI> c = vg.download(nullptr, tmp);
+        std::memcpy(out, c.data(), c.size() * sizeof(PtI));
+        return FLS_OK;
+    });
+}
+
 fls_status fls_get_traffic_counters(fls_handle h, uint64_t* probes, uint64_t* hit_voxels, uint64_t* cand_points) {
     if (!h) return FLS_ERR_INVALID;
     if (probes) *probes = h->last_tc.probes;

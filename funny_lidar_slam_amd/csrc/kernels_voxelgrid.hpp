@@ -1,0 +1,245 @@
+// kernels_voxelgrid.hpp -- pcl::VoxelGrid<PointXYZI>::filter on the device.
+//
+// Reference: VoxelGridCloud (include/common/pointcloud_utility.h:216-271) -> pcl::VoxelGrid (PCL 1.10 voxel_grid.hpp):
+// finite bounds, leaf index i + j*dx + k*dx*dy per finite point, std::sort of (index, point) records by index, one
+// centroid per run of equal indices, runs in ascending index order.
+//
+// CONTRACT (why this path is opt-in, FLS_DEVICE_VOXELGRID=1):
+//   * the SET of leaves, their ORDER and every integer in the pipeline are the reference's (bit-exact);
+//   * a centroid is the float sum of the leaf's points divided by their count.  The reference sums in the order
+//     libstdc++'s std::sort (introsort, unstable) leaves equal keys in; that order is not a function of the leaf alone, so
+//     no parallel algorithm reproduces it.  Here a leaf is summed in ASCENDING POINT INDEX (a stable radix sort): leaves
+//     holding one or two points are bit-identical (float addition commutes), larger leaves differ in the last bits of the
+//     float sum (|delta| <= (count - 2) ulp of the running sum per component; tests/test_gpu_voxelgrid.py measures it).
+//   The host path (host_maps.hpp voxel_grid, the exact std::sort order) stays the default.
+//
+// Kernels (n points, 256-thread blocks, tiles of 1024 keys):
+//   vg_minmax      finite bounds (ordered-uint atomics, one set per block)
+//   vg_index       leaf index per point (non-finite points get the sentinel `total`, sorted last and dropped)
+//   vg_hist / vg_hist_scan / vg_scatter   one stable LSD radix pass over 8 bits (ceil(bits(total) / 8) passes)
+//   vg_heads / vg_heads_scan / vg_centroid   run heads -> output slot -> sequential float sums in sorted order
+#pragma once
+#include "device_common.hpp"
+
+namespace fls {
+
+constexpr int kVgBlock = 256;
+constexpr int kVgItems = 4;
+constexpr int kVgTile = kVgBlock * kVgItems;  // keys per block of a radix pass
+constexpr int kVgMaxBlocks = 1024;            // n <= 1,048,576
+constexpr int kVgScanBlock = 1024;
+
+struct VgHeader {
+    unsigned mn[3], mx[3];  // ordered-uint encoded float bounds of the finite points
+    unsigned n_out;
+    unsigned pad;
+};
+
+__device__ __forceinline__ unsigned vg_ord(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+inline float vg_unord(unsigned u) {
+    const unsigned b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+__device__ __forceinline__ bool vg_finite3(float x, float y, float z) {
+    return fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY;  // false for NaN
+}
+
+__global__ void __launch_bounds__(kVgBlock)
+vg_minmax(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int n, VgHeader* __restrict__ h) {
+    __shared__ unsigned red[kVgBlock / 64][6];
+    unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+    for (int i = blockIdx.x * kVgBlock + threadIdx.x; i < n; i += gridDim.x * kVgBlock) {
+        const float px = x[i], py = y[i], pz = z[i];
+        if (!vg_finite3(px, py, pz)) continue;
+        const unsigned ox = vg_ord(px), oy = vg_ord(py), oz = vg_ord(pz);
+        lo[0] = min(lo[0], ox); hi[0] = max(hi[0], ox);
+        lo[1] = min(lo[1], oy); hi[1] = max(hi[1], oy);
+        lo[2] = min(lo[2], oz); hi[2] = max(hi[2], oz);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = min(lo[a], (unsigned)__shfl_xor((int)lo[a], o, 64));
+            hi[a] = max(hi[a], (unsigned)__shfl_xor((int)hi[a], o, 64));
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { red[w][a] = lo[a]; red[w][3 + a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        unsigned v = red[0][a];
+        for (int q = 1; q < kVgBlock / 64; ++q) v = a < 3 ? min(v, red[q][a]) : max(v, red[q][a]);
+        if (a < 3) atomicMin(&h->mn[a], v);
+        else atomicMax(&h->mx[a - 3], v);
+    }
+}
+
+struct VgGrid {
+    float inv;
+    int min_b[3];
+    int m1, m2;
+    unsigned total;  // number of leaves of the box = the sentinel key of a non-finite point
+};
+
+__global__ void __launch_bounds__(kVgBlock)
+vg_index(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int n, const VgGrid g,
+         unsigned* __restrict__ key, unsigned* __restrict__ val) {
+    const int i = blockIdx.x * kVgBlock + threadIdx.x;
+    if (i >= n) return;
+    const float px = x[i], py = y[i], pz = z[i];
+    unsigned k = g.total;
+    if (vg_finite3(px, py, pz)) {
+        // voxel_grid.hpp:  static_cast<int>(std::floor(p.x * inverse_leaf_size_[0]) - static_cast<float>(min_b_[0]))
+        const int i0 = (int)(floorf(px * g.inv) - (float)g.min_b[0]);
+        const int i1 = (int)(floorf(py * g.inv) - (float)g.min_b[1]);
+        const int i2 = (int)(floorf(pz * g.inv) - (float)g.min_b[2]);
+        k = (unsigned)(i0 + i1 * g.m1 + i2 * g.m2);
+    }
+    key[i] = k;
+    val[i] = (unsigned)i;
+}
+
+// per-tile digit counts, digit-major: hist[d * nb + b]
+__global__ void __launch_bounds__(kVgBlock)
+vg_hist(const unsigned* __restrict__ key, const int n, const int shift, unsigned* __restrict__ hist, const int nb) {
+    __shared__ unsigned c[256];
+    c[threadIdx.x] = 0u;
+    __syncthreads();
+    const int base = blockIdx.x * kVgTile;
+#pragma unroll
+    for (int r = 0; r < kVgItems; ++r) {
+        const int e = base + r * kVgBlock + threadIdx.x;
+        if (e < n) atomicAdd(&c[(key[e] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nb + blockIdx.x] = c[threadIdx.x];
+}
+
+// one workgroup: exclusive scan of `m` counters in place (each thread owns a contiguous chunk)
+__global__ void __launch_bounds__(kVgScanBlock)
+vg_scan(unsigned* __restrict__ v, const int m, unsigned* __restrict__ total_out) {
+    __shared__ unsigned wsum[kVgScanBlock / 64];
+    const int per = (m + kVgScanBlock - 1) / kVgScanBlock;
+    const int b = threadIdx.x * per, e = min(m, b + per);
+    unsigned s = 0u;
+    for (int i = b; i < e; ++i) s += v[i];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned base = 0u, tot = 0u;
+    for (int q = 0; q < kVgScanBlock / 64; ++q) { const unsigned t = wsum[q]; if (q < w) base += t; tot += t; }
+    unsigned run = base + inc - s;
+    for (int i = b; i < e; ++i) { const unsigned t = v[i]; v[i] = run; run += t; }
+    if (total_out != nullptr && threadIdx.x == 0) *total_out = tot;
+}
+
+// stable scatter of one tile: destination = scanned histogram entry + keys of the same digit earlier in the tile.
+// Tile order is (round r, thread t) = key index; the in-tile rank is wave-match (8 ballots) + an LDS prefix over (r, wave).
+__global__ void __launch_bounds__(kVgBlock)
+vg_scatter(const unsigned* __restrict__ kin, const unsigned* __restrict__ vin, unsigned* __restrict__ kout, unsigned* __restrict__ vout,
+           const int n, const int shift, const unsigned* __restrict__ hist, const int nb) {
+    constexpr int kW = kVgBlock / 64;
+    __shared__ unsigned cnt[kVgItems][kW][256];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (int q = t; q < kVgItems * kW * 256; q += kVgBlock) (&cnt[0][0][0])[q] = 0u;
+    __syncthreads();
+    unsigned key[kVgItems], val[kVgItems], lrank[kVgItems];
+    const int base = blockIdx.x * kVgTile;
+#pragma unroll
+    for (int r = 0; r < kVgItems; ++r) {
+        const int e = base + r * kVgBlock + t;
+        const bool valid = e < n;
+        key[r] = valid ? kin[e] : 0u;
+        val[r] = valid ? vin[e] : 0u;
+        const unsigned d = (key[r] >> shift) & 255u;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool on = (d >> bit) & 1u;
+            const unsigned long long bm = __ballot(on);
+            m &= on ? bm : ~bm;
+        }
+        lrank[r] = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (valid && lrank[r] == 0u) cnt[r][w][d] = (unsigned)__popcll(m);
+    }
+    __syncthreads();
+    {
+        unsigned run = 0u;
+#pragma unroll
+        for (int r = 0; r < kVgItems; ++r)
+#pragma unroll
+            for (int q = 0; q < kW; ++q) { const unsigned c = cnt[r][q][t]; cnt[r][q][t] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kVgItems; ++r) {
+        const int e = base + r * kVgBlock + t;
+        if (e >= n) continue;
+        const unsigned d = (key[r] >> shift) & 255u;
+        const unsigned dst = hist[d * nb + blockIdx.x] + cnt[r][w][d] + lrank[r];
+        kout[dst] = key[r];
+        vout[dst] = val[r];
+    }
+}
+
+// run heads of the sorted keys: block-local exclusive rank + block totals
+__global__ void __launch_bounds__(kVgScanBlock)
+vg_heads(const unsigned* __restrict__ key, const int n, const unsigned total, unsigned* __restrict__ lx, unsigned* __restrict__ bt) {
+    __shared__ unsigned wsum[kVgScanBlock / 64];
+    const int e = blockIdx.x * kVgScanBlock + threadIdx.x;
+    unsigned head = 0u;
+    if (e < n) {
+        const unsigned k = key[e];
+        head = (k < total && (e == 0 || key[e - 1] != k)) ? 1u : 0u;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned inc = head;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned base = 0u, tot = 0u;
+    for (int q = 0; q < kVgScanBlock / 64; ++q) { const unsigned t = wsum[q]; if (q < w) base += t; tot += t; }
+    if (e < n) lx[e] = head ? (base + inc - 1u) : 0xffffffffu;
+    if (threadIdx.x == 0) bt[blockIdx.x] = tot;
+}
+
+// one thread per run head: float sums in sorted (= ascending point index) order, centroid = sum / count
+__global__ void __launch_bounds__(kVgBlock)
+vg_centroid(const unsigned* __restrict__ key, const unsigned* __restrict__ val, const int n, const unsigned* __restrict__ lx,
+            const unsigned* __restrict__ bt, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+            const float* __restrict__ in, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, float* __restrict__ oi) {
+    const int e = blockIdx.x * kVgBlock + threadIdx.x;
+    if (e >= n) return;
+    const unsigned l = lx[e];
+    if (l == 0xffffffffu) return;
+    const unsigned o = bt[e / kVgScanBlock] + l;
+    const unsigned k = key[e];
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    int c = 0;
+    for (int q = e; q < n && key[q] == k; ++q) {
+        const unsigned p = val[q];
+        sx += x[p]; sy += y[p]; sz += z[p]; si += in[p];
+        ++c;
+    }
+    const float cf = (float)c;
+    ox[o] = __fdiv_rn(sx, cf);
+    oy[o] = __fdiv_rn(sy, cf);
+    oz[o] = __fdiv_rn(sz, cf);
+    oi[o] = __fdiv_rn(si, cf);
+}
+
+}  // namespace fls

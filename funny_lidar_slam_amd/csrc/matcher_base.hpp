@@ -233,16 +233,16 @@ struct DevScan {
     PinnedBuf<float> stage;
     size_t n = 0;
     std::vector<PtI> host;  // kept for map updates / fitness
-    void push(hipStream_t s) {
-        xyz.reserve(3 * n);
+    void push(hipStream_t s, int fields = 3) {
+        xyz.reserve(size_t(fields) * n);
         x.p = xyz.p; y.p = xyz.p + n; z.p = xyz.p + 2 * n;
-        FLS_HIP(hipMemcpyAsync(xyz.p, stage.p, 3 * n * sizeof(float), hipMemcpyHostToDevice, s));
+        FLS_HIP(hipMemcpyAsync(xyz.p, stage.p, size_t(fields) * n * sizeof(float), hipMemcpyHostToDevice, s));
     }
     // straight from the caller's strided AoS into the pinned SoA staging buffer x[n] | y[n] | z[n] | intensity[n] (no
     // temporary cloud, no per-point host copy).  The first 3 n floats go to the device; the staged intensities stay valid
     // until the next upload, which is all a map update of THIS resident scan needs (fls_match == fls_scan_upload +
     // fls_match_resident for either value of update_map).
-    void upload_raw(const float* p, size_t count, int stride, hipStream_t s) {
+    void upload_raw(const float* p, size_t count, int stride, hipStream_t s, bool intensity_too = false) {
         n = count;
         host.clear();
         if (n == 0) return;
@@ -252,7 +252,7 @@ struct DevScan {
             const float* q = p + i * stride;
             sx[i] = q[0]; sy[i] = q[1]; sz[i] = q[2]; si[i] = intensity_of(q, stride);
         }
-        push(s);
+        push(s, intensity_too ? 4 : 3);  // the device VoxelGrid averages the intensity as well
     }
     float staged_intensity(size_t i) const { return stage.p[3 * n + i]; }
     void upload(const std::vector<PtI>& c, hipStream_t s) {

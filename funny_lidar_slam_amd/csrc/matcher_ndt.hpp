@@ -8,6 +8,7 @@
 #pragma once
 #include "matcher_base.hpp"
 #include "host_math.hpp"
+#include "device_voxelgrid.hpp"
 #include "kernels_knn.hpp"
 #include "fitness_host.hpp"
 #include <list>
@@ -46,6 +47,7 @@ struct NdtMatcher final : fls_matcher {
 
     DevScan scan;
     std::vector<PtI> source;
+    SourceFilter src_filter;
     DevBuf<int> d_hit_vid;
     DevBuf<unsigned char> d_eff7;
     double final_T[16]{};
@@ -60,6 +62,7 @@ struct NdtMatcher final : fls_matcher {
             return FLS_ERR_INVALID;  // CHECK_NE block incremental_ndt.h:27-36
         if (!(p.ndt_voxel_size > 0.0) || !(p.source_cloud_filter_size > 0.f) || p.ndt_capacity <= 0) return FLS_ERR_INVALID;
         init_common();
+        src_filter.init();
         inv_voxel = 1.0 / p.ndt_voxel_size;
         return FLS_OK;
     }
@@ -210,8 +213,7 @@ struct NdtMatcher final : fls_matcher {
         return add_cloud_impl(cloud_from(c0, n0, stride));
     }
     fls_status scan_upload(const float* s0, size_t n0, const float*, size_t, int stride) override {
-        source = voxel_grid(cloud_from(s0, n0, stride), p.source_cloud_filter_size);  // :232
-        scan.upload(source, stream);
+        src_filter.filter(s0, n0, stride, p.source_cloud_filter_size, stream, scan, source);  // :232
         return FLS_OK;
     }
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
@@ -259,6 +261,7 @@ struct NdtMatcher final : fls_matcher {
         // has_converge = true unconditionally (:325, Q10)
         fls_status rc = FLS_OK;
         if (!p.is_localization_mode && update_map && !owner) {
+            src_filter.materialize(stream, source);
             const fls_status arc = add_cloud_impl(hm::xform_cloud_f(source, T_in));  // Q11: transformed with the INPUT T (:327-329)
             if (arc != FLS_OK) rc = arc; else stats.map_updated = 1;
         }
@@ -298,7 +301,11 @@ struct NdtMatcher final : fls_matcher {
         }
         return int(n);
     }
-    size_t map_size(int) const override { return data.size(); }
+    size_t map_size(int slot) const override {
+        if (slot == 105) return size_t(src_filter.device_runs);
+        if (slot == 106) return size_t(src_filter.host_runs);
+        return data.size();
+    }
 };
 
 }  // namespace fls

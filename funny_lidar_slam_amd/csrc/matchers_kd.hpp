@@ -7,6 +7,7 @@
 #pragma once
 #include "matcher_base.hpp"
 #include "host_math.hpp"
+#include "device_voxelgrid.hpp"
 #include "kernels_knn.hpp"
 #include "kernels_grid_coop.hpp"
 #include "fitness_host.hpp"
@@ -26,6 +27,7 @@ inline float cell_for_gate(double gate_sq) {  // smallest safe cell for a square
 struct IcpMatcher final : fls_matcher {
     std::deque<std::vector<PtI>> cloud_deque;
     std::vector<PtI> local_map, source;
+    SourceFilter src_filter;
     CellGridImage grid;
     bool have_map = false;
     const IcpMatcher* owner = nullptr;  // batch lane: reads the owner's map grid
@@ -46,6 +48,7 @@ struct IcpMatcher final : fls_matcher {
             return FLS_ERR_INVALID;  // CHECK_NE block icp_optimized.h:33-41
         if (!(p.point_search_thres > 0.0) || !(p.map_cloud_filter_size > 0.f) || !(p.source_cloud_filter_size > 0.f)) return FLS_ERR_INVALID;
         init_common();
+        src_filter.init();
         return FLS_OK;
     }
     fls_status add_cloud_impl(const std::vector<PtI>& new_cloud) {  // :165-189
@@ -70,8 +73,7 @@ struct IcpMatcher final : fls_matcher {
     }
     fls_status scan_upload(const float* s0, size_t n0, const float*, size_t, int stride) override {
         raw_n = n0;
-        source = voxel_grid(cloud_from(s0, n0, stride), p.source_cloud_filter_size);  // :57
-        scan.upload(source, stream);
+        src_filter.filter(s0, n0, stride, p.source_cloud_filter_size, stream, scan, source);  // :57
         return FLS_OK;
     }
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
@@ -117,6 +119,7 @@ struct IcpMatcher final : fls_matcher {
         // switch, as in the reference; update_map == 0 (this ABI's "registration only" switch) skips the whole statement,
         // so such a call leaves the keyframe gate alone
         if (update_map && !owner && has_converge && gate.need(final_T, p.dist_thre_add_cloud, p.rot_thre_add_cloud) && !p.is_localization_mode) {
+            src_filter.materialize(stream, source);
             const fls_status arc = add_cloud_impl(hm::xform_cloud_f(source, final_T));
             if (arc != FLS_OK) rc = arc; else stats.map_updated = 1;
         }
@@ -147,7 +150,11 @@ struct IcpMatcher final : fls_matcher {
         for (size_t i = 0; i < n; ++i) { ids[i] = id[i]; cnt[i] = id[i] >= 0 ? 1 : 0; valid[i] = ef[i]; }
         return int(n);
     }
-    size_t map_size(int) const override { return local_map.size(); }
+    size_t map_size(int slot) const override {
+        if (slot == 105) return size_t(src_filter.device_runs);  // source filters run on the device / on the host
+        if (slot == 106) return size_t(src_filter.host_runs);
+        return local_map.size();
+    }
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -192,6 +192,13 @@ fls_status fls_get_debug_stamps(fls_handle h, int64_t out[16]);
  * against the oracle's restatement, rank-deficient systems included.                                                      */
 fls_status fls_debug_fullpiv_qr6(int device_id, const double* H, const double* g, int n, double* x);
 
+/* test hook: the device VoxelGrid (pcl::VoxelGrid<PointXYZI>::filter semantics; opt-in source filter of the ICP / NDT kinds,
+ * FLS_DEVICE_VOXELGRID=1) on a caller-supplied cloud: pts (n x stride floats, intensity as in fls_match) -> out (cap x 4
+ * floats x, y, z, intensity), *n_out = number of leaves.  FLS_ERR_STATE when the device path declines (empty / no finite
+ * point / PCL's "leaf size too small" case / n > 1,048,576: the matchers then run the host filter), FLS_ERR_INVALID when
+ * out is too small (*n_out is still set).  Contract: csrc/kernels_voxelgrid.hpp; tests/test_gpu_voxelgrid.py.          */
+fls_status fls_debug_voxel_grid(int device_id, const float* pts, size_t n, int stride, float leaf, float* out, size_t cap, size_t* n_out);
+
 const char* fls_status_string(int status);
 int fls_abi_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => every compute call fails with FLS_ERR_DEVICE) */

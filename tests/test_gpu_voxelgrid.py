@@ -1,0 +1,160 @@
+"""Device VoxelGrid (csrc/kernels_voxelgrid.hpp) against the oracle's pcl::VoxelGrid restatement
+(oracle/flo_cloud.h, itself pinned by the compiled reference's VoxelGridCloud in tests/test_ref_pin.py).
+
+Contract under test (the reason the device path is opt-in, FLS_DEVICE_VOXELGRID=1):
+  * number of leaves, their order, which points fall into which leaf: exactly the reference's;
+  * centroid of a leaf holding one or two points: bit-identical;
+  * centroid of a larger leaf: the reference sums in the order std::sort leaves equal keys in (unspecified), the device in
+    ascending point index -- the difference is bounded by count * 2^-23 * max|coordinate| per component (asserted), and is
+    a few ulp in practice (reported).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from funny_lidar_slam_amd import _lib, registration as reg, synth
+from oracle import oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(built):
+    assert _lib.device_count() >= 1, "gpu tests need an MI355X (gfx950): the HIP path has no CPU fallback"
+
+
+def device_voxel_grid(cloud, leaf, stride=None):
+    a = np.ascontiguousarray(cloud, np.float32)
+    n, s = a.shape
+    out = np.zeros((max(n, 1), 4), np.float32)
+    n_out = C.c_size_t(0)
+    fp = C.POINTER(C.c_float)
+    rc = _lib.lib().fls_debug_voxel_grid(0, a.ctypes.data_as(fp), n, s, np.float32(leaf), out.ctypes.data_as(fp), out.shape[0], C.byref(n_out))
+    return rc, out[: n_out.value].copy()
+
+
+def leaf_counts(cloud, leaf):
+    """points per output leaf, in output order (numpy restatement of the integer part of the filter)"""
+    a = np.asarray(cloud, np.float32)
+    fin = np.isfinite(a[:, :3]).all(1)
+    p = a[fin, :3]
+    inv = np.float32(1.0) / np.float32(leaf)
+    mn, mx = p.min(0), p.max(0)
+    min_b = np.floor(mn * inv).astype(np.int64)
+    div_b = np.floor(mx * inv).astype(np.int64) - min_b + 1
+    ijk = (np.floor(p * inv) - min_b.astype(np.float32)).astype(np.int64)
+    idx = ijk[:, 0] + ijk[:, 1] * div_b[0] + ijk[:, 2] * div_b[0] * div_b[1]
+    u, inv_idx, cnt = np.unique(idx, return_inverse=True, return_counts=True)
+    amax = np.zeros(len(u), np.float32)
+    np.maximum.at(amax, inv_idx, np.abs(a[fin]).max(1))
+    return cnt, amax
+
+
+def check(cloud, leaf):
+    ref = O.voxel_grid(cloud, leaf)
+    rc, out = device_voxel_grid(cloud, leaf)
+    assert rc == 0, rc
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    cnt, amax = leaf_counts(cloud, leaf)
+    assert len(cnt) == ref.shape[0]
+    small = cnt <= 2
+    assert np.array_equal(out[small].view(np.uint32), ref[small].view(np.uint32)), "leaves with <= 2 points must be bit-identical"
+    bound = (cnt.astype(np.float64) * 2.0 ** -23 * amax)[:, None]
+    d = np.abs(out.astype(np.float64) - ref.astype(np.float64))
+    assert (d <= bound).all(), float((d / np.maximum(bound, 1e-30)).max())
+    ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    return dict(leaves=int(len(cnt)), big=int((~small).sum()), identical=float((out.view(np.uint32) == ref.view(np.uint32)).all(1).mean()),
+                max_ulp=float((d / ulp).max()))
+
+
+@pytest.mark.parametrize("cid,leaf", [(0, 0.4), (2, 0.2), (1, 0.5)])
+def test_scan_filters_of_the_benchmark_configs(cid, leaf):
+    """the source filters Match runs: configs[0] (16x900 scan, 0.4 m), configs[2] (64x1800 scan, 0.2 m), and a coarse one"""
+    cfg = synth.make_config(cid, with_map=False)
+    scan = np.concatenate([cfg["scan"][:, :3], np.linspace(0, 1, cfg["scan"].shape[0], dtype=np.float32)[:, None]], axis=1)
+    r = check(scan, leaf)
+    print(cid, leaf, r)
+    assert r["leaves"] > 1000 and r["max_ulp"] <= 16
+
+
+def test_random_clouds_edge_cases():
+    rng = np.random.default_rng(77)
+    checked = declined = 0
+    for case in range(16):
+        n = int(rng.integers(1, 40000))
+        a = (rng.normal(size=(n, 4)) * rng.choice([0.5, 5.0, 60.0])).astype(np.float32)
+        if case % 3 == 0:  # heavy leaves: many points in few cells
+            a[:, :3] = (rng.integers(-3, 3, size=(n, 3)) + rng.random((n, 3)) * 0.999).astype(np.float32)
+        if case % 4 == 1:  # non-finite points are dropped (voxel_grid.hpp:98-101)
+            bad = rng.integers(0, n, size=max(1, n // 50))
+            a[bad, rng.integers(0, 3, size=bad.size)] = rng.choice([np.nan, np.inf, -np.inf], size=bad.size)
+        if case == 5:
+            a = a[:1]
+        if case == 6:      # exact cell boundaries and negative zero
+            a[:, :3] = np.round(a[:, :3] * 2) / 2
+            a[::7, 0] = -0.0
+        leaf = float(rng.choice([0.1, 0.25, 0.5, 1.0, 3.0]))
+        fin = a[np.isfinite(a[:, :3]).all(1), :3]
+        if len(fin) == 0:
+            continue
+        box = np.prod(np.floor((fin.max(0) - fin.min(0)).astype(np.float64) / leaf) + 1)
+        if box > 2 ** 31 - 1:  # "leaf size too small": declined (the host filter copies the input)
+            assert device_voxel_grid(a, leaf)[0] == _lib.FLS_ERR_STATE
+            declined += 1
+            continue
+        r = check(a, leaf)
+        assert r["leaves"] >= 1
+        checked += 1
+    assert checked >= 8 and declined >= 1, (checked, declined)
+
+
+def test_sparse_cloud_is_bit_identical():
+    """every leaf holds at most two points: the whole output equals the reference's bit for bit"""
+    rng = np.random.default_rng(3)
+    g = np.stack(np.meshgrid(np.arange(40), np.arange(40), np.arange(12), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    a = g + rng.random(g.shape, dtype=np.float32) * 0.9
+    b = a[rng.permutation(len(a))[: len(a) // 2]] + np.float32(0.01)  # a second point in half of the cells
+    b = b[(np.floor(b) == np.floor(b - np.float32(0.01))).all(1)]
+    cloud = np.concatenate([a, b])[rng.permutation(len(a) + len(b))]
+    cloud = np.concatenate([cloud, rng.random((len(cloud), 1), dtype=np.float32)], axis=1)
+    ref = O.voxel_grid(cloud, 1.0)
+    rc, out = device_voxel_grid(cloud, 1.0)
+    assert rc == 0 and np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    assert leaf_counts(cloud, 1.0)[0].max() == 2
+
+
+def test_declined_inputs():
+    """no finite point, and PCL's "leaf size too small" case (index would overflow int): the device path declines, the matchers
+    take the host filter (which copies the input in the second case)"""
+    a = np.full((10, 4), np.nan, np.float32)
+    assert device_voxel_grid(a, 0.5)[0] == _lib.FLS_ERR_STATE
+    b = np.array([[0, 0, 0, 0], [1e6, 1e6, 1e6, 0]], np.float32)
+    assert device_voxel_grid(b, 0.1)[0] == _lib.FLS_ERR_STATE
+
+
+@pytest.mark.parametrize("mode,y,cid,loc", [("IcpOptimized", reg.YAML_NCLT_ICP, 0, True), ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, False)])
+def test_match_with_device_source_filter(mode, y, cid, loc, monkeypatch):
+    """ICP / NDT Match with the opt-in device source filter: same number of filtered points, same iteration count and
+    effective points as the exact host filter, poses within the centroid-rounding noise (1e-6 m / rad); then a map update
+    from the device-resident filtered cloud (mapping-mode NDT)."""
+    cfg = synth.make_config(cid, scale=1.0 if cid == 0 else 0.2)
+    res = {}
+    for dev in (0, 1):
+        monkeypatch.setenv("FLS_DEVICE_VOXELGRID", str(dev))
+        m = reg.make_matcher(mode, y, is_localization_mode=loc)
+        m.AddCloudToLocalMap([cfg["map"]])
+        T = np.eye(4)
+        ok = m.Match(util.cluster_for(mode, cfg["scan"]), T, update_map=not loc)
+        T2 = T.copy()
+        ok2 = m.Match(util.cluster_for(mode, cfg["scan"]), T2, update_map=not loc)
+        res[dev] = (ok, T.copy(), m.stats.n_source, m.stats.iterations, ok2, T2.copy(), m.map_size(0), m.map_size(105), m.map_size(106))
+        m.close()
+    h, d = res[0], res[1]
+    assert h[7] == 0 and h[8] == 2 and d[7] == 2 and d[8] == 0  # which filter ran
+    assert h[0] == d[0] and h[4] == d[4] and h[2] == d[2] and h[3] == d[3]
+    for a, b in ((h[1], d[1]), (h[5], d[5])):
+        dt, dr = synth.pose_error(a, b)
+        assert dt < 1e-6 and dr < 1e-6, (dt, dr)
+    assert h[6] == d[6]  # map size after the updates
