@@ -174,6 +174,25 @@ def bench_other_configs(reg, synth, util, O, budget_s=6.0):
         m.set_profiling(False)
         iters = int(m.stats.iterations)
         T_gpu = np.array(Tv)
+        # fls_match from HOST buffers (upload + source VoxelGrid + Match): exact host filter (default) vs the opt-in device filter
+        from_host = None
+        if mode in ("IcpOptimized", "IncrementalNDT"):
+            from_host = {}
+            prev = os.environ.get("FLS_DEVICE_VOXELGRID")
+            for label, env in (("host_filter_exact_default", "0"), ("device_filter_opt_in", "1")):
+                os.environ["FLS_DEVICE_VOXELGRID"] = env
+                m2 = reg.make_matcher(mode, y, is_localization_mode=loc)
+                m2.AddCloudToLocalMap(maps)
+                t2 = []
+                for k in range(25):
+                    Tm = np.eye(4)
+                    t = time.perf_counter(); m2.Match(cl, Tm, update_map=False); t2.append(time.perf_counter() - t)
+                from_host[label] = 1e6 * float(np.median(t2[5:]))
+                m2.close()
+            if prev is None:
+                os.environ.pop("FLS_DEVICE_VOXELGRID", None)
+            else:
+                os.environ["FLS_DEVICE_VOXELGRID"] = prev
         # CPU oracle: result (pose error, counters) + bounded timing
         O.set_threads(min(os.cpu_count() or 1, 64))
 
@@ -210,6 +229,7 @@ def bench_other_configs(reg, synth, util, O, budget_s=6.0):
         out[f"configs[{cid}]"] = {
             "workload": name, "scans_per_s": 1.0 / float(np.median(ts)), "match_us": 1e6 * float(np.median(ts)), "gn_iterations": iters,
             "converged": bool(m.stats.converged), "source_points": n_pts, "pose_err_vs_oracle_m_rad": [dt, dr],
+            "match_from_host_buffers_us": from_host,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_iteration": bytes_iter, "correspondence_launch_us": 1e6 * avg_launch_s,
                          "note": "8d formula; kd-tree kinds: counters of the survey's 27-cell grid (cell = sqrt(gate)) at the final pose, the bracket covers one "

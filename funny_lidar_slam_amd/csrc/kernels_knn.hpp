@@ -235,6 +235,29 @@ struct NdtGridDev {
     double inv_voxel;
 };
 
+// incremental image maintenance (matcher_ndt.hpp::sync_image): final table entries and voxel rows of one map update
+struct NdtTableEdit { unsigned index, pad; HashEntry e; };
+struct NdtRowEdit { unsigned row; int vid; double mu[3]; double info[9]; };
+static_assert(sizeof(NdtTableEdit) == 24 && sizeof(NdtRowEdit) == 104, "edit records are packed back to back");
+
+__global__ void __launch_bounds__(256)
+ndt_apply_edits_kernel(const NdtTableEdit* __restrict__ te, const int nt, const NdtRowEdit* __restrict__ re, const int nr,
+                       HashEntry* __restrict__ table, double* __restrict__ mu, double* __restrict__ info, int* __restrict__ vid) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < nt) table[te[t].index] = te[t].e;
+    if (t < nr * 4) {
+        const NdtRowEdit& r = re[t >> 2];
+        const int part = t & 3;
+        if (part == 0) {
+            vid[r.row] = r.vid;
+            mu[3 * (size_t)r.row] = r.mu[0]; mu[3 * (size_t)r.row + 1] = r.mu[1]; mu[3 * (size_t)r.row + 2] = r.mu[2];
+        } else {
+            const int o = 3 * (part - 1);
+            info[9 * (size_t)r.row + o] = r.info[o]; info[9 * (size_t)r.row + o + 1] = r.info[o + 1]; info[9 * (size_t)r.row + o + 2] = r.info[o + 2];
+        }
+    }
+}
+
 template <bool COUNT>
 __global__ void __launch_bounds__(64)
 ndt_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,

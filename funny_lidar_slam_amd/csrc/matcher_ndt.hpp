@@ -11,9 +11,8 @@
 #include "device_voxelgrid.hpp"
 #include "kernels_knn.hpp"
 #include "fitness_host.hpp"
+#include <chrono>
 #include <list>
-#include <set>
-#include <unordered_map>
 
 namespace fls {
 
@@ -25,12 +24,32 @@ struct NdtMatcher final : fls_matcher {
         bool estimated = false;
         int num_points = 0;
         int vid = 0;
+        int prev = -1, next = -1;  // LRU list (head = most recently touched)
+        int slot = -1;             // row of the device image (estimated voxels only)
+        unsigned epoch = 0;        // last add_cloud call that touched it
+        bool dirty = false;        // mu / info changed in this call
     };
-    struct KeyHash {
-        size_t operator()(unsigned long long k) const { return size_t(hash_key(k)); }
-    };
-    std::list<Voxel> data;  // front = most recently touched
-    std::unordered_map<unsigned long long, std::list<Voxel>::iterator, KeyHash> grids;
+    // std::list + unordered_map of the reference (incremental_ndt.h:352-353) as a pool with an intrusive LRU list and an
+    // open-addressing key map: same sequence of creations, touches and evictions, no node allocation per point
+    std::vector<Voxel> pool;
+    std::vector<int> free_ix;
+    int lru_head = -1, lru_tail = -1;
+    size_t n_alive = 0;
+    FlatKeyMap grids;  // key -> pool index
+    unsigned epoch = 0;
+    void lru_unlink(int v) {
+        Voxel& x = pool[v];
+        if (x.prev >= 0) pool[x.prev].next = x.next; else lru_head = x.next;
+        if (x.next >= 0) pool[x.next].prev = x.prev; else lru_tail = x.prev;
+        x.prev = x.next = -1;
+    }
+    void lru_push_front(int v) {
+        Voxel& x = pool[v];
+        x.prev = -1;
+        x.next = lru_head;
+        if (lru_head >= 0) pool[lru_head].prev = v; else lru_tail = v;
+        lru_head = v;
+    }
     bool flag_first_scan = true;
     int next_vid = 0;
     double inv_voxel = 1.0;
@@ -48,6 +67,7 @@ struct NdtMatcher final : fls_matcher {
     DevScan scan;
     std::vector<PtI> source;
     SourceFilter src_filter;
+    bool host_timing = false;  // FLS_HOST_TIMING=1: print the host-side split of every map update
     DevBuf<int> d_hit_vid;
     DevBuf<unsigned char> d_eff7;
     double final_T[16]{};
@@ -63,6 +83,7 @@ struct NdtMatcher final : fls_matcher {
         if (!(p.ndt_voxel_size > 0.0) || !(p.source_cloud_filter_size > 0.f) || p.ndt_capacity <= 0) return FLS_ERR_INVALID;
         init_common();
         src_filter.init();
+        if (const char* e = std::getenv("FLS_HOST_TIMING")) host_timing = std::atoi(e) != 0;
         inv_voxel = 1.0 / p.ndt_voxel_size;
         return FLS_OK;
     }
@@ -92,6 +113,7 @@ struct NdtMatcher final : fls_matcher {
                 for (int k = 0; k < 9; ++k) v.info[k] = ((k % 4 == 0) ? 1.0 : 0.0) * 1.0e2;
             }
             v.estimated = true;
+            v.dirty = true;
             v.pts.clear();
             return;
         }
@@ -101,6 +123,7 @@ struct NdtMatcher final : fls_matcher {
             mean_cov(v.pts, v.mu, v.sigma);
             regularised_info(v);
             v.estimated = true;
+            v.dirty = true;
             v.pts.clear();
         } else if (v.estimated && npts > p.ndt_min_points_in_voxel) {
             double cmu[3], cvar[9], nmu[3], nvar[9];
@@ -115,6 +138,7 @@ struct NdtMatcher final : fls_matcher {
             std::memcpy(v.mu, nmu, sizeof(nmu));
             std::memcpy(v.sigma, nvar, sizeof(nvar));
             v.num_points += npts;
+            v.dirty = true;
             v.pts.clear();
             double U[9], S[3], V[9];
             hm::svd3(v.sigma, U, S, V);
@@ -129,15 +153,35 @@ struct NdtMatcher final : fls_matcher {
         }
     }
 
+    // ---- device image: table {key -> row}, rows {mu, info, vid}.  Rows are stable per voxel (free list), evicted keys leave a
+    // tombstone in the table (never equal to a packed key, never "empty": probing walks over it); one map update ships only
+    // the rows and table entries it changed -- a full rebuild when the table must grow, when tombstones pile up, or when
+    // most of the image changed anyway (first scan).
+    static constexpr unsigned long long kTombKey = ~0ull - 1ull;
+    std::vector<int> free_rows;
+    unsigned n_rows = 0, n_in_table = 0, n_tomb = 0;
+    size_t row_cap = 0;
+    std::vector<unsigned> changed_idx;
+    std::vector<NdtTableEdit> edit_table;
+    std::vector<NdtRowEdit> edit_rows;
+    std::vector<unsigned long long> evicted_image_keys;
+    PinnedBuf<unsigned char> edit_stage;
+    DevBuf<unsigned char> d_edit;
+    unsigned long long full_rebuilds = 0, incremental_updates = 0;
+
     void rebuild_image() {
         size_t n_est = 0;
-        for (const auto& v : data) n_est += v.estimated ? 1 : 0;
-        const unsigned ts = GridImage::table_size_for(n_est);
+        for (int v = lru_head; v >= 0; v = pool[v].next) n_est += pool[v].estimated ? 1 : 0;
+        const unsigned ts = GridImage::table_size_for(n_est + n_est / 4 + 1024);  // room for the voxels the next scans estimate
         mask = ts - 1;
         h_table.assign(ts, HashEntry{kEmptyKey, 0u, 0u});
         h_mu.clear(); h_info.clear(); h_vid.clear();
+        free_rows.clear();
         unsigned slot = 0;
-        for (const auto& v : data) {
+        for (int vi = lru_head; vi >= 0; vi = pool[vi].next) {
+            Voxel& v = pool[vi];
+            v.dirty = false;
+            v.slot = -1;
             if (!v.estimated) continue;
             const unsigned long long key = pack_key(v.kx, v.ky, v.kz);
             unsigned h = hash_key(key) & mask;
@@ -146,12 +190,17 @@ struct NdtMatcher final : fls_matcher {
             h_mu.insert(h_mu.end(), v.mu, v.mu + 3);
             h_info.insert(h_info.end(), v.info, v.info + 9);
             h_vid.push_back(v.vid);
+            v.slot = int(slot);
             ++slot;
         }
+        n_rows = slot;
+        n_in_table = slot;
+        n_tomb = 0;
+        row_cap = size_t(slot) + slot / 4 + 1024;
         d_table.reserve(ts);
-        d_mu.reserve(std::max<size_t>(h_mu.size(), 3));
-        d_info.reserve(std::max<size_t>(h_info.size(), 9));
-        d_vid.reserve(std::max<size_t>(h_vid.size(), 1));
+        d_mu.reserve(3 * row_cap);
+        d_info.reserve(9 * row_cap);
+        d_vid.reserve(row_cap);
         FLS_HIP(hipMemcpyAsync(d_table.p, h_table.data(), ts * sizeof(HashEntry), hipMemcpyHostToDevice, stream));
         if (slot) {
             FLS_HIP(hipMemcpyAsync(d_mu.p, h_mu.data(), h_mu.size() * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -159,11 +208,79 @@ struct NdtMatcher final : fls_matcher {
             FLS_HIP(hipMemcpyAsync(d_vid.p, h_vid.data(), h_vid.size() * sizeof(int), hipMemcpyHostToDevice, stream));
         }
         FLS_HIP(hipStreamSynchronize(stream));
+        edit_table.clear(); edit_rows.clear(); evicted_image_keys.clear();
         have_map = true;
+        ++full_rebuilds;
+    }
+
+    // ships what this call changed; `touched` = pool indices whose UpdateVoxel ran
+    void sync_image(const std::vector<int>& touched) {
+        if (!have_map) { rebuild_image(); return; }
+        edit_table.clear();
+        edit_rows.clear();
+        changed_idx.clear();
+        size_t n_new = 0;
+        for (int vi : touched) n_new += (pool[vi].dirty && pool[vi].slot < 0) ? 1 : 0;
+        const size_t ts = size_t(mask) + 1;
+        if ((size_t(n_in_table) + n_tomb + n_new) * 2 + 2 > ts || size_t(n_rows) + n_new > row_cap || touched.size() * 4 > size_t(n_in_table) + 4096) {
+            rebuild_image();
+            return;
+        }
+        for (const unsigned long long key : evicted_image_keys) {  // evictions first: their rows are reused below
+            unsigned h = hash_key(key) & mask;
+            while (h_table[h].key != key) h = (h + 1) & mask;
+            free_rows.push_back(int(h_table[h].begin));
+            h_table[h] = HashEntry{kTombKey, 0u, 0u};
+            changed_idx.push_back(h);
+            --n_in_table;
+            ++n_tomb;
+        }
+        evicted_image_keys.clear();
+        for (int vi : touched) {
+            Voxel& v = pool[vi];
+            if (!v.dirty) continue;
+            v.dirty = false;
+            if (v.slot < 0) {
+                if (!free_rows.empty()) { v.slot = free_rows.back(); free_rows.pop_back(); }
+                else v.slot = int(n_rows++);
+                const unsigned long long key = pack_key(v.kx, v.ky, v.kz);
+                unsigned h = hash_key(key) & mask;
+                while (h_table[h].key != kEmptyKey && h_table[h].key != kTombKey) h = (h + 1) & mask;
+                if (h_table[h].key == kTombKey) --n_tomb;
+                h_table[h] = HashEntry{key, unsigned(v.slot), 1u};
+                changed_idx.push_back(h);
+                ++n_in_table;
+            }
+            NdtRowEdit r;
+            r.row = unsigned(v.slot);
+            r.vid = v.vid;
+            std::memcpy(r.mu, v.mu, sizeof(r.mu));
+            std::memcpy(r.info, v.info, sizeof(r.info));
+            edit_rows.push_back(r);
+        }
+        ++incremental_updates;
+        // one edit per table index, carrying its FINAL entry (a tombstone written and re-used within this call is one edit)
+        std::sort(changed_idx.begin(), changed_idx.end());
+        changed_idx.erase(std::unique(changed_idx.begin(), changed_idx.end()), changed_idx.end());
+        for (const unsigned h : changed_idx) edit_table.push_back(NdtTableEdit{h, 0u, h_table[h]});
+        changed_idx.clear();
+        if (edit_table.empty() && edit_rows.empty()) return;
+        const size_t bt = edit_table.size() * sizeof(NdtTableEdit), br = edit_rows.size() * sizeof(NdtRowEdit);
+        edit_stage.reserve(bt + br);
+        d_edit.reserve(bt + br);
+        if (bt) std::memcpy(edit_stage.p, edit_table.data(), bt);
+        if (br) std::memcpy(edit_stage.p + bt, edit_rows.data(), br);
+        FLS_HIP(hipMemcpyAsync(d_edit.p, edit_stage.p, bt + br, hipMemcpyHostToDevice, stream));
+        const int nt = int(edit_table.size()), nr = int(edit_rows.size());
+        hipLaunchKernelGGL(ndt_apply_edits_kernel, dim3(unsigned((std::max(nt, nr * 4) + 255) / 256)), dim3(256), 0, stream,
+                           (const NdtTableEdit*)d_edit.p, nt, (const NdtRowEdit*)(d_edit.p + bt), nr, d_table.p, d_mu.p, d_info.p, d_vid.p);
+        FLS_HIP(hipStreamSynchronize(stream));  // the staging buffer is reused by the next call
     }
 
     fls_status add_cloud_impl(const std::vector<PtI>& cloud_world_full) {  // :182-227
+        const auto t0 = std::chrono::steady_clock::now();
         const std::vector<PtI> cloud_world = voxel_grid(cloud_world_full, p.source_cloud_filter_size);
+        const auto t1 = std::chrono::steady_clock::now();
         // range check first (all-or-nothing)
         for (const PtI& pt : cloud_world) {
             const double f[3] = {double(pt.x) * inv_voxel, double(pt.y) * inv_voxel, double(pt.z) * inv_voxel};
@@ -171,41 +288,72 @@ struct NdtMatcher final : fls_matcher {
                 if (!(std::fabs(f[a]) < double(kKeyLimit))) return FLS_ERR_RANGE;
         }
         if (p.is_localization_mode) { have_fitness_grid = fitness_grid.build(cloud_world, 1.0f, stream) == FLS_OK; }
-        std::set<unsigned long long> active;
+        ++epoch;
+        std::vector<int> touched;
+        touched.reserve(4096);
         for (const PtI& pt : cloud_world) {
             const double pe[3] = {double(pt.x), double(pt.y), double(pt.z)};
             const int kx = int(pe[0] * inv_voxel), ky = int(pe[1] * inv_voxel), kz = int(pe[2] * inv_voxel);  // cast<int>: truncation (:195)
             const unsigned long long key = pack_key(kx, ky, kz);
-            auto it = grids.find(key);
-            if (it == grids.end()) {
-                Voxel v;
+            int vi = grids.find(key);
+            if (vi < 0) {
+                if (!free_ix.empty()) { vi = free_ix.back(); free_ix.pop_back(); }
+                else { vi = int(pool.size()); pool.emplace_back(); }
+                Voxel& v = pool[vi];
                 v.kx = kx; v.ky = ky; v.kz = kz;
-                v.pts = {pe[0], pe[1], pe[2]};
+                v.pts.clear();
+                v.pts.push_back(pe[0]); v.pts.push_back(pe[1]); v.pts.push_back(pe[2]);
+                v.estimated = false;
                 v.num_points = 1;
                 v.vid = next_vid++;
-                data.push_front(std::move(v));
-                grids.emplace(key, data.begin());
-                if (data.size() >= size_t(p.ndt_capacity)) {  // :202-205
-                    const Voxel& b = data.back();
-                    grids.erase(pack_key(b.kx, b.ky, b.kz));
-                    data.pop_back();
+                v.slot = -1;
+                v.dirty = false;
+                v.epoch = 0;
+                lru_push_front(vi);
+                grids.insert(key, vi);
+                ++n_alive;
+                if (n_alive >= size_t(p.ndt_capacity)) {  // :202-205
+                    const int b = lru_tail;
+                    Voxel& e = pool[b];
+                    const unsigned long long ek = pack_key(e.kx, e.ky, e.kz);
+                    grids.erase(ek);
+                    if (e.slot >= 0) evicted_image_keys.push_back(ek);
+                    e.slot = -1;
+                    e.epoch = 0;  // a voxel evicted within the call that touched it gets no UpdateVoxel (the reference would dereference a null entry)
+                    lru_unlink(b);
+                    free_ix.push_back(b);
+                    --n_alive;
+                    if (b == vi) continue;  // capacity 1: the new voxel itself
                 }
             } else {
-                Voxel& v = *it->second;
+                Voxel& v = pool[vi];
                 v.pts.push_back(pe[0]); v.pts.push_back(pe[1]); v.pts.push_back(pe[2]);
                 if (!v.estimated) v.num_points++;
-                data.splice(data.begin(), data, it->second);
-                it->second = data.begin();
+                if (lru_head != vi) { lru_unlink(vi); lru_push_front(vi); }
             }
-            active.insert(key);
+            Voxel& v = pool[vi];
+            if (v.epoch != epoch) { v.epoch = epoch; touched.push_back(vi); }
         }
-        for (unsigned long long k : active) {
-            auto it = grids.find(k);
-            if (it == grids.end()) continue;  // evicted within this very call (the reference would dereference a null entry)
-            update_voxel(*it->second);
+        const auto t2 = std::chrono::steady_clock::now();
+        size_t w = 0;
+        for (size_t k = 0; k < touched.size(); ++k) {
+            const int vi = touched[k];
+            if (pool[vi].epoch != epoch) continue;  // evicted after its touch
+            pool[vi].epoch = epoch + 0x40000000u;   // a pool entry re-created after an eviction appears twice: processed once
+            update_voxel(pool[vi]);
+            touched[w++] = vi;
         }
+        touched.resize(w);
+        for (int vi : touched) pool[vi].epoch = epoch;
         flag_first_scan = p.is_localization_mode ? true : false;  // :222-226
-        rebuild_image();
+        const auto t3 = std::chrono::steady_clock::now();
+        sync_image(touched);
+        if (host_timing) {
+            const auto t4 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            std::fprintf(stderr, "[fls_reg] ndt map update: %zu -> %zu pts | VoxelGrid %.3f ms | insert + LRU %.3f ms | UpdateVoxel x%zu %.3f ms | image sync %.3f ms (%zu voxels)\n",
+                         cloud_world_full.size(), cloud_world.size(), ms(t0, t1), ms(t1, t2), touched.size(), ms(t2, t3), ms(t3, t4), n_alive);
+        }
         return FLS_OK;
     }
     fls_status add_cloud(const float* c0, size_t n0, const float* c1, size_t n1, int stride) override {
@@ -218,7 +366,7 @@ struct NdtMatcher final : fls_matcher {
     }
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
         const NdtMatcher& M = owner ? *owner : *this;  // a batch lane reads its owner's voxel tables
-        if (M.grids.empty() || !M.have_map) return FLS_ERR_STATE;  // CHECK(!grids_.empty()) :230
+        if (M.n_alive == 0 || !M.have_map) return FLS_ERR_STATE;  // CHECK(!grids_.empty()) :230
         const size_t n = scan.n;
         const int nblk = int((n + 63) / 64);
         stats = fls_stats{};
@@ -304,7 +452,9 @@ struct NdtMatcher final : fls_matcher {
     size_t map_size(int slot) const override {
         if (slot == 105) return size_t(src_filter.device_runs);
         if (slot == 106) return size_t(src_filter.host_runs);
-        return data.size();
+        if (slot == 107) return size_t(full_rebuilds);  // image: full rebuilds / incremental updates
+        if (slot == 108) return size_t(incremental_updates);
+        return n_alive;
     }
 };
 

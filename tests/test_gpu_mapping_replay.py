@@ -45,6 +45,8 @@ def run_replay(name, monkeypatch=None):
             assert m.map_size(s) == o.map_size(s), (name, k, s, m.map_size(s), o.map_size(s))
         hist.append(dict(ok=ok_ref, upd=int(o.stats.map_updated), size=o.map_size(0), iters=int(o.stats.iterations)))
         Tprev = T_ref
+    if mode == "IncrementalNDT":
+        r["image_syncs"] = (m.map_size(107), m.map_size(108))  # full rebuilds, incremental updates of the device image
     m.close()
     return r, hist
 
@@ -65,6 +67,8 @@ def test_ndt_mapping_replay():
     cap = r["y"]["ndt_capacity"]
     assert all(x["upd"] == 1 for x in h)
     assert h[-1]["size"] == cap - 1 and sum(1 for x in h if x["size"] == cap - 1) >= 4, "the LRU list must sit at capacity for several scans"
+    full, incr = r["image_syncs"]
+    assert incr >= 4, (full, incr)  # the device image is edited in place (rows, table entries, tombstones of evicted voxels), not re-uploaded
 
 
 def test_loam_full_mapping_replay():
