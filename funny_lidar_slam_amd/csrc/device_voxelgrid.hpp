@@ -13,7 +13,9 @@ namespace fls {
 
 struct DeviceVoxelGrid {
     DevBuf<unsigned> keys, vals;  // ping | pong
-    DevBuf<unsigned> hist, lx, bt;
+    DevBuf<unsigned> hist, lx, bt;  // hist: counts | scanned counts, bt: block totals | scanned
+    DevBuf<float4> sorted;          // the points in sorted order
+    DevBuf<unsigned> dig_tot;       // [pass][256] keys per digit
     DevBuf<float> out;            // x | y | z | i, capacity n each
     DevBuf<VgHeader> d_hdr;
     PinnedBuf<VgHeader> h_hdr;    // [0] = init template, [1] = read-back
@@ -36,7 +38,7 @@ struct DeviceVoxelGrid {
         FLS_HIP(hipMemcpyAsync(d_hdr.p, &h_hdr.p[0], sizeof(VgHeader), hipMemcpyHostToDevice, s));
         const int ni = int(n);
         const int nb = (ni + kVgTile - 1) / kVgTile, nb1 = (ni + kVgBlock - 1) / kVgBlock, nb2 = (ni + kVgScanBlock - 1) / kVgScanBlock;
-        hipLaunchKernelGGL(vg_minmax, dim3(unsigned(std::min(nb1, 256))), dim3(kVgBlock), 0, s, x, y, z, ni, d_hdr.p);
+        hipLaunchKernelGGL(vg_minmax, dim3(unsigned(std::min(nb1, 48))), dim3(kVgBlock), 0, s, x, y, z, ni, d_hdr.p);  // few blocks: six header atomics each
         FLS_HIP(hipMemcpyAsync(&h_hdr.p[1], d_hdr.p, sizeof(VgHeader), hipMemcpyDeviceToHost, s));
         FLS_HIP(hipStreamSynchronize(s));
         const VgHeader& hh = h_hdr.p[1];
@@ -66,25 +68,30 @@ struct DeviceVoxelGrid {
 
         keys.reserve(2 * n);
         vals.reserve(2 * n);
-        hist.reserve(size_t(256) * nb);
+        hist.reserve(size_t(512) * nb);
+        dig_tot.reserve(4 * 256);
+        FLS_HIP(hipMemsetAsync(dig_tot.p, 0, 4 * 256 * sizeof(unsigned), s));
         lx.reserve(n);
-        bt.reserve(size_t(nb2));
+        bt.reserve(size_t(2 * nb2));
+        sorted.reserve(n);
         out.reserve(4 * n);
         unsigned* k0 = keys.p; unsigned* k1 = keys.p + n;
         unsigned* v0 = vals.p; unsigned* v1 = vals.p + n;
         hipLaunchKernelGGL(vg_index, dim3(unsigned(nb1)), dim3(kVgBlock), 0, s, x, y, z, ni, g, k0, v0);
         for (int pass = 0; pass < passes; ++pass) {
-            hipLaunchKernelGGL(vg_hist, dim3(unsigned(nb)), dim3(kVgBlock), 0, s, (const unsigned*)k0, ni, pass * 8, hist.p, nb);
-            hipLaunchKernelGGL(vg_scan, dim3(1), dim3(kVgScanBlock), 0, s, hist.p, 256 * nb, (unsigned*)nullptr);
+            hipLaunchKernelGGL(vg_hist, dim3(unsigned(nb)), dim3(kVgBlock), 0, s, (const unsigned*)k0, ni, pass * 8, hist.p, nb, dig_tot.p + 256 * pass);
+            hipLaunchKernelGGL(vg_scan_rows, dim3(256), dim3(kVgScanBlock), 0, s, (const unsigned*)hist.p, hist.p + 256 * nb, nb,
+                               (const unsigned*)(dig_tot.p + 256 * pass));
             hipLaunchKernelGGL(vg_scatter, dim3(unsigned(nb)), dim3(kVgBlock), 0, s, (const unsigned*)k0, (const unsigned*)v0, k1, v1, ni,
-                               pass * 8, (const unsigned*)hist.p, nb);
+                               pass * 8, (const unsigned*)(hist.p + 256 * nb), nb);
             std::swap(k0, k1);
             std::swap(v0, v1);
         }
-        hipLaunchKernelGGL(vg_heads, dim3(unsigned(nb2)), dim3(kVgScanBlock), 0, s, (const unsigned*)k0, ni, g.total, lx.p, bt.p);
-        hipLaunchKernelGGL(vg_scan, dim3(1), dim3(kVgScanBlock), 0, s, bt.p, nb2, &d_hdr.p->n_out);
-        hipLaunchKernelGGL(vg_centroid, dim3(unsigned(nb1)), dim3(kVgBlock), 0, s, (const unsigned*)k0, (const unsigned*)v0, ni,
-                           (const unsigned*)lx.p, (const unsigned*)bt.p, x, y, z, in, out.p, out.p + n, out.p + 2 * n, out.p + 3 * n);
+        hipLaunchKernelGGL(vg_heads, dim3(unsigned(nb2)), dim3(kVgScanBlock), 0, s, (const unsigned*)k0, (const unsigned*)v0, ni, g.total, x, y, z, in,
+                           sorted.p, lx.p, bt.p);
+        hipLaunchKernelGGL(vg_scan, dim3(1), dim3(kVgScanBlock), 0, s, (const unsigned*)bt.p, bt.p + nb2, nb2, &d_hdr.p->n_out);
+        hipLaunchKernelGGL(vg_centroid, dim3(unsigned(nb1)), dim3(kVgBlock), 0, s, (const unsigned*)k0, (const float4*)sorted.p, ni,
+                           (const unsigned*)lx.p, (const unsigned*)(bt.p + nb2), out.p, out.p + n, out.p + 2 * n, out.p + 3 * n);
         FLS_HIP(hipMemcpyAsync(&h_hdr.p[1], d_hdr.p, sizeof(VgHeader), hipMemcpyDeviceToHost, s));
         FLS_HIP(hipStreamSynchronize(s));
         FLS_HIP(hipGetLastError());

@@ -16,8 +16,8 @@
 // Kernels (n points, 256-thread blocks, tiles of 1024 keys):
 //   vg_minmax      finite bounds (ordered-uint atomics, one set per block)
 //   vg_index       leaf index per point (non-finite points get the sentinel `total`, sorted last and dropped)
-//   vg_hist / vg_hist_scan / vg_scatter   one stable LSD radix pass over 8 bits (ceil(bits(total) / 8) passes)
-//   vg_heads / vg_heads_scan / vg_centroid   run heads -> output slot -> sequential float sums in sorted order
+//   vg_hist / vg_scan_rows / vg_scatter   one stable LSD radix pass over 8 bits (ceil(bits(total) / 8) passes)
+//   vg_heads / vg_scan / vg_centroid      run heads (+ points gathered into sorted order) -> output slot -> sequential float sums
 #pragma once
 #include "device_common.hpp"
 
@@ -111,7 +111,7 @@ vg_index(const float* __restrict__ x, const float* __restrict__ y, const float* 
 
 // per-tile digit counts, digit-major: hist[d * nb + b]
 __global__ void __launch_bounds__(kVgBlock)
-vg_hist(const unsigned* __restrict__ key, const int n, const int shift, unsigned* __restrict__ hist, const int nb) {
+vg_hist(const unsigned* __restrict__ key, const int n, const int shift, unsigned* __restrict__ hist, const int nb, unsigned* __restrict__ dig_tot) {
     __shared__ unsigned c[256];
     c[threadIdx.x] = 0u;
     __syncthreads();
@@ -123,27 +123,67 @@ vg_hist(const unsigned* __restrict__ key, const int n, const int shift, unsigned
     }
     __syncthreads();
     hist[threadIdx.x * nb + blockIdx.x] = c[threadIdx.x];
+    if (c[threadIdx.x]) atomicAdd(&dig_tot[threadIdx.x], c[threadIdx.x]);  // integer sums: order-free
 }
 
-// one workgroup: exclusive scan of `m` counters in place (each thread owns a contiguous chunk)
+// exclusive scan of the digit-major histogram, one workgroup per digit: base = keys of all smaller digits (from the digit
+// totals vg_hist accumulated), then the scan of this digit's row of nb tile counts.  (One workgroup over all 256 x nb
+// counters was a 17-35 us serial chain; this is 256-way parallel.)
 __global__ void __launch_bounds__(kVgScanBlock)
-vg_scan(unsigned* __restrict__ v, const int m, unsigned* __restrict__ total_out) {
-    __shared__ unsigned wsum[kVgScanBlock / 64];
-    const int per = (m + kVgScanBlock - 1) / kVgScanBlock;
-    const int b = threadIdx.x * per, e = min(m, b + per);
-    unsigned s = 0u;
-    for (int i = b; i < e; ++i) s += v[i];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned inc = s;
+vg_scan_rows(const unsigned* __restrict__ hist, unsigned* __restrict__ out, const int nb, const unsigned* __restrict__ dig_tot) {
+    __shared__ unsigned wsum[kVgScanBlock / 64], bsum[kVgScanBlock / 64];
+    const int d = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned lower = ((int)threadIdx.x < d && threadIdx.x < 256u) ? dig_tot[threadIdx.x] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lower += __shfl_xor(lower, o, 64);
+    const unsigned v = (int)threadIdx.x < nb ? hist[d * nb + threadIdx.x] : 0u;
+    unsigned inc = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
     if (lane == 63) wsum[w] = inc;
+    if (lane == 0) bsum[w] = lower;
     __syncthreads();
-    unsigned base = 0u, tot = 0u;
-    for (int q = 0; q < kVgScanBlock / 64; ++q) { const unsigned t = wsum[q]; if (q < w) base += t; tot += t; }
-    unsigned run = base + inc - s;
-    for (int i = b; i < e; ++i) { const unsigned t = v[i]; v[i] = run; run += t; }
-    if (total_out != nullptr && threadIdx.x == 0) *total_out = tot;
+    unsigned wbase = 0u, base = 0u;
+#pragma unroll
+    for (int q = 0; q < kVgScanBlock / 64; ++q) { if (q < w) wbase += wsum[q]; if (q < 4) base += bsum[q]; }
+    if ((int)threadIdx.x < nb) out[d * nb + threadIdx.x] = base + wbase + inc - v;
+}
+
+// one workgroup: exclusive scan of `m` counters, in -> out, in coalesced tiles of 1024 with a carried running total.  The
+// loads of 32 tiles are issued together (one ~1 us memory round trip per 32 tiles instead of one per tile); a contiguous
+// chunk per thread made every wave load touch 64 cache lines: 27-35 us on the one CU that runs this.
+__global__ void __launch_bounds__(kVgScanBlock)
+vg_scan(const unsigned* __restrict__ in, unsigned* __restrict__ out, const int m, unsigned* __restrict__ total_out) {
+    __shared__ unsigned wsum[2][kVgScanBlock / 64];
+    constexpr int B = 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned carry = 0u;
+    for (int sb = 0; sb < m; sb += B * kVgScanBlock) {
+        unsigned v[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const int i = sb + k * kVgScanBlock + (int)threadIdx.x;
+            v[k] = i < m ? in[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const int base = sb + k * kVgScanBlock;
+            if (base < m) {  // uniform
+                const int i = base + (int)threadIdx.x;
+                unsigned inc = v[k];
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+                if (lane == 63) wsum[k & 1][w] = inc;
+                __syncthreads();  // one barrier per tile: the LDS row alternates, a row is rewritten two tiles later
+                unsigned wbase = 0u, tot = 0u;
+#pragma unroll
+                for (int q = 0; q < kVgScanBlock / 64; ++q) { const unsigned t = wsum[k & 1][q]; if (q < w) wbase += t; tot += t; }
+                if (i < m) out[i] = carry + wbase + inc - v[k];
+                carry += tot;
+            }
+        }
+    }
+    if (total_out != nullptr && threadIdx.x == 0) *total_out = carry;
 }
 
 // stable scatter of one tile: destination = scanned histogram entry + keys of the same digit earlier in the tile.
@@ -197,13 +237,17 @@ vg_scatter(const unsigned* __restrict__ kin, const unsigned* __restrict__ vin, u
 
 // run heads of the sorted keys: block-local exclusive rank + block totals
 __global__ void __launch_bounds__(kVgScanBlock)
-vg_heads(const unsigned* __restrict__ key, const int n, const unsigned total, unsigned* __restrict__ lx, unsigned* __restrict__ bt) {
+vg_heads(const unsigned* __restrict__ key, const unsigned* __restrict__ val, const int n, const unsigned total, const float* __restrict__ x,
+         const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ in, float4* __restrict__ sorted,
+         unsigned* __restrict__ lx, unsigned* __restrict__ bt) {
     __shared__ unsigned wsum[kVgScanBlock / 64];
     const int e = blockIdx.x * kVgScanBlock + threadIdx.x;
     unsigned head = 0u;
     if (e < n) {
         const unsigned k = key[e];
         head = (k < total && (e == 0 || key[e - 1] != k)) ? 1u : 0u;
+        const unsigned p = val[e];
+        sorted[e] = make_float4(x[p], y[p], z[p], in[p]);  // the points in sorted order: the centroid walk reads contiguous memory
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned inc = head;
@@ -219,9 +263,8 @@ vg_heads(const unsigned* __restrict__ key, const int n, const unsigned total, un
 
 // one thread per run head: float sums in sorted (= ascending point index) order, centroid = sum / count
 __global__ void __launch_bounds__(kVgBlock)
-vg_centroid(const unsigned* __restrict__ key, const unsigned* __restrict__ val, const int n, const unsigned* __restrict__ lx,
-            const unsigned* __restrict__ bt, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-            const float* __restrict__ in, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, float* __restrict__ oi) {
+vg_centroid(const unsigned* __restrict__ key, const float4* __restrict__ sorted, const int n, const unsigned* __restrict__ lx,
+            const unsigned* __restrict__ bt, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, float* __restrict__ oi) {
     const int e = blockIdx.x * kVgBlock + threadIdx.x;
     if (e >= n) return;
     const unsigned l = lx[e];
@@ -231,8 +274,8 @@ vg_centroid(const unsigned* __restrict__ key, const unsigned* __restrict__ val, 
     float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
     int c = 0;
     for (int q = e; q < n && key[q] == k; ++q) {
-        const unsigned p = val[q];
-        sx += x[p]; sy += y[p]; sz += z[p]; si += in[p];
+        const float4 p = sorted[q];
+        sx += p.x; sy += p.y; sz += p.z; si += p.w;
         ++c;
     }
     const float cf = (float)c;
