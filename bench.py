@@ -344,7 +344,9 @@ def main():
         tb1 = time.perf_counter()
         if rank != 0:
             m.ImportMap(blob)
-        map_bcast = {"blob_MB": blob.size / 1e6, "broadcast_ms": 1e3 * (tb1 - tb0), "import_ms_nonzero_ranks": 1e3 * (time.perf_counter() - tb1)}
+        ti = torch.tensor([time.perf_counter() - tb1], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(ti, op=dist.ReduceOp.MAX)  # rank 0 imports nothing: the slowest importing rank
+        map_bcast = {"blob_MB": blob.size / 1e6, "broadcast_ms": 1e3 * (tb1 - tb0), "import_ms_max_over_ranks": 1e3 * float(ti.item())}
         del blob
     t_map = time.perf_counter() - t_map
     cluster = reg.PointcloudCluster(planar_cloud_=cfg["scan"])
