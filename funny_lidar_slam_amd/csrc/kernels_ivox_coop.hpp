@@ -134,6 +134,23 @@ __device__ __forceinline__ unsigned slot_select(const unsigned idx, const unsign
     return idx + sel;
 }
 
+// nearest_points_ rows: 9.2 MB per launch at the benchmark size, flushed from the write-back L2 at the kernel boundary
+// (2.7 us of this kernel + 3.2 us of re-reads in the fit kernel, measured by removing the stores).  -DFLS_NN_STORE=1 sends
+// them out as nontemporal stores instead: measured -0.5 us per launch, -0.5 us per Match (inside the noise), so the plain
+// store stays the default; write-through (sc1) stores were slower (18.6-21.2 us per launch).
+#ifndef FLS_NN_STORE
+#define FLS_NN_STORE 0
+#endif
+typedef float fls_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_nn_row(float4* p, const float4 v) {
+#if FLS_NN_STORE == 0
+    *p = v;
+#else
+    fls_v4f w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<fls_v4f*>(p));
+#endif
+}
+
 template <int G, bool COUNT, bool DENSE, bool FIRST, bool BAL = false>
 __global__ void __launch_bounds__(256)
 ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
@@ -339,7 +356,7 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
             }
             if (G >= 8) { if (sub == j) mine = m; }
             else if (sub == 0 && active) {  // G == 4: lane 0 writes all five
-                nn_pts[(size_t)q * 5 + j] = mv ? grid.pts[dkey_slot(m)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+                store_nn_row(&nn_pts[(size_t)q * 5 + j], mv ? grid.pts[dkey_slot(m)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1)));
             }
         }
         if (G >= 8 && sub < 5 && active)
