@@ -11,11 +11,49 @@
 
 namespace fls {
 
-struct DeviceVoxelGrid {
+// stable LSD radix sort of {key, value} pairs (8 bits per pass; values keep their input order among equal keys)
+struct DevicePairSort {
     DevBuf<unsigned> keys, vals;  // ping | pong
-    DevBuf<unsigned> hist, lx, bt;  // hist: counts | scanned counts, bt: block totals | scanned
+    DevBuf<unsigned> hist;        // tile counts | scanned
+    DevBuf<unsigned> dig_tot;     // [pass][256] keys per digit
+    size_t n = 0;
+    unsigned* k0 = nullptr;       // input before run(), sorted result after
+    unsigned* v0 = nullptr;
+    void prepare(size_t count) {
+        n = count;
+        keys.reserve(2 * n);
+        vals.reserve(2 * n);
+        k0 = keys.p;
+        v0 = vals.p;
+    }
+    static int passes_for(unsigned long long max_key) {
+        int bits = 1;
+        while ((1ull << bits) <= max_key) ++bits;
+        return (bits + 7) / 8;
+    }
+    void run(int passes, hipStream_t s) {
+        const int ni = int(n), nb = (ni + kVgTile - 1) / kVgTile;
+        hist.reserve(size_t(512) * nb);
+        dig_tot.reserve(4 * 256);
+        FLS_HIP(hipMemsetAsync(dig_tot.p, 0, 4 * 256 * sizeof(unsigned), s));
+        unsigned* k1 = k0 == keys.p ? keys.p + n : keys.p;
+        unsigned* v1 = v0 == vals.p ? vals.p + n : vals.p;
+        for (int pass = 0; pass < passes; ++pass) {
+            hipLaunchKernelGGL(vg_hist, dim3(unsigned(nb)), dim3(kVgBlock), 0, s, (const unsigned*)k0, ni, pass * 8, hist.p, nb, dig_tot.p + 256 * pass);
+            hipLaunchKernelGGL(vg_scan_rows, dim3(256), dim3(kVgScanBlock), 0, s, (const unsigned*)hist.p, hist.p + 256 * nb, nb,
+                               (const unsigned*)(dig_tot.p + 256 * pass));
+            hipLaunchKernelGGL(vg_scatter, dim3(unsigned(nb)), dim3(kVgBlock), 0, s, (const unsigned*)k0, (const unsigned*)v0, k1, v1, ni,
+                               pass * 8, (const unsigned*)(hist.p + 256 * nb), nb);
+            std::swap(k0, k1);
+            std::swap(v0, v1);
+        }
+    }
+};
+
+struct DeviceVoxelGrid {
+    DevicePairSort sort;
+    DevBuf<unsigned> lx, bt;        // bt: block totals | scanned
     DevBuf<float4> sorted;          // the points in sorted order
-    DevBuf<unsigned> dig_tot;       // [pass][256] keys per digit
     DevBuf<float> out;            // x | y | z | i, capacity n each
     DevBuf<VgHeader> d_hdr;
     PinnedBuf<VgHeader> h_hdr;    // [0] = init template, [1] = read-back
@@ -37,7 +75,7 @@ struct DeviceVoxelGrid {
         h_hdr.p[0].n_out = 0u; h_hdr.p[0].pad = 0u;
         FLS_HIP(hipMemcpyAsync(d_hdr.p, &h_hdr.p[0], sizeof(VgHeader), hipMemcpyHostToDevice, s));
         const int ni = int(n);
-        const int nb = (ni + kVgTile - 1) / kVgTile, nb1 = (ni + kVgBlock - 1) / kVgBlock, nb2 = (ni + kVgScanBlock - 1) / kVgScanBlock;
+        const int nb1 = (ni + kVgBlock - 1) / kVgBlock, nb2 = (ni + kVgScanBlock - 1) / kVgScanBlock;
         hipLaunchKernelGGL(vg_minmax, dim3(unsigned(std::min(nb1, 48))), dim3(kVgBlock), 0, s, x, y, z, ni, d_hdr.p);  // few blocks: six header atomics each
         FLS_HIP(hipMemcpyAsync(&h_hdr.p[1], d_hdr.p, sizeof(VgHeader), hipMemcpyDeviceToHost, s));
         FLS_HIP(hipStreamSynchronize(s));
@@ -61,32 +99,18 @@ struct DeviceVoxelGrid {
         g.m1 = int(div_b[0]);
         g.m2 = int(div_b[0] * div_b[1]);
         g.total = unsigned(total);
-        int bits = 1;
-        while ((1ull << bits) <= (unsigned long long)total) ++bits;  // the sentinel `total` itself must sort
-        const int passes = (bits + 7) / 8;
+        const int passes = DevicePairSort::passes_for((unsigned long long)total);  // the sentinel `total` itself must sort
         last_passes = passes;
 
-        keys.reserve(2 * n);
-        vals.reserve(2 * n);
-        hist.reserve(size_t(512) * nb);
-        dig_tot.reserve(4 * 256);
-        FLS_HIP(hipMemsetAsync(dig_tot.p, 0, 4 * 256 * sizeof(unsigned), s));
+        sort.prepare(n);
         lx.reserve(n);
         bt.reserve(size_t(2 * nb2));
         sorted.reserve(n);
         out.reserve(4 * n);
-        unsigned* k0 = keys.p; unsigned* k1 = keys.p + n;
-        unsigned* v0 = vals.p; unsigned* v1 = vals.p + n;
-        hipLaunchKernelGGL(vg_index, dim3(unsigned(nb1)), dim3(kVgBlock), 0, s, x, y, z, ni, g, k0, v0);
-        for (int pass = 0; pass < passes; ++pass) {
-            hipLaunchKernelGGL(vg_hist, dim3(unsigned(nb)), dim3(kVgBlock), 0, s, (const unsigned*)k0, ni, pass * 8, hist.p, nb, dig_tot.p + 256 * pass);
-            hipLaunchKernelGGL(vg_scan_rows, dim3(256), dim3(kVgScanBlock), 0, s, (const unsigned*)hist.p, hist.p + 256 * nb, nb,
-                               (const unsigned*)(dig_tot.p + 256 * pass));
-            hipLaunchKernelGGL(vg_scatter, dim3(unsigned(nb)), dim3(kVgBlock), 0, s, (const unsigned*)k0, (const unsigned*)v0, k1, v1, ni,
-                               pass * 8, (const unsigned*)(hist.p + 256 * nb), nb);
-            std::swap(k0, k1);
-            std::swap(v0, v1);
-        }
+        hipLaunchKernelGGL(vg_index, dim3(unsigned(nb1)), dim3(kVgBlock), 0, s, x, y, z, ni, g, sort.k0, sort.v0);
+        sort.run(passes, s);
+        unsigned* const k0 = sort.k0;
+        unsigned* const v0 = sort.v0;
         hipLaunchKernelGGL(vg_heads, dim3(unsigned(nb2)), dim3(kVgScanBlock), 0, s, (const unsigned*)k0, (const unsigned*)v0, ni, g.total, x, y, z, in,
                            sorted.p, lx.p, bt.p);
         hipLaunchKernelGGL(vg_scan, dim3(1), dim3(kVgScanBlock), 0, s, (const unsigned*)bt.p, bt.p + nb2, nb2, &d_hdr.p->n_out);

@@ -1,5 +1,6 @@
 // host_math.hpp -- the small amount of dense algebra the HOST side of the product needs
 // (map bookkeeping between Matches; nothing here is on the per-point hot path):
+// (the 3x3 routines are __host__ __device__: the device NDT map update, kernels_ndt_update.hpp, runs the same code)
 //   * keyframe gate IsNeedAddCloud: R_last^-1 * R, RPY            icp_optimized.h:218-234
 //   * IncrementalNDT::UpdateVoxel: mean/cov, (S + eps I)^-1, SVD  incremental_ndt.h:91-179
 //   * float cloud transform for map updates                       pointcloud_utility.h:141-195
@@ -9,27 +10,27 @@
 namespace fls {
 namespace hm {
 
-inline void mul3(const double* A, const double* B, double* C) {  // column-major 3x3
+__host__ __device__ inline void mul3(const double* A, const double* B, double* C) {  // column-major 3x3
     double T[9];
     for (int j = 0; j < 3; ++j)
         for (int i = 0; i < 3; ++i) T[i + j * 3] = (A[i] * B[j * 3] + A[i + 3] * B[1 + j * 3]) + A[i + 6] * B[2 + j * 3];
-    std::memcpy(C, T, sizeof(T));
+    for (int k = 0; k < 9; ++k) C[k] = T[k];
 }
-inline double cof3(const double* m, int i, int j) {
+__host__ __device__ inline double cof3(const double* m, int i, int j) {
     const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
     return m[i1 + j1 * 3] * m[i2 + j2 * 3] - m[i1 + j2 * 3] * m[i2 + j1 * 3];
 }
-inline void inv3(const double* m, double* inv) {  // closed-form cofactor inverse (Eigen Matrix3d::inverse)
+__host__ __device__ inline void inv3(const double* m, double* inv) {  // closed-form cofactor inverse (Eigen Matrix3d::inverse)
     const double c00 = cof3(m, 0, 0), c10 = cof3(m, 1, 0), c20 = cof3(m, 2, 0);
     const double invdet = 1.0 / ((c00 * m[0] + c10 * m[1]) + c20 * m[2]);
     inv[0] = c00 * invdet; inv[3] = c10 * invdet; inv[6] = c20 * invdet;
     inv[1] = cof3(m, 0, 1) * invdet; inv[4] = cof3(m, 1, 1) * invdet; inv[7] = cof3(m, 2, 1) * invdet;
     inv[2] = cof3(m, 0, 2) * invdet; inv[5] = cof3(m, 1, 2) * invdet; inv[8] = cof3(m, 2, 2) * invdet;
 }
-inline double nrm3(const double* v) { return std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+__host__ __device__ inline double nrm3(const double* v) { return std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
 
 // two-sided Jacobi SVD of a 3x3, full U and V, singular values descending
-inline void svd3(const double* A, double* U, double* S, double* V) {
+__host__ __device__ inline void svd3(const double* A, double* U, double* S, double* V) {
     const double tiny = std::numeric_limits<double>::min(), prec = 2.0 * std::numeric_limits<double>::epsilon();
     double scale = 0.0;
     for (int i = 0; i < 9; ++i) scale = std::max(scale, std::fabs(A[i]));
@@ -91,10 +92,55 @@ inline void svd3(const double* A, double* U, double* S, double* V) {
         for (int k = i + 1; k < 3; ++k) if (S[k] > S[pos]) pos = k;
         if (S[pos] == 0.0) break;
         if (pos != i) {
-            std::swap(S[i], S[pos]);
-            for (int k = 0; k < 3; ++k) { std::swap(U[k + i * 3], U[k + pos * 3]); std::swap(V[k + i * 3], V[k + pos * 3]); }
+            { const double t = S[i]; S[i] = S[pos]; S[pos] = t; }
+            for (int k = 0; k < 3; ++k) {
+                const double tu = U[k + i * 3]; U[k + i * 3] = U[k + pos * 3]; U[k + pos * 3] = tu;
+                const double tv = V[k + i * 3]; V[k + i * 3] = V[k + pos * 3]; V[k + pos * 3] = tv;
+            }
         }
     }
+}
+
+// ---- IncrementalNDT voxel statistics (incremental_ndt.h:91-179), shared by the host path (matcher_ndt.hpp) and the device
+// map update (kernels_ndt_update.hpp): the same code, the same IEEE operation sequence on both sides ----
+template <class GetPt>
+__host__ __device__ inline void ndt_mean_cov(const int len, GetPt get, double* mean, double* cov) {  // ComputeMeanAndCov :91-110
+    double s[3] = {0.0, 0.0, 0.0}, q[3];
+    for (int k = 0; k < len; ++k) { get(k, q); s[0] += q[0]; s[1] += q[1]; s[2] += q[2]; }
+    for (int a = 0; a < 3; ++a) mean[a] = s[a] / double(len);
+    double c[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < len; ++k) {
+        get(k, q);
+        const double v[3] = {q[0] - mean[0], q[1] - mean[1], q[2] - mean[2]};
+        for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) c[i + j * 3] += v[i] * v[j];
+    }
+    for (int k = 0; k < 9; ++k) cov[k] = c[k] / double(len - 1);
+}
+__host__ __device__ inline void ndt_regularised_info(const double* sigma, double* info) {  // (sigma + 1e-3 I)^-1 :144, :155
+    double m[9];
+    for (int k = 0; k < 9; ++k) m[k] = sigma[k] + ((k % 4 == 0) ? 1.0 : 0.0) * 1.0e-3;
+    inv3(m, info);
+}
+// UpdateMeanAndCov :112-120 followed by the SVD clamp and info = V diag(1/s) U^T :160-176
+__host__ __device__ inline void ndt_merge(double* mu, double* sigma, double* info, const int hist_n, const double* cmu, const double* cvar, const int cn) {
+    double nmu[3], nvar[9];
+    for (int a = 0; a < 3; ++a) nmu[a] = (double(hist_n) * mu[a] + double(cn) * cmu[a]) / double(hist_n + cn);
+    const double dh[3] = {mu[0] - nmu[0], mu[1] - nmu[1], mu[2] - nmu[2]};
+    const double dc[3] = {cmu[0] - nmu[0], cmu[1] - nmu[1], cmu[2] - nmu[2]};
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i)
+            nvar[i + j * 3] = (double(hist_n) * (sigma[i + j * 3] + dh[i] * dh[j]) + double(cn) * (cvar[i + j * 3] + dc[i] * dc[j])) / double(hist_n + cn);
+    for (int a = 0; a < 3; ++a) mu[a] = nmu[a];
+    for (int k = 0; k < 9; ++k) sigma[k] = nvar[k];
+    double U[9], S[3], V[9];
+    svd3(sigma, U, S, V);
+    if (S[1] < S[0] * 1e-3) S[1] = S[0] * 1e-3;
+    if (S[2] < S[0] * 1e-3) S[2] = S[0] * 1e-3;
+    const double il[3] = {1.0 / S[0], 1.0 / S[1], 1.0 / S[2]};
+    double VL[9];
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) VL[i + k * 3] = V[i + k * 3] * il[k];
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) info[i + j * 3] = (VL[i] * U[j] + VL[i + 3] * U[j + 3]) + VL[i + 6] * U[j + 6];
 }
 
 // TransformPointCloud(cloud, Mat4d): R,t -> float, then float r0*x + (r1*y + r2*z) + t

@@ -306,7 +306,7 @@ ndt_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const flo
                 HashEntry e = ng.table[h];
                 while (e.key != key && e.key != kEmptyKey) { h = (h + 1) & ng.mask; e = ng.table[h]; }
                 if (COUNT) c_p++;
-                if (e.key == key) {
+                if (e.key == key && e.count != 0u) {  // count == 0: a voxel that exists but has no estimate yet (device map update)
                     if (COUNT) c_h++;
                     const unsigned v = e.begin;
                     const double e0 = q0 - ng.mu[3 * v], e1 = q1 - ng.mu[3 * v + 1], e2 = q2 - ng.mu[3 * v + 2];

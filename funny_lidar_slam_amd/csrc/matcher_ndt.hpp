@@ -9,6 +9,7 @@
 #include "matcher_base.hpp"
 #include "host_math.hpp"
 #include "device_voxelgrid.hpp"
+#include "kernels_ndt_update.hpp"
 #include "kernels_knn.hpp"
 #include "fitness_host.hpp"
 #include <chrono>
@@ -84,30 +85,19 @@ struct NdtMatcher final : fls_matcher {
         init_common();
         src_filter.init();
         if (const char* e = std::getenv("FLS_HOST_TIMING")) host_timing = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_NDT_DEVICE_UPDATE")) allow_device_update = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_NDT_DEVICE_MARGIN")) { const long c = std::atol(e); if (c >= 0) device_margin = size_t(c); }
         inv_voxel = 1.0 / p.ndt_voxel_size;
         return FLS_OK;
     }
 
     static void mean_cov(const std::vector<double>& pts, double* mean, double* cov) {  // ComputeMeanAndCov :91-110
-        const size_t len = pts.size() / 3;
-        double s[3] = {0, 0, 0};
-        for (size_t k = 0; k < len; ++k) { s[0] += pts[3 * k]; s[1] += pts[3 * k + 1]; s[2] += pts[3 * k + 2]; }
-        for (int a = 0; a < 3; ++a) mean[a] = s[a] / double(len);
-        double c[9] = {0};
-        for (size_t k = 0; k < len; ++k) {
-            const double v[3] = {pts[3 * k] - mean[0], pts[3 * k + 1] - mean[1], pts[3 * k + 2] - mean[2]};
-            for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) c[i + j * 3] += v[i] * v[j];
-        }
-        for (int k = 0; k < 9; ++k) cov[k] = c[k] / double(len - 1);
-    }
-    void regularised_info(Voxel& v) const {
-        double m[9];
-        for (int k = 0; k < 9; ++k) m[k] = v.sigma[k] + ((k % 4 == 0) ? 1.0 : 0.0) * 1.0e-3;
-        hm::inv3(m, v.info);
+        const double* P = pts.data();
+        hm::ndt_mean_cov(int(pts.size() / 3), [P](int k, double* q) { q[0] = P[3 * k]; q[1] = P[3 * k + 1]; q[2] = P[3 * k + 2]; }, mean, cov);
     }
     void update_voxel(Voxel& v) const {  // UpdateVoxel :130-179
         if (flag_first_scan) {
-            if (v.pts.size() / 3 > 1u) { mean_cov(v.pts, v.mu, v.sigma); regularised_info(v); }
+            if (v.pts.size() / 3 > 1u) { mean_cov(v.pts, v.mu, v.sigma); hm::ndt_regularised_info(v.sigma, v.info); }
             else {
                 v.mu[0] = v.pts[0]; v.mu[1] = v.pts[1]; v.mu[2] = v.pts[2];
                 for (int k = 0; k < 9; ++k) v.info[k] = ((k % 4 == 0) ? 1.0 : 0.0) * 1.0e2;
@@ -121,35 +111,17 @@ struct NdtMatcher final : fls_matcher {
         const int npts = int(v.pts.size() / 3);
         if (!v.estimated && npts > p.ndt_min_points_in_voxel) {
             mean_cov(v.pts, v.mu, v.sigma);
-            regularised_info(v);
+            hm::ndt_regularised_info(v.sigma, v.info);
             v.estimated = true;
             v.dirty = true;
             v.pts.clear();
         } else if (v.estimated && npts > p.ndt_min_points_in_voxel) {
-            double cmu[3], cvar[9], nmu[3], nvar[9];
+            double cmu[3], cvar[9];
             mean_cov(v.pts, cmu, cvar);
-            const int hm_ = v.num_points, cn = npts;  // UpdateMeanAndCov :112-120
-            for (int a = 0; a < 3; ++a) nmu[a] = (double(hm_) * v.mu[a] + double(cn) * cmu[a]) / double(hm_ + cn);
-            const double dh[3] = {v.mu[0] - nmu[0], v.mu[1] - nmu[1], v.mu[2] - nmu[2]};
-            const double dc[3] = {cmu[0] - nmu[0], cmu[1] - nmu[1], cmu[2] - nmu[2]};
-            for (int j = 0; j < 3; ++j)
-                for (int i = 0; i < 3; ++i)
-                    nvar[i + j * 3] = (double(hm_) * (v.sigma[i + j * 3] + dh[i] * dh[j]) + double(cn) * (cvar[i + j * 3] + dc[i] * dc[j])) / double(hm_ + cn);
-            std::memcpy(v.mu, nmu, sizeof(nmu));
-            std::memcpy(v.sigma, nvar, sizeof(nvar));
+            hm::ndt_merge(v.mu, v.sigma, v.info, v.num_points, cmu, cvar, npts);
             v.num_points += npts;
             v.dirty = true;
             v.pts.clear();
-            double U[9], S[3], V[9];
-            hm::svd3(v.sigma, U, S, V);
-            if (S[1] < S[0] * 1e-3) S[1] = S[0] * 1e-3;
-            if (S[2] < S[0] * 1e-3) S[2] = S[0] * 1e-3;
-            const double il[3] = {1.0 / S[0], 1.0 / S[1], 1.0 / S[2]};
-            double VL[9];
-            for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) VL[i + k * 3] = V[i + k * 3] * il[k];
-            for (int j = 0; j < 3; ++j)
-                for (int i = 0; i < 3; ++i)
-                    v.info[i + j * 3] = (VL[i] * U[j] + VL[i + 3] * U[j + 3]) + VL[i + 6] * U[j + 6];
         }
     }
 
@@ -277,6 +249,212 @@ struct NdtMatcher final : fls_matcher {
         FLS_HIP(hipStreamSynchronize(stream));  // the staging buffer is reused by the next call
     }
 
+    // ---- device map update (kernels_ndt_update.hpp): the image holds EVERY alive voxel (table count = "estimated"), the
+    // per-voxel bookkeeping lives in device rows, the host mirror (pool / LRU list / key map) is stale until
+    // sync_host_from_device().  Entered after a host-path update in mapping mode, left for good by the first refused batch.
+    bool allow_device_update = true;  // FLS_NDT_DEVICE_UPDATE
+    size_t device_margin = 4096;      // FLS_NDT_DEVICE_MARGIN: voxels below the LRU capacity at which device mode is not entered
+    bool device_mode = false, device_left = false;
+    DevBuf<unsigned long long> r_key, r_stamp;
+    DevBuf<unsigned> r_hslot;
+    DevBuf<int> r_np;
+    DevBuf<unsigned char> r_est, r_cc;
+    DevBuf<double> r_carry, d_sigma;
+    DevBuf<NdtUpdState> d_upd;
+    PinnedBuf<NdtUpdState> h_upd;
+    DevBuf<unsigned> u_slot, u_lx, u_bt;
+    DevBuf<float> u_cloud;
+    PinnedBuf<float> u_stage;
+    DevicePairSort u_sort;
+    size_t dev_rows = 0, dev_alive = 0, dev_table = 0;
+    int dev_next_vid = 0;
+    unsigned long long dev_epoch = 0, device_batches = 0, refused_batches = 0;
+    size_t alive() const { return device_mode ? dev_alive : n_alive; }
+    NdtRows rows_dev() { return NdtRows{r_key.p, r_hslot.p, r_np.p, r_est.p, r_cc.p, r_carry.p, d_mu.p, d_sigma.p, d_info.p, d_vid.p, r_stamp.p}; }
+    void reserve_rows(size_t cap, bool keep) {
+        r_key.reserve(cap, keep, stream); r_stamp.reserve(cap, keep, stream); r_hslot.reserve(cap, keep, stream); r_np.reserve(cap, keep, stream);
+        r_est.reserve(cap, keep, stream); r_cc.reserve(cap, keep, stream); r_carry.reserve(cap * kNdtCarry * 3, keep, stream);
+        d_sigma.reserve(cap * 9, keep, stream); d_mu.reserve(cap * 3, keep, stream); d_info.reserve(cap * 9, keep, stream); d_vid.reserve(cap, keep, stream);
+        row_cap = cap;
+    }
+    bool can_enter_device_mode() const {
+        return allow_device_update && !device_left && !device_mode && !owner && !p.is_localization_mode && !flag_first_scan &&
+               p.ndt_min_points_in_voxel <= kNdtCarry && p.ndt_min_points_in_voxel >= 0 && n_alive + device_margin < size_t(p.ndt_capacity);
+    }
+    // uploads the whole host mirror as rows (LRU order: row 0 = least recently touched) + a table holding every alive voxel
+    void enter_device_mode(size_t batch_hint) {
+        const size_t na = n_alive;
+        const unsigned ts = GridImage::table_size_for(na + na / 2 + 2 * batch_hint + 65536);
+        mask = ts - 1;
+        h_table.assign(ts, HashEntry{kEmptyKey, kNdtNewBit, 0u});
+        std::vector<unsigned long long> k(na), st(na);
+        std::vector<unsigned> hs(na);
+        std::vector<int> np(na), vid(na);
+        std::vector<unsigned char> est(na), cc(na);
+        std::vector<double> carry(na * kNdtCarry * 3, 0.0), mu(na * 3), sg(na * 9), inf(na * 9);
+        size_t r = 0;
+        for (int vi = lru_tail; vi >= 0; vi = pool[vi].prev, ++r) {
+            Voxel& v = pool[vi];
+            const unsigned long long key = pack_key(v.kx, v.ky, v.kz);
+            unsigned h = hash_key(key) & mask;
+            while (h_table[h].key != kEmptyKey) h = (h + 1) & mask;
+            h_table[h] = HashEntry{key, unsigned(r), v.estimated ? 1u : 0u};
+            k[r] = key; hs[r] = h; st[r] = r + 1; np[r] = v.num_points; vid[r] = v.vid; est[r] = v.estimated ? 1 : 0;
+            // unconsumed points: at most min_points of them matter (a saturated voxel's list is never read again)
+            const size_t keep = (v.estimated && v.num_points > p.ndt_max_points_in_voxel) ? 0 : v.pts.size() / 3;
+            cc[r] = (unsigned char)std::min<size_t>(keep, kNdtCarry);
+            for (size_t q = 0; q < size_t(cc[r]) * 3; ++q) carry[r * kNdtCarry * 3 + q] = v.pts[q];
+            std::memcpy(&mu[3 * r], v.mu, sizeof(v.mu)); std::memcpy(&sg[9 * r], v.sigma, sizeof(v.sigma)); std::memcpy(&inf[9 * r], v.info, sizeof(v.info));
+            v.slot = -1;
+            v.dirty = false;
+        }
+        reserve_rows(na + na / 2 + 2 * batch_hint + 65536, false);
+        d_table.reserve(ts);
+        auto up = [&](void* d, const void* h, size_t bytes) { if (bytes) FLS_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream)); };
+        up(d_table.p, h_table.data(), ts * sizeof(HashEntry));
+        up(r_key.p, k.data(), na * 8); up(r_stamp.p, st.data(), na * 8); up(r_hslot.p, hs.data(), na * 4); up(r_np.p, np.data(), na * 4);
+        up(d_vid.p, vid.data(), na * 4); up(r_est.p, est.data(), na); up(r_cc.p, cc.data(), na); up(r_carry.p, carry.data(), carry.size() * 8);
+        up(d_mu.p, mu.data(), mu.size() * 8); up(d_sigma.p, sg.data(), sg.size() * 8); up(d_info.p, inf.data(), inf.size() * 8);
+        FLS_HIP(hipStreamSynchronize(stream));
+        dev_rows = dev_alive = na;
+        dev_table = ts;
+        dev_next_vid = next_vid;
+        dev_epoch = na + 1;
+        d_upd.reserve(1);
+        h_upd.reserve(2);
+        edit_table.clear(); edit_rows.clear(); evicted_image_keys.clear(); changed_idx.clear(); free_rows.clear();
+        have_map = true;
+        device_mode = true;
+        ++full_rebuilds;
+    }
+    // the table of a device-mode image is rebuilt on the device when the next batch might fill it past one half
+    void grow_table_device(size_t need_entries) {
+        const unsigned ts = GridImage::table_size_for(need_entries + need_entries / 2 + 65536);
+        DevBuf<HashEntry> nt;
+        nt.reserve(ts);
+        hipLaunchKernelGGL(ndt_table_fill_kernel, dim3((ts + 255) / 256), dim3(256), 0, stream, nt.p, ts);
+        hipLaunchKernelGGL(ndt_table_rehash_kernel, dim3(unsigned((dev_rows + 255) / 256)), dim3(256), 0, stream, nt.p, ts - 1, rows_dev(), unsigned(dev_rows));
+        FLS_HIP(hipStreamSynchronize(stream));
+        std::swap(d_table.p, nt.p);
+        std::swap(d_table.cap, nt.cap);
+        mask = ts - 1;
+        dev_table = ts;
+    }
+    // one map update on the device; false = refused (nothing changed): the caller syncs the host mirror and replays on the host
+    bool device_add_cloud(const std::vector<PtI>& cloud) {
+        const size_t n = cloud.size();
+        if (n == 0) return true;
+        u_stage.reserve(3 * n);
+        u_cloud.reserve(3 * n);
+        for (size_t i = 0; i < n; ++i) { u_stage.p[i] = cloud[i].x; u_stage.p[n + i] = cloud[i].y; u_stage.p[2 * n + i] = cloud[i].z; }
+        FLS_HIP(hipMemcpyAsync(u_cloud.p, u_stage.p, 3 * n * sizeof(float), hipMemcpyHostToDevice, stream));
+        return device_add_cloud_dev(u_cloud.p, u_cloud.p + n, u_cloud.p + 2 * n, n);
+    }
+    // the filtered world cloud already on the device (x, y, z of n points, cloud order)
+    bool device_add_cloud_dev(const float* x, const float* y, const float* z, const size_t n) {
+        if (n == 0) return true;
+        if (n > size_t(kVgMaxBlocks) * kVgTile) return false;
+        if ((dev_alive + n) * 2 + 2 > dev_table) grow_table_device(dev_alive + n);
+        if (dev_rows + n > row_cap) reserve_rows(dev_rows + dev_rows / 2 + 2 * n, true);
+        NdtUpdState& hs = h_upd.p[0];
+        hs = NdtUpdState{};
+        hs.n_rows = unsigned(dev_rows); hs.n_alive = unsigned(dev_alive); hs.next_vid = dev_next_vid; hs.epoch = dev_epoch;
+        hs.capacity = unsigned(p.ndt_capacity); hs.row_cap = unsigned(std::min<size_t>(row_cap, 0x7fffffffu));
+        FLS_HIP(hipMemcpyAsync(d_upd.p, &hs, sizeof(NdtUpdState), hipMemcpyHostToDevice, stream));
+        const int ni = int(n), nb1 = (ni + 255) / 256, nb2 = (ni + kVgScanBlock - 1) / kVgScanBlock;
+        u_slot.reserve(n); u_lx.reserve(n); u_bt.reserve(size_t(2 * nb2));
+        const NdtRows R = rows_dev();
+        hipLaunchKernelGGL(ndt_upd_locate, dim3(unsigned(nb1)), dim3(256), 0, stream, x, y, z, ni, inv_voxel, d_table.p, mask, u_slot.p, d_upd.p);
+        hipLaunchKernelGGL(ndt_upd_creators, dim3(unsigned(nb2)), dim3(kVgScanBlock), 0, stream, ni, (const HashEntry*)d_table.p, (const unsigned*)u_slot.p, u_lx.p, u_bt.p);
+        hipLaunchKernelGGL(vg_scan, dim3(1), dim3(kVgScanBlock), 0, stream, (const unsigned*)u_bt.p, u_bt.p + nb2, nb2, &d_upd.p->n_new);
+        hipLaunchKernelGGL(ndt_upd_decide, dim3(1), dim3(1), 0, stream, d_upd.p);
+        hipLaunchKernelGGL(ndt_upd_create, dim3(unsigned(nb1)), dim3(256), 0, stream, x, y, z, ni, inv_voxel, d_table.p, (const unsigned*)u_slot.p,
+                           (const unsigned*)u_lx.p, (const unsigned*)(u_bt.p + nb2), R, (const NdtUpdState*)d_upd.p);
+        u_sort.prepare(n);
+        hipLaunchKernelGGL(ndt_upd_rowkeys, dim3(unsigned(nb1)), dim3(256), 0, stream, ni, (const HashEntry*)d_table.p, (const unsigned*)u_slot.p, u_sort.k0, u_sort.v0,
+                           (const NdtUpdState*)d_upd.p);
+        u_sort.run(DevicePairSort::passes_for((unsigned long long)(dev_rows + n)), stream);
+        hipLaunchKernelGGL(ndt_upd_voxel, dim3(unsigned((ni + 63) / 64)), dim3(64), 0, stream, (const unsigned*)u_sort.k0, (const unsigned*)u_sort.v0, ni, x, y, z, R,
+                           d_table.p, d_upd.p, int(p.ndt_min_points_in_voxel), int(p.ndt_max_points_in_voxel));
+        hipLaunchKernelGGL(ndt_upd_commit, dim3(1), dim3(1), 0, stream, d_upd.p, unsigned(n));
+        FLS_HIP(hipMemcpyAsync(&h_upd.p[1], d_upd.p, sizeof(NdtUpdState), hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipStreamSynchronize(stream));
+        FLS_HIP(hipGetLastError());
+        const NdtUpdState& o = h_upd.p[1];
+        if (!o.apply) { ++refused_batches; return false; }
+        dev_rows = o.n_rows; dev_alive = o.n_alive; dev_next_vid = o.next_vid; dev_epoch = o.epoch;
+        last_touched = o.touched;
+        ++device_batches;
+        return true;
+    }
+    unsigned last_touched = 0;
+    // opt-in device source filter (FLS_DEVICE_VOXELGRID=1): the filtered scan never left the device -- transform it, filter it
+    // again (the reference's second VoxelGrid, :186) and update the map without touching the host.  false: not applied (the
+    // caller takes the host path, which also reports a key out of range)
+    DevBuf<float> w_cloud;
+    DeviceVoxelGrid map_vg;
+    unsigned long long resident_updates = 0;
+    bool device_update_from_resident_source(const double* T_in) {
+        const size_t n = src_filter.vg.n_out;
+        if (n == 0) return false;
+        const auto t0 = std::chrono::steady_clock::now();
+        w_cloud.reserve(3 * n);
+        XformF xf;
+        for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) xf.R[i + j * 3] = float(T_in[i + j * 4]);
+        for (int i = 0; i < 3; ++i) xf.t[i] = float(T_in[12 + i]);
+        hipLaunchKernelGGL(xform_cloud_f_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, src_filter.vg.ox(), src_filter.vg.oy(), src_filter.vg.oz(),
+                           int(n), xf, w_cloud.p, w_cloud.p + n, w_cloud.p + 2 * n);
+        if (!map_vg.run(w_cloud.p, w_cloud.p + n, w_cloud.p + 2 * n, src_filter.vg.oi(), n, p.source_cloud_filter_size, stream)) return false;
+        if (!device_add_cloud_dev(map_vg.ox(), map_vg.oy(), map_vg.oz(), map_vg.n_out)) {
+            sync_host_from_device();
+            return false;
+        }
+        ++resident_updates;
+        if (host_timing) {
+            const auto t1 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[fls_reg] ndt map update (device, resident source): %zu -> %zu pts | transform + VoxelGrid + UpdateVoxel x%u %.3f ms (%zu voxels)\n", n,
+                         map_vg.n_out, last_touched, std::chrono::duration<double, std::milli>(t1 - t0).count(), dev_alive);
+        }
+        return true;
+    }
+    // device rows -> host mirror (pool, LRU list in stamp order, key map); the image is rebuilt by the next host-path update
+    void sync_host_from_device() {
+        const size_t nr = dev_rows;
+        std::vector<unsigned long long> k(nr), st(nr);
+        std::vector<int> np(nr), vid(nr);
+        std::vector<unsigned char> est(nr), cc(nr);
+        std::vector<double> carry(nr * kNdtCarry * 3), mu(nr * 3), sg(nr * 9), inf(nr * 9);
+        auto dn = [&](void* h, const void* d, size_t bytes) { if (bytes) FLS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream)); };
+        dn(k.data(), r_key.p, nr * 8); dn(st.data(), r_stamp.p, nr * 8); dn(np.data(), r_np.p, nr * 4); dn(vid.data(), d_vid.p, nr * 4);
+        dn(est.data(), r_est.p, nr); dn(cc.data(), r_cc.p, nr); dn(carry.data(), r_carry.p, carry.size() * 8);
+        dn(mu.data(), d_mu.p, mu.size() * 8); dn(sg.data(), d_sigma.p, sg.size() * 8); dn(inf.data(), d_info.p, inf.size() * 8);
+        FLS_HIP(hipStreamSynchronize(stream));
+        std::vector<size_t> order(nr);
+        for (size_t i = 0; i < nr; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return st[a] < st[b]; });  // stamps are unique
+        pool.clear(); free_ix.clear(); grids.clear();
+        lru_head = lru_tail = -1;
+        n_alive = 0;
+        pool.reserve(nr);
+        for (const size_t r : order) {  // oldest first: every push_front leaves the most recent at the head
+            pool.emplace_back();
+            Voxel& v = pool.back();
+            unpack_key(k[r], v.kx, v.ky, v.kz);
+            v.pts.assign(carry.begin() + r * kNdtCarry * 3, carry.begin() + r * kNdtCarry * 3 + size_t(cc[r]) * 3);
+            std::memcpy(v.mu, &mu[3 * r], sizeof(v.mu)); std::memcpy(v.sigma, &sg[9 * r], sizeof(v.sigma)); std::memcpy(v.info, &inf[9 * r], sizeof(v.info));
+            v.estimated = est[r] != 0; v.num_points = np[r]; v.vid = vid[r];
+            const int vi = int(pool.size()) - 1;
+            lru_push_front(vi);
+            grids.insert(k[r], vi);
+            ++n_alive;
+        }
+        next_vid = dev_next_vid;
+        device_mode = false;
+        device_left = true;
+        have_map = false;  // the host-path image (estimated voxels only, host-assigned rows) is rebuilt from the mirror
+        rebuild_image();
+    }
+
     fls_status add_cloud_impl(const std::vector<PtI>& cloud_world_full) {  // :182-227
         const auto t0 = std::chrono::steady_clock::now();
         const std::vector<PtI> cloud_world = voxel_grid(cloud_world_full, p.source_cloud_filter_size);
@@ -288,6 +466,18 @@ struct NdtMatcher final : fls_matcher {
                 if (!(std::fabs(f[a]) < double(kKeyLimit))) return FLS_ERR_RANGE;
         }
         if (p.is_localization_mode) { have_fitness_grid = fitness_grid.build(cloud_world, 1.0f, stream) == FLS_OK; }
+        if (device_mode) {
+            if (!flag_first_scan && device_add_cloud(cloud_world)) {
+                if (host_timing) {
+                    const auto t4 = std::chrono::steady_clock::now();
+                    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                    std::fprintf(stderr, "[fls_reg] ndt map update (device): %zu -> %zu pts | VoxelGrid %.3f ms | upload + device UpdateVoxel x%u %.3f ms (%zu voxels)\n",
+                                 cloud_world_full.size(), cloud_world.size(), ms(t0, t1), last_touched, ms(t1, t4), dev_alive);
+                }
+                return FLS_OK;
+            }
+            sync_host_from_device();  // refused (a batch that would evict, a key out of range): exact sequential replay below
+        }
         ++epoch;
         std::vector<int> touched;
         touched.reserve(4096);
@@ -348,6 +538,7 @@ struct NdtMatcher final : fls_matcher {
         flag_first_scan = p.is_localization_mode ? true : false;  // :222-226
         const auto t3 = std::chrono::steady_clock::now();
         sync_image(touched);
+        if (can_enter_device_mode()) enter_device_mode(cloud_world.size());
         if (host_timing) {
             const auto t4 = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -366,7 +557,7 @@ struct NdtMatcher final : fls_matcher {
     }
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
         const NdtMatcher& M = owner ? *owner : *this;  // a batch lane reads its owner's voxel tables
-        if (M.n_alive == 0 || !M.have_map) return FLS_ERR_STATE;  // CHECK(!grids_.empty()) :230
+        if (M.alive() == 0 || !M.have_map) return FLS_ERR_STATE;  // CHECK(!grids_.empty()) :230
         const size_t n = scan.n;
         const int nblk = int((n + 63) / 64);
         stats = fls_stats{};
@@ -409,9 +600,14 @@ struct NdtMatcher final : fls_matcher {
         // has_converge = true unconditionally (:325, Q10)
         fls_status rc = FLS_OK;
         if (!p.is_localization_mode && update_map && !owner) {
-            src_filter.materialize(stream, source);
-            const fls_status arc = add_cloud_impl(hm::xform_cloud_f(source, T_in));  // Q11: transformed with the INPUT T (:327-329)
-            if (arc != FLS_OK) rc = arc; else stats.map_updated = 1;
+            // Q11: the cloud is transformed with the INPUT T (:327-329)
+            if (device_mode && !flag_first_scan && src_filter.resident && device_update_from_resident_source(T_in)) {
+                stats.map_updated = 1;
+            } else {
+                src_filter.materialize(stream, source);
+                const fls_status arc = add_cloud_impl(hm::xform_cloud_f(source, T_in));
+                if (arc != FLS_OK) rc = arc; else stats.map_updated = 1;
+            }
         }
         std::memcpy(T, s.T, sizeof(double) * 16);
         std::memcpy(final_T, s.T, sizeof(final_T));
@@ -454,7 +650,10 @@ struct NdtMatcher final : fls_matcher {
         if (slot == 106) return size_t(src_filter.host_runs);
         if (slot == 107) return size_t(full_rebuilds);  // image: full rebuilds / incremental updates
         if (slot == 108) return size_t(incremental_updates);
-        return n_alive;
+        if (slot == 109) return size_t(device_batches);  // map updates applied on the device / refused (replayed on the host)
+        if (slot == 110) return size_t(refused_batches);
+        if (slot == 111) return size_t(resident_updates);  // map updates fed by the device-resident filtered scan
+        return alive();
     }
 };
 

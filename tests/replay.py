@@ -39,6 +39,8 @@ SCENARIOS = {
     "icp": dict(mode="IcpOptimized", y=dict(reg.YAML_NCLT_ICP, local_map_size=3, optimization_iter_num=12), frames=11, n_az=90, rng_job=21,
                 max_range=45.0, lidar="v64"),
     "ndt": dict(mode="IncrementalNDT", y=dict(reg.YAML_NCLT_NDT, ndt_capacity=2600), frames=10, n_az=100, rng_job=22, max_range=40.0, lidar="v64"),
+    # same frames, capacity far away: the map update runs on the device (kernels_ndt_update.hpp)
+    "ndt_dev": dict(mode="IncrementalNDT", y=dict(reg.YAML_NCLT_NDT, ndt_capacity=100000), frames=10, n_az=100, rng_job=22, max_range=40.0, lidar="v64"),
     "loam": dict(mode="LoamFull_KdTree", y=dict(reg.YAML_NCLT_LOAM_FULL), frames=11, n_az=90, rng_job=23, max_range=45.0, lidar="v64"),
     "ivox": dict(mode="PointToPlane_IVOX", y=dict(reg.YAML_NCLT_IVOX), frames=7, n_az=60, rng_job=24, max_range=38.0, lidar="v64"),
 }

@@ -47,6 +47,7 @@ def run_replay(name, monkeypatch=None):
         Tprev = T_ref
     if mode == "IncrementalNDT":
         r["image_syncs"] = (m.map_size(107), m.map_size(108))  # full rebuilds, incremental updates of the device image
+        r["device_updates"] = (m.map_size(109), m.map_size(110))  # map updates applied on the device / refused
     m.close()
     return r, hist
 
@@ -69,6 +70,35 @@ def test_ndt_mapping_replay():
     assert h[-1]["size"] == cap - 1 and sum(1 for x in h if x["size"] == cap - 1) >= 4, "the LRU list must sit at capacity for several scans"
     full, incr = r["image_syncs"]
     assert incr >= 4, (full, incr)  # the device image is edited in place (rows, table entries, tombstones of evicted voxels), not re-uploaded
+
+
+def test_ndt_mapping_replay_device_update():
+    """The same frames with the LRU capacity far away: after the first (host) update the handle enters device mode and every later
+    AddCloud -- key lookup / voxel creation (ids in first-appearance order), pending-point carry, pooled mean + covariance, SVD
+    clamp, LRU stamps -- runs in kernels_ndt_update.hpp; correspondence ids (voxel ids), n_valid, poses and map sizes of every
+    frame equal the oracle's."""
+    r, h = run_replay("ndt_dev")
+    applied, refused = r["device_updates"]
+    assert all(x["upd"] == 1 for x in h)
+    assert applied >= len(h) - 1 and refused == 0, (applied, refused)
+
+
+def test_ndt_mapping_replay_device_refusal(monkeypatch):
+    """Capacity 2,600 with no safety margin: device mode is entered below the capacity, the first batch that would evict is
+    refused without side effects, the device state comes back to the host mirror (LRU order from the stamps, pending points
+    from the carry buffers) and the exact sequential path takes over -- including the evictions."""
+    monkeypatch.setenv("FLS_NDT_DEVICE_MARGIN", "0")
+    r, h = run_replay("ndt")
+    applied, refused = r["device_updates"]
+    cap = r["y"]["ndt_capacity"]
+    assert refused == 1 and applied >= 1, (applied, refused)
+    assert h[-1]["size"] == cap - 1
+
+
+def test_ndt_mapping_replay_host_path_ab(monkeypatch):
+    monkeypatch.setenv("FLS_NDT_DEVICE_UPDATE", "0")
+    r, h = run_replay("ndt_dev")
+    assert r["device_updates"] == (0, 0) and r["image_syncs"][1] >= 1  # small map: most updates touch too much of it for in-place edits
 
 
 def test_loam_full_mapping_replay():

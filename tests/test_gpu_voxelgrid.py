@@ -149,7 +149,8 @@ def test_match_with_device_source_filter(mode, y, cid, loc, monkeypatch):
         ok = m.Match(util.cluster_for(mode, cfg["scan"]), T, update_map=not loc)
         T2 = T.copy()
         ok2 = m.Match(util.cluster_for(mode, cfg["scan"]), T2, update_map=not loc)
-        res[dev] = (ok, T.copy(), m.stats.n_source, m.stats.iterations, ok2, T2.copy(), m.map_size(0), m.map_size(105), m.map_size(106))
+        res[dev] = (ok, T.copy(), m.stats.n_source, m.stats.iterations, ok2, T2.copy(), m.map_size(0), m.map_size(105), m.map_size(106),
+                    m.map_size(111) if mode == "IncrementalNDT" else 0)
         m.close()
     h, d = res[0], res[1]
     assert h[7] == 0 and h[8] == 2 and d[7] == 2 and d[8] == 0  # which filter ran
@@ -158,3 +159,5 @@ def test_match_with_device_source_filter(mode, y, cid, loc, monkeypatch):
         dt, dr = synth.pose_error(a, b)
         assert dt < 1e-6 and dr < 1e-6, (dt, dr)
     assert h[6] == d[6]  # map size after the updates
+    if mode == "IncrementalNDT":  # with the device filter the whole update chain (transform, second VoxelGrid, UpdateVoxel) stays on the device
+        assert h[9] == 0 and d[9] == 2, (h[9], d[9])
