@@ -271,9 +271,49 @@ def bench_mapping_mode(reg, synth, cfg, n_scans=6):
                       "map_points_after": m.map_size()}
         m.close()
     os.environ.pop("FLS_IVOX_DEVICE_UPDATE", None)
+    try:
+        res["incremental_ndt"] = bench_ndt_mapping_mode(reg, synth)
+    except Exception as e:  # never at the expense of the rest of the line
+        res["incremental_ndt"] = {"error": repr(e)[:200]}
     res["note"] = (f"{n_scans} consecutive scans (0.5 m / 0.5 deg steps), scan resident; medians over scans 1..; the scans that follow a map update run more "
                    "iterations against a map the insert rule has densified near the sensor, so ms_match_only here is not the headline step")
     return res
+
+
+def bench_ndt_mapping_mode(reg, synth, n_scans=6):
+    """configs[2] as the ROS adapter issues it: fls_match from HOST buffers with update_map = 1 (source VoxelGrid + Match + the
+    reference's in-Match AddCloud), three settings: everything the round-1 way on the host, the device map update behind the
+    exact host filters (default), and the opt-in device filters (the whole chain on the device)."""
+    cfg = synth.make_config(2)
+    rng = synth.rng_for(2, 321)
+    Tgt = cfg["T_gt"].copy()
+    scans = []
+    for k in range(n_scans):
+        scans.append(synth.cast_scan(cfg["scene"], Tgt, rng=rng, **synth.VELODYNE_64))
+        Tgt = Tgt @ synth.random_pose(rng, 0.3, 0.2)
+    out = {}
+    keys = ("FLS_NDT_DEVICE_UPDATE", "FLS_DEVICE_VOXELGRID")
+    prev = {k: os.environ.get(k) for k in keys}
+    for label, env in (("host_update_host_filters", ("0", "0")), ("device_update_host_filters_default", ("1", "0")), ("device_update_device_filters_opt_in", ("1", "1"))):
+        os.environ.update(dict(zip(keys, env)))
+        m = reg.make_matcher("IncrementalNDT", reg.YAML_NCLT_NDT)
+        m.AddCloudToLocalMap([cfg["map"]])
+        guess = np.eye(4)
+        tm, tb = [], []
+        for scan in scans:
+            cl = reg.PointcloudCluster(ordered_cloud_=scan)
+            T = guess.copy(); t = time.perf_counter(); m.Match(cl, T, update_map=False); tm.append(time.perf_counter() - t)
+            T = guess.copy(); t = time.perf_counter(); m.Match(cl, T, update_map=True); tb.append(time.perf_counter() - t)
+            guess = T
+        out[label] = {"ms_match_only": 1e3 * float(np.median(tm[1:])), "ms_per_scan_match_plus_update": 1e3 * float(np.median(tb[1:])),
+                      "device_batches": m.map_size(109), "refused_batches": m.map_size(110), "voxels_after": m.map_size()}
+        m.close()
+    for k, v in prev.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    return out
 
 
 def main():
