@@ -9,7 +9,7 @@
 
 namespace fls {
 
-inline CellGridDev cell_dev(const CellGridImage& g) { return CellGridDev{g.dev(), 1.0 / double(g.cell), double(g.cell), g.rings, g.window()}; }
+inline CellGridDev cell_dev(const CellGridImage& g) { return CellGridDev{g.dev(), 1.0 / double(g.cell), double(g.cell), g.rings, g.window(), g.d_by_id.p}; }
 
 inline fls_status fitness_score_device(fls_matcher& m, const CellGridImage& grid, const DevScan& scan, const double* final_T,
                                        float max_range, float* score) {

@@ -516,8 +516,16 @@ struct CellGridImage : GridImage {
     float cell = 1.0f, inv_cell = 1.0f;
     int rings = 1;  // 2: the cell is half the gate radius, the search covers the 5x5x5 block in two stages
     size_t n_cells = 0;
-    fls_status build(const std::vector<PtI>& cloud, float cell_size, hipStream_t s, int n_rings = 1) {
+    DevBuf<float4> d_by_id;  // optional: the cloud in its own order (see CellGridDev::by_id)
+    fls_status build(const std::vector<PtI>& cloud, float cell_size, hipStream_t s, int n_rings = 1, bool with_by_id = false) {
         rings = n_rings;
+        if (with_by_id && !cloud.empty()) {
+            std::vector<Pt4> ordered(cloud.size());
+            for (size_t i = 0; i < cloud.size(); ++i) ordered[i] = Pt4{cloud[i].x, cloud[i].y, cloud[i].z, int(i)};
+            d_by_id.reserve(cloud.size());
+            FLS_HIP(hipMemcpyAsync(d_by_id.p, ordered.data(), ordered.size() * sizeof(Pt4), hipMemcpyHostToDevice, s));
+            FLS_HIP(hipStreamSynchronize(s));
+        }
         cell = cell_size;
         inv_cell = 1.0f / cell_size;
         const size_t n = cloud.size();

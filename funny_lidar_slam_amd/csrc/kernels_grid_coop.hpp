@@ -54,17 +54,19 @@ __device__ __forceinline__ unsigned group8_min_u32(unsigned v) {
     return v;
 }
 
+// (the body is a device function of the block index so that two queries -- the corner and the planar class of the LOAM
+// matcher -- can share one launch: grid_knn_dual_kernel below)
 template <int K, bool FLOAT_XFORM>
-__global__ void __launch_bounds__(256)
-grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
-                const GnState* __restrict__ st, const int first, const Pose16 T0, const CellGridDev cg, const float gate,
-                float4* __restrict__ nn_pts /* [n][K] */, unsigned char* __restrict__ nn_cnt, float* __restrict__ kth_d2,
-                unsigned char* __restrict__ flag_to_clear /* may be null */) {
+__device__ __forceinline__ void
+grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+              const GnState* __restrict__ st, const int first, const Pose16& T0, const CellGridDev& cg, const float gate,
+              float4* __restrict__ nn_pts /* [n][K] */, unsigned char* __restrict__ nn_cnt, float* __restrict__ kth_d2,
+              unsigned char* __restrict__ flag_to_clear /* may be null */) {
     constexpr int G = 8, QPB = 256 / G;  // 27 cells over 8 lanes: 4 rounds
     // XCD-aware order: interleaved chunks of 8 workgroups per XCD (kernels_ivox_coop.hpp; the grid is a multiple of 64).
     // One contiguous eighth per XCD left the XCD that owns the sparse upper rings with all the second-stage searches.
     const int nb = (n + QPB - 1) / QPB;
-    const int lb = (((blockIdx.x >> 3) >> 3) * 8 + (blockIdx.x & 7)) * 8 + ((blockIdx.x >> 3) & 7);
+    const int lb = (((bid >> 3) >> 3) * 8 + (bid & 7)) * 8 + ((bid >> 3) & 7);
     const int sub = threadIdx.x % G;
     const int q = lb * QPB + threadIdx.x / G;
     const bool active = lb < nb && q < n;
@@ -291,13 +293,196 @@ grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
     if (sub == 0 && active) { nn_cnt[q] = (unsigned char)found; kth_d2[q] = kth; }
 }
 
+template <int K, bool FLOAT_XFORM>
+__global__ void __launch_bounds__(256)
+grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                const GnState* __restrict__ st, const int first, const Pose16 T0, const CellGridDev cg, const float gate,
+                float4* __restrict__ nn_pts /* [n][K] */, unsigned char* __restrict__ nn_cnt, float* __restrict__ kth_d2,
+                unsigned char* __restrict__ flag_to_clear /* may be null */) {
+    grid_knn_body<K, FLOAT_XFORM>((int)blockIdx.x, sx, sy, sz, n, st, first, T0, cg, gate, nn_pts, nn_cnt, kth_d2, flag_to_clear);
+}
+
+// two independent queries in one launch: blocks [0, nb_a) serve A, the rest B (both block counts are multiples of 64, so the
+// XCD a block lands on is the one its own launch would have given it).  LoamFull: the corner class is 7,680 queries with
+// long candidate lists (~1 wave per SIMD, 27 us alone), the planar class 57,600 queries (33 us alone): together ~35 us.
+struct GridKnnArgs {
+    const float *sx, *sy, *sz;
+    int n;
+    CellGridDev cg;
+    float gate;
+    float4* nn_pts;
+    unsigned char* nn_cnt;
+    float* kth_d2;
+    unsigned char* flag_to_clear;
+};
+template <int K, bool FLOAT_XFORM>
+__global__ void __launch_bounds__(256)
+grid_knn_dual_kernel(const GnState* __restrict__ st, const int first, const Pose16 T0, const GridKnnArgs a, const GridKnnArgs b, const int nb_a) {
+    if ((int)blockIdx.x < nb_a)
+        grid_knn_body<K, FLOAT_XFORM>((int)blockIdx.x, a.sx, a.sy, a.sz, a.n, st, first, T0, a.cg, a.gate, a.nn_pts, a.nn_cnt, a.kth_d2, a.flag_to_clear);
+    else
+        grid_knn_body<K, FLOAT_XFORM>((int)blockIdx.x - nb_a, b.sx, b.sy, b.sz, b.n, st, first, T0, b.cg, b.gate, b.nn_pts, b.nn_cnt, b.kth_d2, b.flag_to_clear);
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid_knn27_kernel: the gated 5-NN of the LOAM feature maps as ONE stage, built like ivox_knn_kernel: 4 lanes per query, the
+// 27 gate-sized cells of the 3x3x3 block looked up together (7 per lane, all loads in flight), the block's candidates cut
+// into four equal ranges (per-group LDS table), private sorted top-5 of IEEE-double keys {float-bits(d2) : map index},
+// five rounds of DPP group-min.  No pruning, no second stage: every point within the gate lies in the block (cell >=
+// sqrt(gate), kernels_knn.hpp), so the result is exact whenever the reference accepts the point (5th neighbour inside the
+// gate); the nearest-first / pruned / two-stage kernel above spends its time in dependent memory round trips
+// (cell -> points -> bound -> cells -> points -> merge -> shell ...), this one trades them for candidate arithmetic.
+// Winners are gathered from the map cloud in its own order (by_id): the key's low word is the map index (tie rule).
+// ---------------------------------------------------------------------------------------------
+template <bool FLOAT_XFORM>
+__global__ void __launch_bounds__(256)
+grid_knn27_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                  const GnState* __restrict__ st, const int first, const Pose16 T0, const CellGridDev cg,
+                  float4* __restrict__ nn_pts /* [n][5] */, unsigned char* __restrict__ nn_cnt, float* __restrict__ kth_d2,
+                  unsigned char* __restrict__ flag_to_clear /* may be null */) {
+    constexpr int G = 4, QPB = 256 / G, R = 7, ROW = 36;
+    __shared__ __attribute__((aligned(16))) unsigned s_end[QPB][ROW];
+    __shared__ __attribute__((aligned(16))) unsigned s_off[QPB][ROW];
+    const int nb = (n + QPB - 1) / QPB;
+    const int lb = (((blockIdx.x >> 3) >> 3) * 8 + (blockIdx.x & 7)) * 8 + ((blockIdx.x >> 3) & 7);  // interleaved XCD chunks of 8 workgroups
+    const int sub = threadIdx.x % G, g = threadIdx.x / G;
+    const int q = lb * QPB + g;
+    const bool active = lb < nb && q < n;
+    const int done = first ? 0 : st->done;
+    double T[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T[k] = first ? T0.m[k] : st->T[k];
+    const int qq = active ? q : 0;
+    const float px = sx[qq], py = sy[qq], pz = sz[qq];
+    if (done) return;
+    if (first && flag_to_clear && active && sub == 0) flag_to_clear[q] = 0;
+    float qx, qy, qz;
+    if (FLOAT_XFORM) {
+        const RtFloat rt = load_rt_float(T);
+        xform_f(rt, px, py, pz, qx, qy, qz);
+    } else {
+        const double x = px, y = py, z = pz;
+        qx = (float)(((T[0] * x + T[4] * y) + T[8] * z) + T[12]);
+        qy = (float)(((T[1] * x + T[5] * y) + T[9] * z) + T[13]);
+        qz = (float)(((T[2] * x + T[6] * y) + T[10] * z) + T[14]);
+    }
+    const double fx = floor((double)qx * cg.inv_cell), fy = floor((double)qy * cg.inv_cell), fz = floor((double)qz * cg.inv_cell);
+    const bool in_range = active && fabs(fx) < (double)(kKeyLimit - 3) && fabs(fy) < (double)(kKeyLimit - 3) && fabs(fz) < (double)(kKeyLimit - 3);
+    const int cx = in_range ? (int)fx : 0, cy = in_range ? (int)fy : 0, cz = in_range ? (int)fz : 0;
+    // this lane's cells: raster codes sub, sub + 4, ... < 27
+    auto lookup = [&](const int r, unsigned& b, unsigned& c) {
+        const int k = sub + G * r;
+        const bool pv = in_range && k < 27;
+        const int kk = k < 27 ? k : 0;
+        const int dx = kk % 3 - 1, dy = (kk / 3) % 3 - 1, dz = kk / 9 - 1;
+        if (cg.win.cells) {  // uniform
+            const int wx = cx + dx - cg.win.ox, wy = cy + dy - cg.win.oy, wz = cz + dz - cg.win.oz;
+            const bool ok = pv && (unsigned)wx < (unsigned)cg.win.nx && (unsigned)wy < (unsigned)cg.win.ny && (unsigned)wz < (unsigned)cg.win.nz;
+            const uint2 e = cg.win.cells[ok ? (unsigned)((wz * cg.win.ny + wy) * cg.win.nx + wx) : 0u];
+            b = e.x;
+            c = ok ? e.y : 0u;
+        } else {
+            const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
+            unsigned h = hash_key(key) & cg.g.mask;
+            HashEntry ek = pv ? cg.g.table[h] : HashEntry{kEmptyKey, 0u, 0u};
+            while (pv && ek.key != key && ek.key != kEmptyKey) { h = (h + 1) & cg.g.mask; ek = cg.g.table[h]; }
+            const bool hit = pv && ek.key == key;
+            b = hit ? ek.begin : 0u;
+            c = hit ? ek.count : 0u;
+        }
+    };
+    unsigned b0, b1, b2, b3, b4, b5, b6, c0, c1, c2, c3, c4, c5, c6;
+    lookup(0, b0, c0); lookup(1, b1, c1); lookup(2, b2, c2); lookup(3, b3, c3); lookup(4, b4, c4); lookup(5, b5, c5); lookup(6, b6, c6);
+    static_assert(R == 7, "seven explicit rounds");
+    const double kNone = __hiloint2double((int)kKeyNoneHi, -1);
+    double t5[5] = {kNone, kNone, kNone, kNone, kNone};
+    int ncand = 0;
+    auto consider = [&](const float4 p, const bool ok) {
+        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;  // flann::L2_Simple<float>
+        const bool v = ok && !(d2 != d2);
+        ncand += v ? 1 : 0;
+        top5_insert_dkey(t5, make_dkey(d2, (unsigned)__float_as_int(p.w), v));
+    };
+    // balanced split of the block's candidates over the four lanes (ivox_knn_kernel, BAL)
+    const unsigned tot = ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + c6);
+    const unsigned nz = (c0 ? 1u : 0u) + (c1 ? 1u : 0u) + (c2 ? 1u : 0u) + (c3 ? 1u : 0u) + (c4 ? 1u : 0u) + (c5 ? 1u : 0u) + (c6 ? 1u : 0u);
+    const unsigned packed = tot * 32u + nz;  // candidates (< 2^27) and occupied cells (<= 27 per group)
+    const unsigned t0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)packed, 0x00, 0xf, 0xf, true);  // quad broadcasts
+    const unsigned t1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)packed, 0x55, 0xf, 0xf, true);
+    const unsigned t2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)packed, 0xAA, 0xf, 0xf, true);
+    const unsigned t3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)packed, 0xFF, 0xf, 0xf, true);
+    const unsigned before = (sub > 0 ? t0 : 0u) + (sub > 1 ? t1 : 0u) + (sub > 2 ? t2 : 0u), all = t0 + t1 + t2 + t3;
+    const unsigned TOT = all >> 5;
+    unsigned pos = before & 31u, run = before >> 5;
+#pragma unroll
+    for (int k = 0; k < ROW / G; ++k) s_end[g][(ROW / G) * sub + k] = ~0u;  // sentinels behind the last real entry
+    if (c0) { s_off[g][pos] = b0 - run; run += c0; s_end[g][pos] = run; ++pos; }
+    if (c1) { s_off[g][pos] = b1 - run; run += c1; s_end[g][pos] = run; ++pos; }
+    if (c2) { s_off[g][pos] = b2 - run; run += c2; s_end[g][pos] = run; ++pos; }
+    if (c3) { s_off[g][pos] = b3 - run; run += c3; s_end[g][pos] = run; ++pos; }
+    if (c4) { s_off[g][pos] = b4 - run; run += c4; s_end[g][pos] = run; ++pos; }
+    if (c5) { s_off[g][pos] = b5 - run; run += c5; s_end[g][pos] = run; ++pos; }
+    if (c6) { s_off[g][pos] = b6 - run; run += c6; s_end[g][pos] = run; ++pos; }
+    // a group lives inside one wave and the LDS serves a wave's operations in order: wave-level ordering only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        const unsigned Q = (TOT + 3u) >> 2, a = sub * Q, e = a + Q < TOT ? a + Q : TOT;
+        unsigned k = 0;  // first table entry whose range reaches past a
+#pragma unroll
+        for (int v = 0; v < 7; ++v) {
+            const uint4 e4 = *reinterpret_cast<const uint4*>(&s_end[g][4 * v]);
+            k += (e4.x <= a ? 1u : 0u) + (e4.y <= a ? 1u : 0u) + (e4.z <= a ? 1u : 0u) + (e4.w <= a ? 1u : 0u);
+        }
+        for (unsigned idx = a; idx < e; idx += 4) {
+            const unsigned E0 = s_end[g][k], E1 = s_end[g][k + 1], E2 = s_end[g][k + 2], E3 = s_end[g][k + 3];
+            const unsigned O0 = s_off[g][k], O1 = s_off[g][k + 1], O2 = s_off[g][k + 2], O3 = s_off[g][k + 3], O4 = s_off[g][k + 4];
+            const unsigned last = e - 1;
+            const unsigned i1 = idx + 1, i2 = idx + 2, i3 = idx + 3;
+            const unsigned s0 = slot_select<5>(idx, E0, E1, E2, E3, O0, O1, O2, O3, O4);
+            const unsigned s1 = slot_select<5>(i1 < last ? i1 : last, E0, E1, E2, E3, O0, O1, O2, O3, O4);
+            const unsigned s2 = slot_select<5>(i2 < last ? i2 : last, E0, E1, E2, E3, O0, O1, O2, O3, O4);
+            const unsigned s3 = slot_select<5>(i3 < last ? i3 : last, E0, E1, E2, E3, O0, O1, O2, O3, O4);
+            const float4 q0 = cg.g.pts[s0], q1 = cg.g.pts[s1], q2 = cg.g.pts[s2], q3 = cg.g.pts[s3];
+            consider(q0, true);
+            consider(q1, i1 <= last);
+            consider(q2, i2 <= last);
+            consider(q3, i3 <= last);
+            const unsigned nx = idx + 4;
+            k += (E0 <= nx ? 1u : 0u) + (E1 <= nx ? 1u : 0u) + (E2 <= nx ? 1u : 0u) + (E3 <= nx ? 1u : 0u);
+        }
+    }
+    // merge: five rounds of group-min + pop (keys are unique: the map index is the low word)
+    const int total = group_sum_i32<G>(ncand);
+    double last = kNone;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const double m = group_min_dkey<G>(t5[0]);
+        const bool mv = dkey_valid(m);
+        if (mv && __double_as_longlong(t5[0]) == __double_as_longlong(m)) {
+            t5[0] = t5[1]; t5[1] = t5[2]; t5[2] = t5[3]; t5[3] = t5[4]; t5[4] = kNone;
+        }
+        if (sub == 0 && active) nn_pts[(size_t)q * 5 + j] = mv ? cg.by_id[dkey_slot(m)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        last = m;
+    }
+    if (sub == 0 && active) {
+        nn_cnt[q] = (unsigned char)(total < 5 ? total : 5);
+        kth_d2[q] = (total >= 5 && dkey_valid(last)) ? __uint_as_float((unsigned)__double2hiint(last) - kKeyBias) : INFINITY;
+    }
+}
+
 // one partial row per 256-thread workgroup from the per-wave sums in LDS (fixed order)
-__device__ __forceinline__ void block_row_from_wave_sums(double (*wsum)[32], double* __restrict__ partials) {
+__device__ __forceinline__ void block_row_from_wave_sums(double (*wsum)[32], double* __restrict__ partials, const int bid) {
     __syncthreads();
     if (threadIdx.x < 29) {
         const double v = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
-        partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
+        partials[(size_t)bid * kPartialStride + threadIdx.x] = v;
     }
+}
+__device__ __forceinline__ void block_row_from_wave_sums(double (*wsum)[32], double* __restrict__ partials) {
+    block_row_from_wave_sums(wsum, partials, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -373,13 +558,13 @@ icp_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const
 // LINE = false: plane (Appendix C.1), LINE = true: corner feature (Appendix C.2)
 // ---------------------------------------------------------------------------------------------
 template <bool LINE>
-__global__ void __launch_bounds__(256)
-feature_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
-                   const GnState* __restrict__ st, const int first, const Pose16 T0, const float4* __restrict__ nn_pts /* [n][5] */,
-                   const unsigned char* __restrict__ nn_cnt, const float* __restrict__ kth_d2, const float gate, const double thres,
-                   int* __restrict__ nn_id /* [n][5] */, unsigned char* __restrict__ cnt_out, double* __restrict__ Jst /* [7][n] */,
-                   unsigned char* __restrict__ flag, double* __restrict__ partials) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void
+feature_fit_body(const int bid, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                 const GnState* __restrict__ st, const int first, const Pose16& T0, const float4* __restrict__ nn_pts /* [n][5] */,
+                 const unsigned char* __restrict__ nn_cnt, const float* __restrict__ kth_d2, const float gate, const double thres,
+                 int* __restrict__ nn_id /* [n][5] */, unsigned char* __restrict__ cnt_out, double* __restrict__ Jst /* [7][n] */,
+                 unsigned char* __restrict__ flag, double* __restrict__ partials) {
+    const int i = bid * 256 + threadIdx.x;
     const int done = first ? 0 : st->done;
     double T44[16];
 #pragma unroll
@@ -420,7 +605,42 @@ feature_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
         }
     }
     reduce_rank1_and_store(contrib, J, res, &wsum[threadIdx.x >> 6][0]);
-    block_row_from_wave_sums(wsum, partials);
+    block_row_from_wave_sums(wsum, partials, bid);
+}
+
+template <bool LINE>
+__global__ void __launch_bounds__(256)
+feature_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                   const GnState* __restrict__ st, const int first, const Pose16 T0, const float4* __restrict__ nn_pts /* [n][5] */,
+                   const unsigned char* __restrict__ nn_cnt, const float* __restrict__ kth_d2, const float gate, const double thres,
+                   int* __restrict__ nn_id /* [n][5] */, unsigned char* __restrict__ cnt_out, double* __restrict__ Jst /* [7][n] */,
+                   unsigned char* __restrict__ flag, double* __restrict__ partials) {
+    feature_fit_body<LINE>((int)blockIdx.x, sx, sy, sz, n, st, first, T0, nn_pts, nn_cnt, kth_d2, gate, thres, nn_id, cnt_out, Jst, flag, partials);
+}
+
+// corner (line) and planar fits of one LOAM iteration in one launch: blocks [0, nb_line) fit lines, the rest planes
+struct FeatureFitArgs {
+    const float *sx, *sy, *sz;
+    int n;
+    const float4* nn_pts;
+    const unsigned char* nn_cnt;
+    const float* kth_d2;
+    float gate;
+    double thres;
+    int* nn_id;
+    unsigned char* cnt_out;
+    double* Jst;
+    unsigned char* flag;
+    double* partials;
+};
+__global__ void __launch_bounds__(256)
+feature_fit_dual_kernel(const GnState* __restrict__ st, const int first, const Pose16 T0, const FeatureFitArgs line, const FeatureFitArgs plane, const int nb_line) {
+    if ((int)blockIdx.x < nb_line)
+        feature_fit_body<true>((int)blockIdx.x, line.sx, line.sy, line.sz, line.n, st, first, T0, line.nn_pts, line.nn_cnt, line.kth_d2, line.gate, line.thres,
+                               line.nn_id, line.cnt_out, line.Jst, line.flag, line.partials);
+    else
+        feature_fit_body<false>((int)blockIdx.x - nb_line, plane.sx, plane.sy, plane.sz, plane.n, st, first, T0, plane.nn_pts, plane.nn_cnt, plane.kth_d2,
+                                plane.gate, plane.thres, plane.nn_id, plane.cnt_out, plane.Jst, plane.flag, plane.partials);
 }
 
 }  // namespace fls

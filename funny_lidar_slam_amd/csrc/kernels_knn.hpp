@@ -30,6 +30,7 @@ struct CellGridDev {
     double cell;
     int rings;  // 1: the gate fits into one cell (27-cell block suffices); 2: half-size cells, 125-cell block in two stages
     DenseWindow win;  // cells == nullptr: no dense window (extent too large), hash table only
+    const float4* by_id;  // the map cloud in its own order {x, y, z, id bits} (grid_knn27_kernel gathers its winners here), may be null
 };
 
 template <int K>

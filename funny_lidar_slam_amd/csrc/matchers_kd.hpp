@@ -179,14 +179,26 @@ struct FeatureDev {
         FLS_HIP(hipStreamSynchronize(s));
         return int(n);
     }
+    GridKnnArgs knn_args(const CellGridDev& cg, float gate) {
+        return GridKnnArgs{scan.x.p, scan.y.p, scan.z.p, int(scan.n), cg, gate, nn_pts.p, nn_cnt.p, kth.p, flag.p};
+    }
+    FeatureFitArgs fit_args(float gate, double thres, double* partials) {
+        return FeatureFitArgs{scan.x.p, scan.y.p, scan.z.p, int(scan.n), nn_pts.p, nn_cnt.p, kth.p, gate, thres, nn_id.p, cnt_out.p, J.p, flag.p, partials};
+    }
     // grid_knn_kernel<5> (flags cleared by the first iteration: once per Match, Q1) + feature_fit_kernel<LINE>
     template <bool LINE>
     void launch(hipStream_t s, GnState* st, int first, const Pose16& T0, const CellGridDev& cg, float gate, double thres, double* partials) {
         const size_t n = scan.n;
         if (n == 0) return;
-        const dim3 knn_grid_dim(unsigned((((n * 8 + 255) / 256) + 63) / 64 * 64));  // multiple of 64: the XCD chunk re-map is a bijection
-        hipLaunchKernelGGL((grid_knn_kernel<5, false>), knn_grid_dim, dim3(256), 0, s, scan.x.p, scan.y.p, scan.z.p, int(n), st, first, T0, cg, gate,
-                           nn_pts.p, nn_cnt.p, kth.p, flag.p);
+        if (cg.rings == 1 && cg.by_id != nullptr) {  // gate-sized cells + the cloud by index: the one-stage 27-cell kernel
+            const dim3 g27(unsigned((((n * 4 + 255) / 256) + 63) / 64 * 64));
+            hipLaunchKernelGGL((grid_knn27_kernel<false>), g27, dim3(256), 0, s, scan.x.p, scan.y.p, scan.z.p, int(n), st, first, T0, cg, nn_pts.p, nn_cnt.p,
+                               kth.p, flag.p);
+        } else {
+            const dim3 knn_grid_dim(unsigned((((n * 8 + 255) / 256) + 63) / 64 * 64));  // multiple of 64: the XCD chunk re-map is a bijection
+            hipLaunchKernelGGL((grid_knn_kernel<5, false>), knn_grid_dim, dim3(256), 0, s, scan.x.p, scan.y.p, scan.z.p, int(n), st, first, T0, cg, gate,
+                               nn_pts.p, nn_cnt.p, kth.p, flag.p);
+        }
         hipLaunchKernelGGL((feature_fit_kernel<LINE>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, scan.x.p, scan.y.p, scan.z.p, int(n), st,
                            first, T0, (const float4*)nn_pts.p, (const unsigned char*)nn_cnt.p, (const float*)kth.p, gate, thres, nn_id.p,
                            cnt_out.p, J.p, flag.p, partials);
@@ -201,8 +213,12 @@ struct LoamFullMatcher final : fls_matcher {
     const LoamFullMatcher* owner = nullptr;  // batch lane: reads the owner's two map grids
     FeatureDev corner, planar;
     hm::KeyframeGate gate;
+    bool grid27 = false;     // FLS_GRID27=1: gate-sized cells + the one-stage 27-cell kernel (measured slower: A/B switch)
+    bool dual_launch = true;  // FLS_LOAM_DUAL=0: one correspondence + one fit launch per feature class
 
     fls_status init() {
+        if (const char* e = std::getenv("FLS_GRID27")) grid27 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_LOAM_DUAL")) dual_launch = std::atoi(e) != 0;
         if (unset_d(p.point_to_planar_thres) || unset_d(p.point_search_thres) || unset_d(p.line_ratio_thres) ||
             unset_d(p.position_converge_thres) || unset_d(p.rotation_converge_thres) || unset_d(p.rot_thre_add_cloud) ||
             unset_d(p.dist_thre_add_cloud))
@@ -223,10 +239,12 @@ struct LoamFullMatcher final : fls_matcher {
         for (const auto& c : corner_deque) local_corner.insert(local_corner.end(), c.begin(), c.end());
         if (planar_deque.size() > 5) local_planar = voxel_grid(local_planar, p.planar_voxel_filter_size);
         if (corner_deque.size() > 5) local_corner = voxel_grid(local_corner, p.corner_voxel_filter_size);
-        const float cs = 0.5f * cell_for_gate(p.point_search_thres);
-        fls_status rc = planar_grid.build(local_planar, cs, stream, kGridRings);
+        // FLS_GRID27=1: gate-sized cells + the one-stage 27-cell kernel; default: half-gate cells + the two-stage kernel
+        const bool g27 = grid27;
+        const float cs = (g27 ? 1.0f : 0.5f) * cell_for_gate(p.point_search_thres);
+        fls_status rc = planar_grid.build(local_planar, cs, stream, g27 ? 1 : kGridRings, g27);
         if (rc != FLS_OK) return rc;
-        rc = corner_grid.build(local_corner, cs, stream, kGridRings);
+        rc = corner_grid.build(local_corner, cs, stream, g27 ? 1 : kGridRings, g27);
         have_map = rc == FLS_OK;
         return rc;
     }
@@ -256,8 +274,17 @@ struct LoamFullMatcher final : fls_matcher {
         std::memcpy(T0.m, T, sizeof(T0.m));
         const unsigned word = run_mailbox_loop(int(p.max_iterations), np + nc, [&](int it, int first) {
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
-            corner.launch<true>(stream, d_state.p, first, T0, cgc, gate_f, p.line_ratio_thres, d_partials_a.p);
-            planar.launch<false>(stream, d_state.p, first, T0, cgp, gate_f, p.point_to_planar_thres, d_partials_b.p);
+            if (dual_launch && nc != 0 && np != 0 && !(cgc.rings == 1 && cgc.by_id != nullptr)) {
+                // both classes in one correspondence launch and one fit launch (they are independent until the solve)
+                const int kc = int((((nc * 8 + 255) / 256) + 63) / 64 * 64), kp = int((((np * 8 + 255) / 256) + 63) / 64 * 64);
+                hipLaunchKernelGGL((grid_knn_dual_kernel<5, false>), dim3(unsigned(kc + kp)), dim3(256), 0, stream, (const GnState*)d_state.p, first, T0,
+                                   corner.knn_args(cgc, gate_f), planar.knn_args(cgp, gate_f), kc);
+                hipLaunchKernelGGL(feature_fit_dual_kernel, dim3(unsigned(nbc + nbp)), dim3(256), 0, stream, (const GnState*)d_state.p, first, T0,
+                                   corner.fit_args(gate_f, p.line_ratio_thres, d_partials_a.p), planar.fit_args(gate_f, p.point_to_planar_thres, d_partials_b.p), nbc);
+            } else {
+                corner.launch<true>(stream, d_state.p, first, T0, cgc, gate_f, p.line_ratio_thres, d_partials_a.p);
+                planar.launch<false>(stream, d_state.p, first, T0, cgp, gate_f, p.point_to_planar_thres, d_partials_b.p);
+            }
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
             hipLaunchKernelGGL(gn_solve_loam_kernel, dim3(1), dim3(kSolveThreads), 0, stream, d_state.p, first, T0, (const double*)d_partials_a.p,
                                nbc, (const double*)d_partials_b.p, nbp, p.rotation_converge_thres, p.position_converge_thres, mb_dev, match_id);
