@@ -141,6 +141,9 @@ __device__ __forceinline__ unsigned slot_select(const unsigned idx, const unsign
 #ifndef FLS_NN_STORE
 #define FLS_NN_STORE 0
 #endif
+#ifndef FLS_KNN_PIPE
+#define FLS_KNN_PIPE 0
+#endif
 typedef float fls_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_nn_row(float4* p, const float4 v) {
 #if FLS_NN_STORE == 0
@@ -311,6 +314,39 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
             const uint4 e4 = *reinterpret_cast<const uint4*>(&s_end[g][4 * v]);
             k += (e4.x <= a ? 1u : 0u) + (e4.y <= a ? 1u : 0u) + (e4.z <= a ? 1u : 0u) + (e4.w <= a ? 1u : 0u);
         }
+#if FLS_KNN_PIPE
+        // software-pipelined variant (A/B switch): the four loads of trip t + 1 are issued before the candidates of trip t are
+        // consumed, so a lane has up to eight points in flight
+        {
+            const unsigned last = e - 1;
+            unsigned cs0 = 0, cs1 = 0, cs2 = 0, cs3 = 0;
+            float4 cq0 = make_float4(0.f, 0.f, 0.f, 0.f), cq1 = cq0, cq2 = cq0, cq3 = cq0;
+            auto fetch = [&](const unsigned idx, unsigned& s0, unsigned& s1, unsigned& s2, unsigned& s3, float4& q0, float4& q1, float4& q2, float4& q3) {
+                const unsigned E0 = s_end[g][k], E1 = s_end[g][k + 1], E2 = s_end[g][k + 2], E3 = s_end[g][k + 3];
+                const unsigned O0 = s_off[g][k], O1 = s_off[g][k + 1], O2 = s_off[g][k + 2], O3 = s_off[g][k + 3], O4 = s_off[g][k + 4];
+                const unsigned i1 = idx + 1, i2 = idx + 2, i3 = idx + 3;
+                s0 = slot_select<5>(idx, E0, E1, E2, E3, O0, O1, O2, O3, O4);
+                s1 = slot_select<5>(i1 < last ? i1 : last, E0, E1, E2, E3, O0, O1, O2, O3, O4);
+                s2 = slot_select<5>(i2 < last ? i2 : last, E0, E1, E2, E3, O0, O1, O2, O3, O4);
+                s3 = slot_select<5>(i3 < last ? i3 : last, E0, E1, E2, E3, O0, O1, O2, O3, O4);
+                q0 = grid.pts[s0]; q1 = grid.pts[s1]; q2 = grid.pts[s2]; q3 = grid.pts[s3];
+                const unsigned nx = idx + 4;
+                k += (E0 <= nx ? 1u : 0u) + (E1 <= nx ? 1u : 0u) + (E2 <= nx ? 1u : 0u) + (E3 <= nx ? 1u : 0u);
+            };
+            if (a < e) fetch(a, cs0, cs1, cs2, cs3, cq0, cq1, cq2, cq3);
+            for (unsigned idx = a; idx < e; idx += 4) {
+                unsigned ns0 = 0, ns1 = 0, ns2 = 0, ns3 = 0;
+                float4 nq0 = cq0, nq1 = cq0, nq2 = cq0, nq3 = cq0;
+                if (idx + 4 < e) fetch(idx + 4, ns0, ns1, ns2, ns3, nq0, nq1, nq2, nq3);
+                consider(cq0, cs0, true);
+                consider(cq1, cs1, idx + 1 <= last);
+                consider(cq2, cs2, idx + 2 <= last);
+                consider(cq3, cs3, idx + 3 <= last);
+                cs0 = ns0; cs1 = ns1; cs2 = ns2; cs3 = ns3;
+                cq0 = nq0; cq1 = nq1; cq2 = nq2; cq3 = nq3;
+            }
+        }
+#else
         for (unsigned idx = a; idx < e; idx += 4) {
             const unsigned E0 = s_end[g][k], E1 = s_end[g][k + 1], E2 = s_end[g][k + 2], E3 = s_end[g][k + 3];
             const unsigned O0 = s_off[g][k], O1 = s_off[g][k + 1], O2 = s_off[g][k + 2], O3 = s_off[g][k + 3], O4 = s_off[g][k + 4];
@@ -328,6 +364,7 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
             const unsigned nx = idx + 4;
             k += (E0 <= nx ? 1u : 0u) + (E1 <= nx ? 1u : 0u) + (E2 <= nx ? 1u : 0u) + (E3 <= nx ? 1u : 0u);
         }
+#endif
     } else
     for (unsigned j = 0; j < tot; j += 4) {
         const unsigned last = tot - 1;
