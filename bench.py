@@ -26,7 +26,7 @@ Extra objects on the line:
                 device-side AddPoints, and with the exact host path.
   inclusive_h2d fls_match from host buffers (de-interleave + PCIe copy inside the call).
   c5_batch      BASELINE configs[4]: 512 independent scan-to-map jobs (64 per GPU at 8 GPUs; distinct scans, one per job)
-                block-partitioned over the ranks, fls_match_batch on 4 stream lanes, host-to-device scan upload and the
+                block-partitioned over the ranks, fls_match_batch on 8 stream lanes, host-to-device scan upload and the
                 gather of the result table inside the timed region.
   cpu_baseline  the CPU oracle (a port of the reference algorithm, pinned against the reference's own compiled code:
                 tests/test_ref_pin.py) timed on this box's host cores on the headline workload, rank 0, N = 1 only.
@@ -42,9 +42,9 @@ import time
 
 import numpy as np
 
-# configs[4] batch: 4 stream lanes map 1:1 onto hardware queues only if the runtime may open that many
+# configs[4] batch: 8 stream lanes (+ the handle's own stream) map onto hardware queues only if the runtime may open that many
 # (ROCm's default is 4 per process, shared with torch's own streams); must be set before HIP initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -407,8 +407,9 @@ def main():
     # start / stop hipEvents are attached to every correspondence-kernel launch of every EVENT_EVERY-th step of the
     # timed region (hipExtLaunchKernelGGL: the kernel's own execution time); they are settled after the region.  A bracketed step
     # costs ~36 us more than a plain one (measured, tools/loop_overhead.py: 125 us / step without events, 134 with every 4th, 128 with
-    # every 16th), so the sampling is kept sparse: every 8th step = at least 3 steps / 9 launches at the driver's K = 20.
-    EVENT_EVERY = 8
+    # every 16th), so the sampling is kept sparse: every 16th step = 2 steps / 6 launches at K = 20, 4 steps / 12 launches at K = 50
+    # (launch durations repeat to +-1 us).
+    EVENT_EVERY = 16
     m.kernel_time()  # reset the accumulators
     if distributed:
         dist.barrier()
@@ -446,8 +447,9 @@ def main():
 
     c5 = None
     if not args.no_batch:
-        # configs[4]: job ids block-partitioned (batch.partition), every job its own scan, 4 stream lanes per GPU
-        lanes = 4
+        # configs[4]: job ids block-partitioned (batch.partition), every job its own scan, 8 stream lanes per GPU
+        # (tools/gpu_batch.py, 256 jobs: 1 lane 3.8k, 2: 7.0k, 4: 7.7k, 8: 10.2k, 16: 10.8k scans/s)
+        lanes = 8
         clusters = [reg.PointcloudCluster(planar_cloud_=s) for s in my_scans]
         T0s = [np.eye(4)] * len(clusters)
         warm = clusters[: min(len(clusters), 16)]
