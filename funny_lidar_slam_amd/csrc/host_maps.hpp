@@ -13,6 +13,7 @@
 #pragma once
 #include "device_common.hpp"
 #include "host_util.hpp"
+#include "host_parallel.hpp"
 #include <unordered_map>
 #include <algorithm>
 #include <climits>
@@ -465,7 +466,9 @@ struct GridImage {
 // ---------------------------------------------------------------------------------------------
 // pcl::VoxelGrid<PointXYZI>::filter (PCL 1.10 applyFilter; downsample_all_data_ = true)
 // ---------------------------------------------------------------------------------------------
-inline std::vector<PtI> voxel_grid(const std::vector<PtI>& in, float leaf) {
+struct VoxelLeafRec { unsigned idx, pt; bool operator<(const VoxelLeafRec& o) const { return idx < o.idx; } };
+
+inline std::vector<PtI> voxel_grid_sequential(const std::vector<PtI>& in, float leaf) {
     std::vector<PtI> out;
     if (in.empty()) return out;
     const float inv = 1.0f / leaf;
@@ -485,8 +488,7 @@ inline std::vector<PtI> voxel_grid(const std::vector<PtI>& in, float leaf) {
         div_b[a] = int(std::floor(mx[a] * inv)) - min_b[a] + 1;
     }
     const int m1 = div_b[0], m2 = div_b[0] * div_b[1];
-    struct Leaf { unsigned idx, pt; bool operator<(const Leaf& o) const { return idx < o.idx; } };
-    std::vector<Leaf> lv;
+    std::vector<VoxelLeafRec> lv;
     lv.reserve(in.size());
     for (size_t k = 0; k < in.size(); ++k) {
         const PtI& p = in[k];
@@ -494,7 +496,7 @@ inline std::vector<PtI> voxel_grid(const std::vector<PtI>& in, float leaf) {
         const int i0 = int(std::floor(p.x * inv) - float(min_b[0]));
         const int i1 = int(std::floor(p.y * inv) - float(min_b[1]));
         const int i2 = int(std::floor(p.z * inv) - float(min_b[2]));
-        lv.push_back(Leaf{unsigned(i0 + i1 * m1 + i2 * m2), unsigned(k)});
+        lv.push_back(VoxelLeafRec{unsigned(i0 + i1 * m1 + i2 * m2), unsigned(k)});
     }
     std::sort(lv.begin(), lv.end());
     for (size_t a = 0; a < lv.size();) {
@@ -507,6 +509,105 @@ inline std::vector<PtI> voxel_grid(const std::vector<PtI>& in, float leaf) {
         a = b;
     }
     return out;
+}
+
+// The same filter on the host worker pool (host_parallel.hpp): bounds, leaf indices and centroids are data-parallel chunks,
+// the sort is the EXACT parallel restatement of std::sort (same permutation of equal leaf indices => the same float sums, bit
+// for bit).  Falls back to the sequential code when the pool is busy / single-threaded or introsort would have heap-sorted.
+inline bool voxel_grid_parallel(const std::vector<PtI>& in, float leaf, std::vector<PtI>& out) {
+    HostPool& pool = HostPool::get();
+    const size_t n = in.size();
+    const float inv = 1.0f / leaf;
+    const size_t C = size_t(pool.threads()) * 4;  // chunks per phase
+    struct Chunk { float mn[3], mx[3]; size_t finite, offset; std::vector<PtI> part; };
+    std::vector<Chunk> ch(C);
+    std::vector<VoxelLeafRec> lv;
+    ExactSortShared<VoxelLeafRec> sh;
+    int verdict = 0;  // 1: input copied ("leaf size too small"), 2: sort needs the sequential path, 3: no finite point
+    const bool ran = pool.run([&](HostPool::Region& reg) {
+        auto finite = [](const PtI& p) { return std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z); };
+        reg.phase(C, [&](const size_t c) {
+            Chunk& me = ch[c];
+            for (int k = 0; k < 3; ++k) { me.mn[k] = INFINITY; me.mx[k] = -INFINITY; }
+            me.finite = 0;
+            for (size_t k = n * c / C, e = n * (c + 1) / C; k < e; ++k) {
+                const PtI& p = in[k];
+                if (!finite(p)) continue;
+                ++me.finite;
+                me.mn[0] = std::min(me.mn[0], p.x); me.mx[0] = std::max(me.mx[0], p.x);
+                me.mn[1] = std::min(me.mn[1], p.y); me.mx[1] = std::max(me.mx[1], p.y);
+                me.mn[2] = std::min(me.mn[2], p.z); me.mx[2] = std::max(me.mx[2], p.z);
+            }
+        });
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        size_t total = 0;
+        for (Chunk& c : ch) {
+            for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], c.mn[k]); mx[k] = std::max(mx[k], c.mx[k]); }
+            c.offset = total;
+            total += c.finite;
+        }
+        if (total == 0) { verdict = 3; return; }
+        const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1,
+                        dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+        if (dx * dy * dz > (long long)std::numeric_limits<int>::max()) { verdict = 1; return; }
+        int min_b[3], div_b[3];
+        for (int k = 0; k < 3; ++k) {
+            min_b[k] = int(std::floor(mn[k] * inv));
+            div_b[k] = int(std::floor(mx[k] * inv)) - min_b[k] + 1;
+        }
+        const int m1 = div_b[0], m2 = div_b[0] * div_b[1];
+        lv.resize(total);
+        reg.phase(C, [&](const size_t c) {
+            size_t w = ch[c].offset;
+            for (size_t k = n * c / C, e = n * (c + 1) / C; k < e; ++k) {
+                const PtI& p = in[k];
+                if (!finite(p)) continue;
+                const int i0 = int(std::floor(p.x * inv) - float(min_b[0]));
+                const int i1 = int(std::floor(p.y * inv) - float(min_b[1]));
+                const int i2 = int(std::floor(p.z * inv) - float(min_b[2]));
+                lv[w++] = VoxelLeafRec{unsigned(i0 + i1 * m1 + i2 * m2), unsigned(k)};
+            }
+        });
+        sh.reset(lv.data(), lv.data() + total);
+        reg.phase(size_t(pool.threads()), [&](size_t) { exact_sort_worker(sh); });
+        if (sh.failed.load()) { verdict = 2; return; }
+        // centroids: chunk c owns the leaves that START in its slice of the sorted records
+        reg.phase(C, [&](const size_t c) {
+            size_t s0 = total * c / C, s1 = total * (c + 1) / C;
+            while (s0 > 0 && s0 < total && lv[s0].idx == lv[s0 - 1].idx) ++s0;
+            while (s1 > 0 && s1 < total && lv[s1].idx == lv[s1 - 1].idx) ++s1;
+            std::vector<PtI>& part = ch[c].part;
+            part.clear();
+            for (size_t x = s0; x < s1;) {
+                size_t y = x + 1;
+                while (y < total && lv[y].idx == lv[x].idx) ++y;
+                float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+                for (size_t k = x; k < y; ++k) { const PtI& p = in[lv[k].pt]; sx += p.x; sy += p.y; sz += p.z; si += p.i; }
+                const float cnt = float(y - x);
+                part.push_back(PtI{sx / cnt, sy / cnt, sz / cnt, si / cnt});
+                x = y;
+            }
+        });
+    });
+    if (!ran || verdict == 2) return false;   // the sequential path works on the untouched input
+    if (verdict == 1) { out = in; return true; }  // PCL: "leaf size too small", input copied
+    out.clear();
+    if (verdict == 3) return true;
+    size_t tot = 0;
+    for (const Chunk& c : ch) tot += c.part.size();
+    out.reserve(tot);
+    for (const Chunk& c : ch) out.insert(out.end(), c.part.begin(), c.part.end());
+    return true;
+}
+
+inline std::vector<PtI> voxel_grid(const std::vector<PtI>& in, float leaf) {
+    // the pool pays from ~50k points on (waking the workers costs 0.1-0.2 ms; 27k points: 0.8 ms alone, 1.05 ms pooled;
+    // 115k points: 2.6 ms alone, 0.75 ms on 8 threads)
+    if (in.size() >= 49152) {
+        std::vector<PtI> out;
+        if (voxel_grid_parallel(in, leaf, out)) return out;
+    }
+    return voxel_grid_sequential(in, leaf);
 }
 
 // ---------------------------------------------------------------------------------------------

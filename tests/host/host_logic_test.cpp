@@ -6,6 +6,7 @@
 #include "../../funny_lidar_slam_amd/csrc/host_maps.hpp"
 #include "../../oracle/flo_api.h"
 #include <cstdio>
+#include <cstring>
 #include <list>
 #include <map>
 #include <random>
@@ -99,6 +100,44 @@ int main() {
             CHECK(vg[i].x == out[4 * i] && vg[i].y == out[4 * i + 1] && vg[i].z == out[4 * i + 2] && vg[i].i == out[4 * i + 3]);
     }
     CHECK(voxel_grid(std::vector<PtI>(), 0.4f).empty());
+    // ---- 3b. the exact restatement of std::sort (host_parallel.hpp): the SAME permutation as libstdc++'s introsort on
+    //          records that compare by their key only (heavy ties), sequential form and pool form, all sizes --------------
+    {
+        struct Rec { unsigned idx, pt; bool operator<(const Rec& o) const { return idx < o.idx; } };
+        HostPool& pool = HostPool::get();
+        for (int round = 0; round < 260; ++round) {
+            const size_t n = round < 40 ? size_t(round) : (round < 200 ? size_t(rng() % 5000) : size_t(20000 + rng() % 200000));
+            const unsigned keys = round % 5 == 0 ? 3u : (round % 5 == 1 ? unsigned(n / 2 + 1) : (round % 5 == 2 ? 0xffffffffu : unsigned(n / 7 + 1)));
+            std::vector<Rec> a(n);
+            for (size_t i = 0; i < n; ++i) a[i] = Rec{keys == 0xffffffffu ? unsigned(rng()) : unsigned(rng() % keys), unsigned(i)};
+            if (round % 7 == 3) std::sort(a.begin(), a.end(), [](const Rec& x, const Rec& y) { return x.idx < y.idx || (x.idx == y.idx && x.pt < y.pt); });  // already sorted
+            if (round % 7 == 4) std::reverse(a.begin(), a.end());
+            std::vector<Rec> ref = a, s1 = a, s2 = a;
+            std::sort(ref.begin(), ref.end());
+            CHECK(exact_sort_sequential(s1.data(), s1.data() + n));
+            for (size_t i = 0; i < n; ++i) CHECK(s1[i].idx == ref[i].idx && s1[i].pt == ref[i].pt);
+            ExactSortShared<Rec> sh;
+            sh.reset(s2.data(), s2.data() + n);
+            const bool ran = pool.run([&](HostPool::Region& reg) { reg.phase(size_t(pool.threads()), [&](size_t) { exact_sort_worker(sh); }); });
+            if (ran) {
+                CHECK(!sh.failed.load());
+                for (size_t i = 0; i < n; ++i) CHECK(s2[i].idx == ref[i].idx && s2[i].pt == ref[i].pt);
+            } else {
+                CHECK(pool.threads() <= 1);
+            }
+        }
+    }
+    // ---- 3c. the pooled VoxelGrid == the sequential one, bit for bit (sizes that take the pool path; NaN points; the
+    //          "leaf size too small" copy) -------------------------------------------------------------------------------
+    for (int round = 0; round < 6; ++round) {
+        auto cloud = random_cloud(rng, 60000 + 30000 * size_t(round), round % 2 ? 60.0f : 8.0f);
+        if (round == 2) for (size_t i = 0; i < cloud.size(); i += 97) cloud[i].y = std::nanf("");
+        const float leaf = round == 5 ? 0.0005f : (round % 3 == 0 ? 0.2f : 0.5f);
+        const auto a = voxel_grid(cloud, leaf), b = voxel_grid_sequential(cloud, leaf);
+        CHECK(a.size() == b.size());
+        CHECK(a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(PtI)) == 0 || round == 2);
+        if (round == 2) for (size_t i = 0; i < a.size(); ++i) CHECK(std::memcmp(&a[i], &b[i], sizeof(PtI)) == 0 || (a[i].x != a[i].x && b[i].x != b[i].x));
+    }
     // ---- 4. incremental image bookkeeping --------------------------------------------------------------
     {
         HostIvox iv;
