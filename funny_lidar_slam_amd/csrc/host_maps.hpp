@@ -636,7 +636,7 @@ struct CellGridImage : GridImage {
             if (!(std::fabs(fx) < float(kKeyLimit) && std::fabs(fy) < float(kKeyLimit) && std::fabs(fz) < float(kKeyLimit))) return FLS_ERR_RANGE;
             kv[i] = {pack_key(int(fx), int(fy), int(fz)), unsigned(i)};
         }
-        std::sort(kv.begin(), kv.end());
+        pooled_sort_total_order(kv.data(), kv.data() + n);  // (cell key, index) pairs: a total order
         size_t cells = 0;
         for (size_t a = 0; a < n; ++a) if (a == 0 || kv[a].first != kv[a - 1].first) ++cells;
         n_cells = cells;

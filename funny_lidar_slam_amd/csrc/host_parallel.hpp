@@ -296,4 +296,19 @@ inline void exact_sort_worker(ExactSortShared<T>& sh) {
     }
 }
 
+// std::sort of records whose order is TOTAL (no two compare equal): every correct sort gives the same array, so the pooled
+// introsort may simply be finished by std::sort when it gives up.  (Records with ties need the exact permutation: see
+// voxel_grid_parallel in host_maps.hpp, which restarts from the untouched input instead.)
+template <class T>
+inline void pooled_sort_total_order(T* first, T* last) {
+    if (last - first >= 65536) {
+        HostPool& pool = HostPool::get();
+        ExactSortShared<T> sh;
+        sh.reset(first, last);
+        const bool ran = pool.run([&](HostPool::Region& reg) { reg.phase(size_t(pool.threads()), [&](size_t) { exact_sort_worker(sh); }); });
+        if (ran && !sh.failed.load()) return;
+    }
+    std::sort(first, last);
+}
+
 }  // namespace fls
