@@ -165,7 +165,7 @@ struct SourceFilter {
                 return;
             }
         }
-        source = voxel_grid(cloud_from(s0, n0, stride), leaf);
+        source = voxel_grid_strided(s0, n0, stride, leaf);
         scan.upload(source, s);
         ++host_runs;
     }

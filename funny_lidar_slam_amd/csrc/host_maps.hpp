@@ -514,7 +514,19 @@ inline std::vector<PtI> voxel_grid_sequential(const std::vector<PtI>& in, float 
 // The same filter on the host worker pool (host_parallel.hpp): bounds, leaf indices and centroids are data-parallel chunks,
 // the sort is the EXACT parallel restatement of std::sort (same permutation of equal leaf indices => the same float sums, bit
 // for bit).  Falls back to the sequential code when the pool is busy / single-threaded or introsort would have heap-sorted.
-inline bool voxel_grid_parallel(const std::vector<PtI>& in, float leaf, std::vector<PtI>& out) {
+// a caller's strided AoS cloud read in place (no intermediate copy): the same values cloud_from() would produce
+struct StridedCloud {
+    const float* p;
+    size_t n;
+    int stride;
+    size_t size() const { return n; }
+    PtI operator[](size_t k) const { const float* q = p + k * size_t(stride); return PtI{q[0], q[1], q[2], intensity_of(q, stride)}; }
+};
+inline void copy_cloud(const std::vector<PtI>& in, std::vector<PtI>& out) { out = in; }
+inline void copy_cloud(const StridedCloud& in, std::vector<PtI>& out) { out = cloud_from(in.p, in.n, in.stride); }
+
+template <class Cloud>
+inline bool voxel_grid_parallel(const Cloud& in, float leaf, std::vector<PtI>& out) {
     HostPool& pool = HostPool::get();
     const size_t n = in.size();
     const float inv = 1.0f / leaf;
@@ -531,7 +543,7 @@ inline bool voxel_grid_parallel(const std::vector<PtI>& in, float leaf, std::vec
             for (int k = 0; k < 3; ++k) { me.mn[k] = INFINITY; me.mx[k] = -INFINITY; }
             me.finite = 0;
             for (size_t k = n * c / C, e = n * (c + 1) / C; k < e; ++k) {
-                const PtI& p = in[k];
+                const PtI p = in[k];
                 if (!finite(p)) continue;
                 ++me.finite;
                 me.mn[0] = std::min(me.mn[0], p.x); me.mx[0] = std::max(me.mx[0], p.x);
@@ -560,7 +572,7 @@ inline bool voxel_grid_parallel(const std::vector<PtI>& in, float leaf, std::vec
         reg.phase(C, [&](const size_t c) {
             size_t w = ch[c].offset;
             for (size_t k = n * c / C, e = n * (c + 1) / C; k < e; ++k) {
-                const PtI& p = in[k];
+                const PtI p = in[k];
                 if (!finite(p)) continue;
                 const int i0 = int(std::floor(p.x * inv) - float(min_b[0]));
                 const int i1 = int(std::floor(p.y * inv) - float(min_b[1]));
@@ -582,7 +594,7 @@ inline bool voxel_grid_parallel(const std::vector<PtI>& in, float leaf, std::vec
                 size_t y = x + 1;
                 while (y < total && lv[y].idx == lv[x].idx) ++y;
                 float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-                for (size_t k = x; k < y; ++k) { const PtI& p = in[lv[k].pt]; sx += p.x; sy += p.y; sz += p.z; si += p.i; }
+                for (size_t k = x; k < y; ++k) { const PtI p = in[lv[k].pt]; sx += p.x; sy += p.y; sz += p.z; si += p.i; }
                 const float cnt = float(y - x);
                 part.push_back(PtI{sx / cnt, sy / cnt, sz / cnt, si / cnt});
                 x = y;
@@ -590,7 +602,7 @@ inline bool voxel_grid_parallel(const std::vector<PtI>& in, float leaf, std::vec
         });
     });
     if (!ran || verdict == 2) return false;   // the sequential path works on the untouched input
-    if (verdict == 1) { out = in; return true; }  // PCL: "leaf size too small", input copied
+    if (verdict == 1) { copy_cloud(in, out); return true; }  // PCL: "leaf size too small", input copied
     out.clear();
     if (verdict == 3) return true;
     size_t tot = 0;
@@ -608,6 +620,14 @@ inline std::vector<PtI> voxel_grid(const std::vector<PtI>& in, float leaf) {
         if (voxel_grid_parallel(in, leaf, out)) return out;
     }
     return voxel_grid_sequential(in, leaf);
+}
+// the filter of a caller's strided cloud (Match's source filter): large clouds are read in place by the pooled filter
+inline std::vector<PtI> voxel_grid_strided(const float* p, size_t n, int stride, float leaf) {
+    if (n >= 49152) {
+        std::vector<PtI> out;
+        if (voxel_grid_parallel(StridedCloud{p, n, stride}, leaf, out)) return out;
+    }
+    return voxel_grid_sequential(cloud_from(p, n, stride), leaf);
 }
 
 // ---------------------------------------------------------------------------------------------

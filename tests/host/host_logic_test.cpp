@@ -137,6 +137,17 @@ int main() {
         CHECK(a.size() == b.size());
         CHECK(a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(PtI)) == 0 || round == 2);
         if (round == 2) for (size_t i = 0; i < a.size(); ++i) CHECK(std::memcmp(&a[i], &b[i], sizeof(PtI)) == 0 || (a[i].x != a[i].x && b[i].x != b[i].x));
+        // the caller's strided cloud read in place (packed xyzi rows and 32-byte PCL points) == the copied cloud
+        for (int stride : {4, 8}) {
+            std::vector<float> raw(cloud.size() * size_t(stride), 0.f);
+            for (size_t i = 0; i < cloud.size(); ++i) {
+                float* q = &raw[i * size_t(stride)];
+                q[0] = cloud[i].x; q[1] = cloud[i].y; q[2] = cloud[i].z; q[stride >= 8 ? 4 : 3] = cloud[i].i;
+            }
+            const auto c = voxel_grid_strided(raw.data(), cloud.size(), stride, leaf);
+            CHECK(c.size() == b.size());
+            if (round != 2) CHECK(c.empty() || std::memcmp(c.data(), b.data(), c.size() * sizeof(PtI)) == 0);
+        }
     }
     // ---- 4. incremental image bookkeeping --------------------------------------------------------------
     {
