@@ -11,6 +11,7 @@
 #include <map>
 #include <random>
 #include <set>
+#include <thread>
 
 using namespace fls;
 
@@ -147,6 +148,22 @@ int main() {
             const auto c = voxel_grid_strided(raw.data(), cloud.size(), stride, leaf);
             CHECK(c.size() == b.size());
             if (round != 2) CHECK(c.empty() || std::memcmp(c.data(), b.data(), c.size() * sizeof(PtI)) == 0);
+        }
+    }
+    // ---- 3d. several threads filtering at once (batch lanes): one of them gets the pool, the others run the sequential code;
+    //          every result is the sequential one -----------------------------------------------------------------------
+    {
+        std::vector<std::vector<PtI>> clouds, want(6), got(6);
+        for (int t = 0; t < 6; ++t) clouds.push_back(random_cloud(rng, 70000 + 9000 * size_t(t), 12.0f));
+        for (int t = 0; t < 6; ++t) want[size_t(t)] = voxel_grid_sequential(clouds[size_t(t)], 0.3f);
+        for (int rep = 0; rep < 4; ++rep) {
+            std::vector<std::thread> th;
+            for (int t = 0; t < 6; ++t) th.emplace_back([&, t] { got[size_t(t)] = voxel_grid(clouds[size_t(t)], 0.3f); });
+            for (auto& x : th) x.join();
+            for (int t = 0; t < 6; ++t) {
+                CHECK(got[size_t(t)].size() == want[size_t(t)].size());
+                CHECK(std::memcmp(got[size_t(t)].data(), want[size_t(t)].data(), want[size_t(t)].size() * sizeof(PtI)) == 0);
+            }
         }
     }
     // ---- 4. incremental image bookkeeping --------------------------------------------------------------
