@@ -271,6 +271,38 @@ def bench_mapping_mode(reg, synth, cfg, n_scans=6):
                       "map_points_after": m.map_size()}
         m.close()
     os.environ.pop("FLS_IVOX_DEVICE_UPDATE", None)
+    # the production pipeline hands Match a 0.5 m voxel-filtered planar cloud (preprocessing.cpp:236-237), not the raw scan:
+    # the insert rule then keeps the map sparse.  Same six poses, scans filtered with the product's device VoxelGrid
+    # (fls_debug_voxel_grid), fls_match from HOST buffers with update_map = 1 -- the adapter's real call.
+    try:
+        import ctypes as C
+        from funny_lidar_slam_amd import _lib
+
+        def filt(c, leaf=0.5):
+            a = np.ascontiguousarray(np.concatenate([c[:, :3], np.zeros((c.shape[0], 1), np.float32)], axis=1), np.float32)
+            out = np.zeros_like(a)
+            n_out = C.c_size_t(0)
+            fp = C.POINTER(C.c_float)
+            rc = _lib.lib().fls_debug_voxel_grid(0, a.ctypes.data_as(fp), a.shape[0], 4, np.float32(leaf), out.ctypes.data_as(fp), out.shape[0], C.byref(n_out))
+            if rc != 0:
+                raise RuntimeError(f"fls_debug_voxel_grid: {rc}")
+            return np.ascontiguousarray(out[: n_out.value, :3])
+
+        fscans = [filt(sc) for sc in scans]
+        m = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+        m.AddCloudToLocalMap([filt(cfg["map"])])
+        guess = np.eye(4)
+        tb, its = [], []
+        for sc in fscans:
+            T = guess.copy(); t = time.perf_counter(); m.Match(reg.PointcloudCluster(planar_cloud_=sc), T, update_map=True); tb.append(time.perf_counter() - t)
+            its.append(int(m.stats.iterations))
+            guess = T
+        res["filtered_planar_cloud_0p5m"] = {"scan_points": int(np.median([s.shape[0] for s in fscans])), "map_points_after": m.map_size(),
+                                             "ms_per_scan_match_plus_update_from_host_buffers": 1e3 * float(np.median(tb[1:])),
+                                             "gn_iterations": its, "device_batches": m.map_size(103), "refused_batches": m.map_size(104)}
+        m.close()
+    except Exception as e:
+        res["filtered_planar_cloud_0p5m"] = {"error": repr(e)[:200]}
     try:
         res["incremental_ndt"] = bench_ndt_mapping_mode(reg, synth)
     except Exception as e:  # never at the expense of the rest of the line
