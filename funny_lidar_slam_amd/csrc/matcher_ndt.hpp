@@ -87,6 +87,7 @@ struct NdtMatcher final : fls_matcher {
         if (const char* e = std::getenv("FLS_HOST_TIMING")) host_timing = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_NDT_DEVICE_UPDATE")) allow_device_update = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_NDT_DEVICE_MARGIN")) { const long c = std::atol(e); if (c >= 0) device_margin = size_t(c); }
+        if (const char* e = std::getenv("FLS_NDT_DEVICE_SLACK")) { const long c = std::atol(e); if (c >= 0) device_slack = size_t(c); }
         inv_voxel = 1.0 / p.ndt_voxel_size;
         return FLS_OK;
     }
@@ -254,6 +255,7 @@ struct NdtMatcher final : fls_matcher {
     // sync_host_from_device().  Entered after a host-path update in mapping mode, left for good by the first refused batch.
     bool allow_device_update = true;  // FLS_NDT_DEVICE_UPDATE
     size_t device_margin = 4096;      // FLS_NDT_DEVICE_MARGIN: voxels below the LRU capacity at which device mode is not entered
+    size_t device_slack = 65536;      // FLS_NDT_DEVICE_SLACK: spare table entries / rows allocated ahead (test hook: small values force growth)
     bool device_mode = false, device_left = false;
     DevBuf<unsigned long long> r_key, r_stamp;
     DevBuf<unsigned> r_hslot;
@@ -284,7 +286,8 @@ struct NdtMatcher final : fls_matcher {
     // uploads the whole host mirror as rows (LRU order: row 0 = least recently touched) + a table holding every alive voxel
     void enter_device_mode(size_t batch_hint) {
         const size_t na = n_alive;
-        const unsigned ts = GridImage::table_size_for(na + na / 2 + 2 * batch_hint + 65536);
+        const size_t ahead = device_slack ? na / 2 + 2 * batch_hint + device_slack : 1;  // slack 0 (test hook): nothing ahead, every batch grows
+        const unsigned ts = GridImage::table_size_for(na + ahead);
         mask = ts - 1;
         h_table.assign(ts, HashEntry{kEmptyKey, kNdtNewBit, 0u});
         std::vector<unsigned long long> k(na), st(na);
@@ -308,7 +311,7 @@ struct NdtMatcher final : fls_matcher {
             v.slot = -1;
             v.dirty = false;
         }
-        reserve_rows(na + na / 2 + 2 * batch_hint + 65536, false);
+        reserve_rows(na + ahead, false);
         d_table.reserve(ts);
         auto up = [&](void* d, const void* h, size_t bytes) { if (bytes) FLS_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream)); };
         up(d_table.p, h_table.data(), ts * sizeof(HashEntry));
@@ -328,8 +331,10 @@ struct NdtMatcher final : fls_matcher {
         ++full_rebuilds;
     }
     // the table of a device-mode image is rebuilt on the device when the next batch might fill it past one half
+    unsigned long long table_growths = 0, row_growths = 0;
     void grow_table_device(size_t need_entries) {
-        const unsigned ts = GridImage::table_size_for(need_entries + need_entries / 2 + 65536);
+        ++table_growths;
+        const unsigned ts = GridImage::table_size_for(device_slack ? need_entries + need_entries / 2 + device_slack : need_entries);
         DevBuf<HashEntry> nt;
         nt.reserve(ts);
         hipLaunchKernelGGL(ndt_table_fill_kernel, dim3((ts + 255) / 256), dim3(256), 0, stream, nt.p, ts);
@@ -355,7 +360,7 @@ struct NdtMatcher final : fls_matcher {
         if (n == 0) return true;
         if (n > size_t(kVgMaxBlocks) * kVgTile) return false;
         if ((dev_alive + n) * 2 + 2 > dev_table) grow_table_device(dev_alive + n);
-        if (dev_rows + n > row_cap) reserve_rows(dev_rows + dev_rows / 2 + 2 * n, true);
+        if (dev_rows + n > row_cap) { reserve_rows(device_slack ? dev_rows + dev_rows / 2 + 2 * n : dev_rows + n, true); ++row_growths; }
         NdtUpdState& hs = h_upd.p[0];
         hs = NdtUpdState{};
         hs.n_rows = unsigned(dev_rows); hs.n_alive = unsigned(dev_alive); hs.next_vid = dev_next_vid; hs.epoch = dev_epoch;
@@ -653,6 +658,8 @@ struct NdtMatcher final : fls_matcher {
         if (slot == 109) return size_t(device_batches);  // map updates applied on the device / refused (replayed on the host)
         if (slot == 110) return size_t(refused_batches);
         if (slot == 111) return size_t(resident_updates);  // map updates fed by the device-resident filtered scan
+        if (slot == 112) return size_t(table_growths);     // device-side table rebuilds / row-array growths
+        if (slot == 113) return size_t(row_growths);
         return alive();
     }
 };

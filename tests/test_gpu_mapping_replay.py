@@ -48,6 +48,7 @@ def run_replay(name, monkeypatch=None):
     if mode == "IncrementalNDT":
         r["image_syncs"] = (m.map_size(107), m.map_size(108))  # full rebuilds, incremental updates of the device image
         r["device_updates"] = (m.map_size(109), m.map_size(110))  # map updates applied on the device / refused
+        r["device_growths"] = (m.map_size(112), m.map_size(113))  # device-side table rebuilds / row-array growths
     m.close()
     return r, hist
 
@@ -81,6 +82,16 @@ def test_ndt_mapping_replay_device_update():
     applied, refused = r["device_updates"]
     assert all(x["upd"] == 1 for x in h)
     assert applied >= len(h) - 1 and refused == 0, (applied, refused)
+
+
+def test_ndt_mapping_replay_device_update_growing_arrays(monkeypatch):
+    """No spare room allocated ahead: the device-mode table is re-hashed on the device and the row arrays are re-allocated (with
+    their contents) while the map grows -- same results."""
+    monkeypatch.setenv("FLS_NDT_DEVICE_SLACK", "0")
+    r, h = run_replay("ndt_dev")
+    applied, refused = r["device_updates"]
+    assert applied >= len(h) - 1 and refused == 0
+    assert r["device_growths"][0] >= 1 or r["device_growths"][1] >= 1, r["device_growths"]
 
 
 def test_ndt_mapping_replay_device_refusal(monkeypatch):
