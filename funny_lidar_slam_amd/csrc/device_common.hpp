@@ -79,21 +79,28 @@ struct Mailbox {
 // back the whole XCD L2 first -- megabytes of freshly written Jacobian rows -- on the critical path): every
 // payload word goes out as a write-through relaxed system-scope store, the wave drains its stores, then `seq`
 // follows.  The host's acquire load of `seq` (matcher_base.hpp wait_mailbox) completes the hand-off.
+// launch_word = max_iterations << 24 | match_id (23 bits).  The payload (pose, statistics) crosses PCIe only when the host will
+// read it -- the iteration that stops the Match or the last one the host can launch; every other iteration publishes the
+// sequence word alone (the host only counts iterations then) and does not wait for its stores.
 __device__ __forceinline__ void mailbox_publish(Mailbox* __restrict__ mb, const double (&T)[16], const double (&dx)[6], const double sum_res,
                                                 const double sum_res2, const int iter, const int done, const int converged,
-                                                const int n_valid, const int n_valid2, const unsigned seq) {
+                                                const int n_valid, const int n_valid2, const unsigned launch_word) {
 #define FLS_MB_F64(dst, v) __hip_atomic_store((unsigned long long*)&(dst), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #define FLS_MB_I32(dst, v) __hip_atomic_store(&(dst), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-    for (int q = 0; q < 16; ++q) FLS_MB_F64(mb->T[q], T[q]);
-    for (int q = 0; q < 6; ++q) FLS_MB_F64(mb->last_dx[q], dx[q]);
-    FLS_MB_F64(mb->sum_res, sum_res);
-    FLS_MB_F64(mb->sum_res2, sum_res2);
-    FLS_MB_I32(mb->iter, iter);
-    FLS_MB_I32(mb->done, done);
-    FLS_MB_I32(mb->converged, converged);
-    FLS_MB_I32(mb->n_valid, n_valid);
-    FLS_MB_I32(mb->n_valid2, n_valid2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int max_it = (int)(launch_word >> 24);
+    const unsigned seq = ((launch_word & 0x7fffffu) << 9) | ((unsigned)done << 8) | (unsigned)iter;
+    if (done || max_it == 0 || iter >= max_it) {
+        for (int q = 0; q < 16; ++q) FLS_MB_F64(mb->T[q], T[q]);
+        for (int q = 0; q < 6; ++q) FLS_MB_F64(mb->last_dx[q], dx[q]);
+        FLS_MB_F64(mb->sum_res, sum_res);
+        FLS_MB_F64(mb->sum_res2, sum_res2);
+        FLS_MB_I32(mb->iter, iter);
+        FLS_MB_I32(mb->done, done);
+        FLS_MB_I32(mb->converged, converged);
+        FLS_MB_I32(mb->n_valid, n_valid);
+        FLS_MB_I32(mb->n_valid2, n_valid2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     FLS_MB_I32(mb->seq, seq);
 #undef FLS_MB_F64
 #undef FLS_MB_I32

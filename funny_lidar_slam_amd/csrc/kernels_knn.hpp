@@ -426,7 +426,7 @@ gn_solve_lu_kernel(GnState* __restrict__ st, const int first, const Pose16 T0, c
         }
         st->iter = it + 1;
         if (mb) {
-            mailbox_publish(mb, Tl, dxo, sres, 0.0, it + 1, stop, conv, effective, 0, (match_id << 9) | ((unsigned)stop << 8) | (unsigned)(it + 1));
+            mailbox_publish(mb, Tl, dxo, sres, 0.0, it + 1, stop, conv, effective, 0, match_id);  // launch word: max_iterations << 24 | match id
         }
     }
 }

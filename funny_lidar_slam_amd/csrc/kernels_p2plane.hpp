@@ -211,7 +211,7 @@ __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem
         const int stop = ((rn < rot_thr && pn < pos_thr) || (drot < 1.0e-4 && dpos < 1.0e-4)) ? 1 : 0;
         st->done = stop;
         if (mb) {
-            mailbox_publish(mb, Tl, dx, srb, sra, it + 1, stop, 0, nvb, nva, (match_id << 9) | ((unsigned)stop << 8) | (unsigned)(it + 1));
+            mailbox_publish(mb, Tl, dx, srb, sra, it + 1, stop, 0, nvb, nva, match_id);  // launch word: max_iterations << 24 | match id
         }
         FLS_STAMP(5);
     }

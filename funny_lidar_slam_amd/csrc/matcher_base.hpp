@@ -42,6 +42,8 @@ struct fls_matcher {
     fls::Mailbox* mb_host = nullptr;
     fls::Mailbox* mb_dev = nullptr;
     unsigned match_id = 0;
+    // what the tail kernels get: max_iterations << 24 | match id (mailbox_publish, device_common.hpp)
+    unsigned launch_word() const { return (match_id & 0x7fffffu) | (std::min<unsigned>(p.max_iterations, 255u) << 24); }
 
     virtual ~fls_matcher() {
         for (auto e : ev_pool) if (e) (void)hipEventDestroy(e);

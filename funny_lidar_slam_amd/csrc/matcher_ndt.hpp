@@ -587,7 +587,7 @@ struct NdtMatcher final : fls_matcher {
             }
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
             hipLaunchKernelGGL(gn_solve_lu_kernel, dim3(1), dim3(kSolveThreads), 0, stream, d_state.p, first, T0, (const double*)d_partials_b.p, nblk, 1,
-                               p.rotation_converge_thres, p.position_converge_thres, p.ndt_min_effective_pts, mb_dev, match_id);
+                               p.rotation_converge_thres, p.position_converge_thres, p.ndt_min_effective_pts, mb_dev, launch_word());
         });
         const Mailbox& s = *mb_host;
         stats.iterations = int(word & 0xffu);

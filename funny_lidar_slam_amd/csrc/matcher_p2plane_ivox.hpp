@@ -430,7 +430,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
 #define FLS_FIT(F)                                                                                                                   \
     hipExtLaunchKernelGGL(p2plane_fit_solve_kernel<F>, dim3(nwg), dim3(kFitThreads), 0, stream, f0, f1, 0, scan.x.p, scan.y.p, scan.z.p, int(n),  \
                        d_state.p, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,     \
-                       d_ticket.p, mb_dev, match_id, p.point_to_planar_thres, p.rotation_converge_thres, p.position_converge_thres)
+                       d_ticket.p, mb_dev, launch_word(), p.point_to_planar_thres, p.rotation_converge_thres, p.position_converge_thres)
             if (first) FLS_FIT(true); else FLS_FIT(false);
 #undef FLS_FIT
         });

@@ -102,7 +102,7 @@ struct IcpMatcher final : fls_matcher {
                                (const float4*)d_nn_pts.p, (const unsigned char*)d_nn_cnt.p, (const float*)d_kth.p, p.point_search_thres,
                                d_nn_id.p, d_eff.p, d_partials_b.p);
             hipLaunchKernelGGL(gn_solve_lu_kernel, dim3(1), dim3(kSolveThreads), 0, stream, d_state.p, first, T0, (const double*)d_partials_b.p,
-                               nwg, 0, p.rotation_converge_thres, p.position_converge_thres, 0, mb_dev, match_id);
+                               nwg, 0, p.rotation_converge_thres, p.position_converge_thres, 0, mb_dev, launch_word());
         });
         const Mailbox& mb = *mb_host;
         std::memcpy(T, mb.T, sizeof(double) * 16);
@@ -287,7 +287,7 @@ struct LoamFullMatcher final : fls_matcher {
             }
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
             hipLaunchKernelGGL(gn_solve_loam_kernel, dim3(1), dim3(kSolveThreads), 0, stream, d_state.p, first, T0, (const double*)d_partials_a.p,
-                               nbc, (const double*)d_partials_b.p, nbp, p.rotation_converge_thres, p.position_converge_thres, mb_dev, match_id);
+                               nbc, (const double*)d_partials_b.p, nbp, p.rotation_converge_thres, p.position_converge_thres, mb_dev, launch_word());
         });
         const Mailbox& mb = *mb_host;
         std::memcpy(T, mb.T, sizeof(double) * 16);
@@ -383,7 +383,7 @@ struct P2PlaneKdMatcher final : fls_matcher {
             planar.launch<false>(stream, d_state.p, first, T0, cg, INFINITY, p.point_to_planar_thres, d_partials_b.p);  // un-gated (:219)
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
             hipLaunchKernelGGL(gn_solve_loam_kernel, dim3(1), dim3(kSolveThreads), 0, stream, d_state.p, first, T0, (const double*)nullptr, 0,
-                               (const double*)d_partials_b.p, nblk, p.rotation_converge_thres, p.position_converge_thres, mb_dev, match_id);
+                               (const double*)d_partials_b.p, nblk, p.rotation_converge_thres, p.position_converge_thres, mb_dev, launch_word());
         });
         const Mailbox& mb = *mb_host;
         std::memcpy(T, mb.T, sizeof(double) * 16);
