@@ -312,6 +312,15 @@ def bench_mapping_mode(reg, synth, cfg, n_scans=6):
     return res
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim (it travels with the repository); the ASCII spelling if the file is missing"""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "scans/sec (64-ring x 1800 pts -> 1e6-pt iVox map), SE(3) err vs CPU ref"
+
+
 def bench_ndt_mapping_mode(reg, synth, n_scans=6):
     """configs[2] as the ROS adapter issues it: fls_match from HOST buffers with update_map = 1 (source VoxelGrid + Match + the
     reference's in-Match AddCloud), three settings: everything the round-1 way on the host, the device map update behind the
@@ -541,7 +550,7 @@ def main():
         except (OSError, KeyError, ValueError):
             traffic = None
         line = {
-            "metric": "scans/sec (64-ring x 1800 pts -> 1e6-pt iVox map), SE(3) err vs CPU ref",
+            "metric": baseline_metric(),
             "value": value, "unit": "scans/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
