@@ -314,6 +314,25 @@ def test_match_batch_other_kinds(mode, y, cid, scale, loc):
     m.close()
 
 
+def test_match_batch_ndt_full_size_lanes_share_the_host_pool():
+    """Full-size NDT jobs (115,200-point scans: the exact source VoxelGrid takes the host worker pool) on three lanes at once: one lane
+    gets the pool, the others filter sequentially -- every job equals a fresh handle's Match bit for bit."""
+    cfgs = [synth.make_config(2, job=j) for j in range(3)]
+    m = reg.make_matcher("IncrementalNDT", reg.YAML_NCLT_NDT)
+    m.AddCloudToLocalMap([cfgs[0]["map"]])
+    clusters = [util.cluster_for("IncrementalNDT", c["scan"]) for c in cfgs]
+    oks, Ts, stats = m.MatchBatch(clusters, [np.eye(4)] * 3, lanes=3)
+    for j in range(3):
+        f = reg.make_matcher("IncrementalNDT", reg.YAML_NCLT_NDT)
+        f.AddCloudToLocalMap([cfgs[0]["map"]])
+        T = np.eye(4)
+        ok = f.Match(clusters[j], T, update_map=False)
+        assert ok == oks[j] and np.array_equal(T, Ts[j]), j
+        assert f.stats.iterations == stats[j].iterations and f.stats.n_valid == stats[j].n_valid and f.stats.n_source == stats[j].n_source
+        f.close()
+    m.close()
+
+
 @pytest.mark.parametrize("job", list(range(1, 9)))
 def test_config2_many_scans_reduced(job):
     """Eight more scans (different ground-truth poses and noise draws) at a 4 % slice of configs[1]: the bit-exact
