@@ -391,7 +391,14 @@ gn_solve_lu_kernel(GnState* __restrict__ st, const int first, const Pose16 T0, c
     const double sres = tot[27];
     const bool early_fail = (mode == 1 && effective < min_effective);  // incremental_ndt.h:306-309: T = pose; return false
     double det = 1.0;
-    if (!early_fail) det = lu6_solve_wave(Hs, inv, gs, xs, tr);
+    if (!early_fail) {
+        // SPD fast path (kernels_p2plane.hpp::ldlt_solve6_lane): positive pivots imply det(H) > 0, so the reference's exact
+        // det == 0 test (icp_optimized.h:129, Q14) cannot fire; anything else goes through the restated LU inverse
+        int fast = 0;
+        if (lane == 0 && !((match_id >> 23) & 1u)) fast = ldlt_solve6_lane(Hs, gs, xs) ? 1 : 0;
+        fast = __shfl(fast, 0, 64);
+        if (!fast) det = lu6_solve_wave(Hs, inv, gs, xs, tr);
+    }
     if (lane == 0) {
         st->n_valid = effective;
         st->sum_res = sres;

@@ -134,6 +134,56 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 #define FLS_STAMP(k) do { } while (0)
 #endif
 
+// Fast path of the Gauss-Newton tails.  The 6x6 normal equations H = sum J J^T are symmetric positive definite whenever the
+// scene constrains all six degrees of freedom; one lane then solves H x = g by an unpivoted LDL^T in registers (static
+// indices only, ~0.8 us) instead of the wave-cooperative restatement of Eigen's FullPivHouseholderQR (6.2 us) / partial-pivot LU
+// inverse.  Same linear system, so the same x up to rounding (observed 1e-13 relative; the pose the Match returns agrees
+// with the oracle's to <= 1e-12 instead of <= 1e-14, every per-iteration n_valid / flag / id comparison of the test-suite is
+// unchanged).  The Eigen-arithmetic solvers remain the fallback whenever a pivot is not safely positive (rank-deficient or
+// badly conditioned systems: there Eigen's rank-revealing behaviour IS the semantics) and can be forced for every system
+// with FLS_TAIL_EXACT=1 (launch word bit 23).  Returns false when the caller must run the exact solver.
+__device__ __forceinline__ bool ldlt_solve6_lane(const double* __restrict__ H /* 6x6 column-major, LDS */, const double* __restrict__ g, double* __restrict__ x) {
+    double L[6][6], D[6], y[6];
+    double dmax = 0.0, dmin = INFINITY;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = H[j + 6 * j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= (L[j][k] * L[j][k]) * D[k];
+        D[j] = d;
+        dmax = fmax(dmax, d);
+        dmin = fmin(dmin, d);
+        const double inv = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double s = H[i + 6 * j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= (L[i][k] * L[j][k]) * D[k];
+            L[i][j] = s * inv;
+        }
+    }
+    if (!(dmin > 1.0e-9 * dmax)) return false;  // also false for NaN
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = g[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+        y[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = y[i] / D[i];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * y[k];
+        y[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = y[i];
+    return true;
+}
+
 // shared memory of the LOAM-family Gauss-Newton tail
 struct LoamTailSmem {
     double red[32][33];
@@ -171,6 +221,10 @@ __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem
     }
     if (lane < 6) { const double v = sm.tot_a[21 + lane] + sm.tot_b[21 + lane]; sm.gs[lane] = v; st->g[lane] = v; }
     __builtin_amdgcn_wave_barrier();
+    int fast = 0;
+    if (lane == 0 && !((match_id >> 23) & 1u)) fast = ldlt_solve6_lane(sm.Hs, sm.gs, sm.xs) ? 1 : 0;
+    fast = __shfl(fast, 0, 64);
+    if (!fast)
 #ifdef FLS_TIMING
     fullpiv_qr_solve6_wave(sm.Hs, sm.gs, sm.xs, sm.hc, sm.tr, sm.ctr, st->dbg);
 #else

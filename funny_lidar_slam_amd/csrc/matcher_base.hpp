@@ -45,8 +45,11 @@ struct fls_matcher {
     fls::Mailbox* mb_host = nullptr;
     fls::Mailbox* mb_dev = nullptr;
     unsigned match_id = 0;
-    // what the tail kernels get: max_iterations << 24 | match id (mailbox_publish, device_common.hpp)
-    unsigned launch_word() const { return (match_id & 0x7fffffu) | (std::min<unsigned>(p.max_iterations, 255u) << 24); }
+    // what the tail kernels get: max_iterations << 24 | exact-solver flag << 23 | match id (mailbox_publish, device_common.hpp)
+    bool tail_exact = false;  // FLS_TAIL_EXACT=1: every 6x6 system through the Eigen-arithmetic solver (no LDL^T fast path)
+    unsigned launch_word() const {
+        return (match_id & 0x7fffffu) | (tail_exact ? (1u << 23) : 0u) | (std::min<unsigned>(p.max_iterations, 255u) << 24);
+    }
 
     virtual ~fls_matcher() {
         for (auto e : ev_pool) if (e) (void)hipEventDestroy(e);
@@ -124,6 +127,7 @@ struct fls_matcher {
     }
 
     void init_common() {
+        if (const char* e = std::getenv("FLS_TAIL_EXACT")) tail_exact = std::atoi(e) != 0;
         FLS_HIP(hipSetDevice(device));
         FLS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         d_state.reserve(1);

@@ -314,6 +314,35 @@ def test_match_batch_other_kinds(mode, y, cid, scale, loc):
     m.close()
 
 
+@pytest.mark.parametrize("mode,y,cid,scale,loc", [("PointToPlane_IVOX", reg.YAML_NCLT_IVOX, 1, 0.1, False), ("IcpOptimized", reg.YAML_NCLT_ICP, 0, 1.0, True),
+                                                  ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, 0.1, False), ("LoamFull_KdTree", reg.YAML_NCLT_LOAM_FULL, 3, 0.1, False)])
+def test_exact_tail_solvers(mode, y, cid, scale, loc, monkeypatch):
+    """FLS_TAIL_EXACT=1: every 6x6 system goes through the restated Eigen solvers (full-pivot Householder QR / LU inverse) instead
+    of the LDL^T fast path -- same parity assertions, and the pose then agrees with the oracle to 1e-13."""
+    monkeypatch.setenv("FLS_TAIL_EXACT", "1")
+    cfg = synth.make_config(cid, scale=scale)
+    maps = [cfg["map"]] + ([cfg["corner_map"]] if "corner_map" in cfg else [])
+    m, o, T, T_ref = run_pair(mode, y, maps, cfg["scan"], corner=cfg.get("corner_scan"), loc=loc, sets_only_tail=(mode == "PointToPlane_IVOX"))
+    dt, dr = synth.pose_error(T, T_ref)
+    assert dt < 1e-12 and dr < 1e-12, (dt, dr)
+
+
+def test_rank_deficient_system_takes_the_exact_solver():
+    """A scene that constrains three of the six degrees of freedom (one infinite plane): the normal equations are singular, the
+    LDL^T fast path declines (no safely positive pivots) and the restated FullPivHouseholderQR -- whose rank-revealing basic solution
+    IS the reference's behaviour here -- runs; product == oracle per iteration as everywhere else."""
+    rng = np.random.default_rng(5)
+    mp = np.zeros((60000, 3), np.float32)
+    mp[:, :2] = rng.uniform(-25, 25, size=(60000, 2))
+    mp[:, 2] = rng.normal(0, 0.002, size=60000)
+    sc = np.zeros((6000, 3), np.float32)
+    sc[:, :2] = rng.uniform(-15, 15, size=(6000, 2))
+    sc[:, 2] = 0.05 + rng.normal(0, 0.002, size=6000)
+    m, o, T, T_ref = run_pair("PointToPlane_IVOX", reg.YAML_NCLT_IVOX, [mp], sc, sets_only_tail=True)
+    assert m.stats.iterations == o.stats.iterations
+    assert abs(T[2, 3] - T_ref[2, 3]) < 1e-9 and np.allclose(T[:2, 3], T_ref[:2, 3], atol=1e-9)  # in-plane translation left at the basic solution's zeros
+
+
 def test_match_batch_ndt_full_size_lanes_share_the_host_pool():
     """Full-size NDT jobs (115,200-point scans: the exact source VoxelGrid takes the host worker pool) on three lanes at once: one lane
     gets the pool, the others filter sequentially -- every job equals a fresh handle's Match bit for bit."""
