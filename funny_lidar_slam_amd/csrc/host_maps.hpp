@@ -615,7 +615,9 @@ inline bool voxel_grid_parallel(const Cloud& in, float leaf, std::vector<PtI>& o
 inline std::vector<PtI> voxel_grid(const std::vector<PtI>& in, float leaf) {
     // the pool pays from ~50k points on (waking the workers costs 0.1-0.2 ms; 27k points: 0.8 ms alone, 1.05 ms pooled;
     // 115k points: 2.6 ms alone, 0.75 ms on 8 threads)
-    if (in.size() >= 49152) {
+    // ... and from 16k points on while the workers are still spinning after a region that ended less than a millisecond ago
+    // (the second VoxelGrid of an NDT Match follows the first within that window)
+    if (in.size() >= 49152 || (in.size() >= 16384 && HostPool::get().hot())) {
         std::vector<PtI> out;
         if (voxel_grid_parallel(in, leaf, out)) return out;
     }

@@ -105,8 +105,12 @@ public:
             region_ = nullptr;  // a worker that wakes from now on finds no region
         }
         while (inside_.load(std::memory_order_acquire) != 0) spin_pause();
+        last_end_ns_.store(now_ns(), std::memory_order_relaxed);
         return true;
     }
+    // the workers are still spinning after a recent region (no wake-up cost): smaller jobs pay off then
+    bool hot() const { return n_ > 1 && now_ns() - last_end_ns_.load(std::memory_order_relaxed) < 1000000ll; }
+    static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     static void spin_pause() {
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -162,6 +166,7 @@ private:
     bool stop_ = false;
     std::atomic<int> inside_{0};
     std::atomic<unsigned> gen_hint_{0};
+    std::atomic<long long> last_end_ns_{0};
 };
 
 // ---- std::sort (libstdc++ introsort), restated so that its partitions can run as independent tasks ----
