@@ -101,6 +101,54 @@ __host__ __device__ inline void svd3(const double* A, double* U, double* S, doub
     }
 }
 
+// Unpivoted LDL^T solve of a symmetric positive definite 6x6 system H x = g (column-major H), static indices only: the fast path
+// of the Gauss-Newton tails (kernels_p2plane.hpp).  false when a pivot is not safely positive (d_min <= 1e-9 d_max, or NaN):
+// the caller then runs the restated Eigen solver, whose rank-revealing behaviour is the reference's semantics for such systems.
+__host__ __device__ inline bool ldlt_solve6(const double* H, const double* g, double* x) {
+    double L[6][6], D[6], y[6];
+    double dmax = 0.0, dmin = 1.0e300;
+    bool positive = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = H[j + 6 * j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= (L[j][k] * L[j][k]) * D[k];
+        D[j] = d;
+        positive = positive && (d > 0.0);  // false for NaN as well
+        dmax = d > dmax ? d : dmax;
+        dmin = d < dmin ? d : dmin;
+        const double inv = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double s = H[i + 6 * j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= (L[i][k] * L[j][k]) * D[k];
+            L[i][j] = s * inv;
+        }
+    }
+    if (!positive || !(dmin > 1.0e-9 * dmax)) return false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = g[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+        y[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = y[i] / D[i];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * y[k];
+        y[i] = s;
+    }
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { x[i] = y[i]; finite = finite && (y[i] - y[i] == 0.0); }
+    return finite;  // a non-finite right-hand side goes through the exact solver as well
+}
+
 // ---- IncrementalNDT voxel statistics (incremental_ndt.h:91-179), shared by the host path (matcher_ndt.hpp) and the device
 // map update (kernels_ndt_update.hpp): the same code, the same IEEE operation sequence on both sides ----
 template <class GetPt>

@@ -19,6 +19,7 @@
 // the rank-1 normal-equation terms (DPP row shifts: no LDS, no atomics -> bit-reproducible) and the
 // Gauss-Newton tail.  No MFMA: there is no dense contraction in this path (21+6+2 scalars per point).
 #pragma once
+#include "host_math.hpp"
 #include "device_common.hpp"
 #include "linalg_dev.hpp"
 #include "wave_solve.hpp"
@@ -143,45 +144,7 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 // badly conditioned systems: there Eigen's rank-revealing behaviour IS the semantics) and can be forced for every system
 // with FLS_TAIL_EXACT=1 (launch word bit 23).  Returns false when the caller must run the exact solver.
 __device__ __forceinline__ bool ldlt_solve6_lane(const double* __restrict__ H /* 6x6 column-major, LDS */, const double* __restrict__ g, double* __restrict__ x) {
-    double L[6][6], D[6], y[6];
-    double dmax = 0.0, dmin = INFINITY;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        double d = H[j + 6 * j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d -= (L[j][k] * L[j][k]) * D[k];
-        D[j] = d;
-        dmax = fmax(dmax, d);
-        dmin = fmin(dmin, d);
-        const double inv = 1.0 / d;
-#pragma unroll
-        for (int i = j + 1; i < 6; ++i) {
-            double s = H[i + 6 * j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) s -= (L[i][k] * L[j][k]) * D[k];
-            L[i][j] = s * inv;
-        }
-    }
-    if (!(dmin > 1.0e-9 * dmax)) return false;  // also false for NaN
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double s = g[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
-        y[i] = s;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) y[i] = y[i] / D[i];
-#pragma unroll
-    for (int i = 5; i >= 0; --i) {
-        double s = y[i];
-#pragma unroll
-        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * y[k];
-        y[i] = s;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) x[i] = y[i];
-    return true;
+    return hm::ldlt_solve6(H, g, x);  // host_math.hpp (__host__ __device__: tests/host/host_logic_test.cpp checks it on the CPU)
 }
 
 // shared memory of the LOAM-family Gauss-Newton tail

@@ -4,6 +4,7 @@
 //   * GridImage::collect_incremental invariants (disjoint slot regions, unique cell records, eviction records)
 // No HIP runtime call is made: only host members are touched.
 #include "../../funny_lidar_slam_amd/csrc/host_maps.hpp"
+#include "../../funny_lidar_slam_amd/csrc/host_math.hpp"
 #include "../../oracle/flo_api.h"
 #include <cstdio>
 #include <cstring>
@@ -165,6 +166,41 @@ int main() {
                 CHECK(std::memcmp(got[size_t(t)].data(), want[size_t(t)].data(), want[size_t(t)].size() * sizeof(PtI)) == 0);
             }
         }
+    }
+    // ---- 3e. the Gauss-Newton fast path (host_math.hpp::ldlt_solve6, the same code the device tail runs): agrees with the oracle's
+    //          restatement of Eigen's FullPivHouseholderQR on well-conditioned normal equations, declines singular / indefinite / NaN ones
+    {
+        std::normal_distribution<double> nd(0.0, 1.0);
+        int solved = 0;
+        for (int round = 0; round < 400; ++round) {
+            const int rows = 6 + int(rng() % 300);
+            double H[36] = {0}, g[6] = {0};
+            for (int r = 0; r < rows; ++r) {
+                double J[6];
+                for (int a = 0; a < 6; ++a) J[a] = nd(rng) * (a < 3 ? 30.0 : 1.0);  // rotation columns ~ range, translation columns ~ 1
+                if (round % 10 == 9) J[5] = 0.0;                                       // an unobserved direction: singular
+                const double res = nd(rng) * 0.05;
+                for (int a = 0; a < 6; ++a) { g[a] += -J[a] * res; for (int b = 0; b < 6; ++b) H[a + 6 * b] += J[a] * J[b]; }
+            }
+            double x[6], xr[6];
+            const bool ok = hm::ldlt_solve6(H, g, x);
+            if (round % 10 == 9) { CHECK(!ok); continue; }
+            CHECK(ok);
+            flo_fullpiv_qr_solve_6(H, g, xr);
+            double num = 0.0, den = 0.0;
+            for (int a = 0; a < 6; ++a) { num += (x[a] - xr[a]) * (x[a] - xr[a]); den += xr[a] * xr[a]; }
+            CHECK(std::sqrt(num) <= 1e-10 * std::sqrt(den) + 1e-18);
+            ++solved;
+        }
+        CHECK(solved == 360);
+        double Hn[36] = {0}, gn[6] = {1, 1, 1, 1, 1, 1}, xn[6];
+        for (int a = 0; a < 6; ++a) Hn[a + 6 * a] = 1.0;
+        Hn[0] = std::nan("");
+        CHECK(!hm::ldlt_solve6(Hn, gn, xn));
+        Hn[0] = -1.0;
+        CHECK(!hm::ldlt_solve6(Hn, gn, xn));
+        Hn[0] = 1.0; gn[2] = std::nan("");
+        CHECK(!hm::ldlt_solve6(Hn, gn, xn));
     }
     // ---- 4. incremental image bookkeeping --------------------------------------------------------------
     {
