@@ -56,12 +56,20 @@ __device__ __forceinline__ unsigned group8_min_u32(unsigned v) {
 
 // (the body is a device function of the block index so that two queries -- the corner and the planar class of the LOAM
 // matcher -- can share one launch: grid_knn_dual_kernel below)
-template <int K, bool FLOAT_XFORM>
+// (EMIT = false: nothing is written; lane j of a group returns the j-th neighbour's key / slot, every lane the neighbour
+// count, the K-th distance and its query index (-1: none) -- the fused ICP kernel below consumes them in registers)
+struct GridKnnLane {
+    unsigned long long key;
+    unsigned slot;
+    int found, q;
+    float kth;
+};
+template <int K, bool FLOAT_XFORM, bool EMIT = true>
 __device__ __forceinline__ void
 grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
               const GnState* __restrict__ st, const int first, const Pose16& T0, const CellGridDev& cg, const float gate,
               float4* __restrict__ nn_pts /* [n][K] */, unsigned char* __restrict__ nn_cnt, float* __restrict__ kth_d2,
-              unsigned char* __restrict__ flag_to_clear /* may be null */) {
+              unsigned char* __restrict__ flag_to_clear /* may be null */, GridKnnLane* __restrict__ lane_out = nullptr) {
     constexpr int G = 8, QPB = 256 / G;  // 27 cells over 8 lanes: 4 rounds
     // XCD-aware order: interleaved chunks of 8 workgroups per XCD (kernels_ivox_coop.hpp; the grid is a multiple of 64).
     // One contiguous eighth per XCD left the XCD that owns the sparse upper rings with all the second-stage searches.
@@ -288,6 +296,10 @@ grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restri
         }
         return;
     }
+    if (!EMIT) {
+        lane_out->key = mine_key; lane_out->slot = mine_slot; lane_out->found = found; lane_out->kth = kth; lane_out->q = active ? q : -1;
+        return;
+    }
     if (sub < K && active)
         nn_pts[(size_t)q * K + sub] = (mine_key != ~0ull) ? cg.g.pts[mine_slot] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
     if (sub == 0 && active) { nn_cnt[q] = (unsigned char)found; kth_d2[q] = kth; }
@@ -488,6 +500,80 @@ __device__ __forceinline__ void block_row_from_wave_sums(double (*wsum)[32], dou
 // ---------------------------------------------------------------------------------------------
 // IcpOptimized: e = pt - q, J = [I | -R hat(p)], H = J^T J, B = -J^T e   (icp_optimized.h:87-108)
 // ---------------------------------------------------------------------------------------------
+// per-point contribution (upper triangle of J^T J, -J^T e, |e|) of one accepted correspondence
+__device__ __forceinline__ void icp_point_terms(const double (&T)[16], const float px, const float py, const float pz, const float4 m, double (&Hc)[21],
+                                                double (&Bc)[6], double& res) {
+    const RtFloat rt = load_rt_float(T);
+    float qx, qy, qz;
+    xform_f(rt, px, py, pz, qx, qy, qz);
+    const double e0 = (double)qx - (double)m.x, e1 = (double)qy - (double)m.y, e2 = (double)qz - (double)m.z;
+    const double o0 = px, o1 = py, o2 = pz;
+    const double hat[9] = {0.0, o2, -o1, -o2, 0.0, o0, o1, -o0, 0.0};
+    double J[18];  // 3x6 column-major: [I | M],  M = -(R * SO3Hat(o)), zero terms kept in place
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            J[r + j * 3] = (r == j) ? 1.0 : 0.0;
+            J[r + (j + 3) * 3] = -((T[r] * hat[0 + j * 3] + T[r + 4] * hat[1 + j * 3]) + T[r + 8] * hat[2 + j * 3]);
+        }
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) {
+            Hc[k] = (J[0 + a * 3] * J[0 + b * 3] + J[1 + a * 3] * J[1 + b * 3]) + J[2 + a * 3] * J[2 + b * 3];
+            ++k;
+        }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) Bc[a] = ((-J[0 + a * 3]) * e0 + (-J[1 + a * 3]) * e1) + (-J[2 + a * 3]) * e2;
+    res = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+}
+
+// IcpOptimized correspondence search AND fit in one launch: the 1-NN of a query ends up in lane 0 of its 8-lane group, which
+// forms the point's terms at once (no neighbour arrays through memory, one launch per iteration fewer); every workgroup of the
+// search grid writes one partial row (rows of idle workgroups are zero), gn_solve_lu_kernel sums them in row order.
+__global__ void __launch_bounds__(256)
+icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                   const GnState* __restrict__ st, const int first, const Pose16 T0, const CellGridDev cg, const float gate, const double max_corr /* squared */,
+                   int* __restrict__ nn_id, unsigned char* __restrict__ eff, double* __restrict__ partials) {
+    const int done = first ? 0 : st->done;
+    if (done) return;  // uniform over the launch
+    __shared__ double wsum[4][32];
+    GridKnnLane r;
+    r.key = ~0ull; r.slot = 0u; r.found = 0; r.q = -1; r.kth = INFINITY;
+    grid_knn_body<1, true, false>((int)blockIdx.x, sx, sy, sz, n, st, first, T0, cg, gate, nullptr, nullptr, nullptr, nullptr, &r);
+    double T[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T[k] = first ? T0.m[k] : st->T[k];
+    double Hc[21], Bc[6], res = 0.0;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) Hc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Bc[k] = 0.0;
+    bool contrib = false;
+    if ((threadIdx.x & 7) == 0 && r.q >= 0) {
+        int id = -1;
+        if (r.found >= 1 && r.key != ~0ull && !((double)r.kth > max_corr)) {
+            const float4 m = cg.g.pts[r.slot];
+            id = __float_as_int(m.w);
+            icp_point_terms(T, sx[r.q], sy[r.q], sz[r.q], m, Hc, Bc, res);
+            contrib = true;
+        }
+        nn_id[r.q] = id;  // ids are reported for accepted correspondences only
+        eff[r.q] = contrib ? 1 : 0;
+    }
+    const int lane = threadIdx.x & 63;
+    double* row = &wsum[threadIdx.x >> 6][0];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) { const double v = wave_sum_dpp(Hc[k]); if (lane == 63) row[k] = v; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const double v = wave_sum_dpp(Bc[k]); if (lane == 63) row[21 + k] = v; }
+    const double sr = wave_sum_dpp(res), sc = wave_sum_dpp(contrib ? 1.0 : 0.0);
+    if (lane == 63) { row[27] = sr; row[28] = sc; }
+    block_row_from_wave_sums(wsum, partials);
+}
+
 __global__ void __launch_bounds__(256)
 icp_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
                const GnState* __restrict__ st, const int first, const Pose16 T0, const float4* __restrict__ nn_pts /* [n][1] */,
@@ -511,32 +597,7 @@ icp_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const
         if (nn_cnt[i] >= 1 && !((double)kth_d2[i] > max_corr)) {
             const float4 m = nn_pts[i];
             id = __float_as_int(m.w);
-            const RtFloat rt = load_rt_float(T);
-            const float px = sx[i], py = sy[i], pz = sz[i];
-            float qx, qy, qz;
-            xform_f(rt, px, py, pz, qx, qy, qz);
-            const double e0 = (double)qx - (double)m.x, e1 = (double)qy - (double)m.y, e2 = (double)qz - (double)m.z;
-            const double o0 = px, o1 = py, o2 = pz;
-            const double hat[9] = {0.0, o2, -o1, -o2, 0.0, o0, o1, -o0, 0.0};
-            double J[18];  // 3x6 column-major: [I | M],  M = -(R * SO3Hat(o)), zero terms kept in place
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    J[r + j * 3] = (r == j) ? 1.0 : 0.0;
-                    J[r + (j + 3) * 3] = -((T[r] * hat[0 + j * 3] + T[r + 4] * hat[1 + j * 3]) + T[r + 8] * hat[2 + j * 3]);
-                }
-            int k = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = a; b < 6; ++b) {
-                    Hc[k] = (J[0 + a * 3] * J[0 + b * 3] + J[1 + a * 3] * J[1 + b * 3]) + J[2 + a * 3] * J[2 + b * 3];
-                    ++k;
-                }
-#pragma unroll
-            for (int a = 0; a < 6; ++a) Bc[a] = ((-J[0 + a * 3]) * e0 + (-J[1 + a * 3]) * e1) + (-J[2 + a * 3]) * e2;
-            res = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+            icp_point_terms(T, sx[i], sy[i], sz[i], m, Hc, Bc, res);
             contrib = true;
         }
         nn_id[i] = id;  // ids are reported for accepted correspondences only

@@ -30,6 +30,7 @@ struct IcpMatcher final : fls_matcher {
     SourceFilter src_filter;
     CellGridImage grid;
     bool have_map = false;
+    bool fused = true;  // FLS_ICP_FUSED=0: separate correspondence and fit launches
     const IcpMatcher* owner = nullptr;  // batch lane: reads the owner's map grid
     DevScan scan;
     size_t raw_n = 0;
@@ -49,6 +50,7 @@ struct IcpMatcher final : fls_matcher {
         if (!(p.point_search_thres > 0.0) || !(p.map_cloud_filter_size > 0.f) || !(p.source_cloud_filter_size > 0.f)) return FLS_ERR_INVALID;
         init_common();
         src_filter.init();
+        if (const char* e = std::getenv("FLS_ICP_FUSED")) fused = std::atoi(e) != 0;
         return FLS_OK;
     }
     fls_status add_cloud_impl(const std::vector<PtI>& new_cloud) {  // :165-189
@@ -88,13 +90,21 @@ struct IcpMatcher final : fls_matcher {
         d_kth.reserve(std::max<size_t>(n, 1));
         d_nn_id.reserve(std::max<size_t>(n, 1));
         d_eff.reserve(std::max<size_t>(n, 1));
-        d_partials_b.reserve(size_t(std::max(nwg, 1)) * kPartialStride);
         const CellGridDev cg = cell_dev(owner ? owner->grid : grid);
         const dim3 knn_grid_dim(unsigned((((n * 8 + 255) / 256) + 63) / 64 * 64));  // multiple of 64: the XCD chunk re-map is a bijection
+        d_partials_b.reserve(size_t(std::max<unsigned>(knn_grid_dim.x, unsigned(std::max(nwg, 1)))) * kPartialStride);
         Pose16 T0;
         std::memcpy(T0.m, T, sizeof(T0.m));
         const unsigned word = run_mailbox_loop(int(p.max_iterations), n, [&](int it, int first) {
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
+            if (fused) {  // search + fit in one launch: one partial row per workgroup of the search grid
+                hipLaunchKernelGGL(icp_knn_fit_kernel, knn_grid_dim, dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), (const GnState*)d_state.p, first,
+                                   T0, cg, float(p.point_search_thres), p.point_search_thres, d_nn_id.p, d_eff.p, d_partials_b.p);
+                if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
+                hipLaunchKernelGGL(gn_solve_lu_kernel, dim3(1), dim3(kSolveThreads), 0, stream, d_state.p, first, T0, (const double*)d_partials_b.p,
+                                   int(knn_grid_dim.x), 0, p.rotation_converge_thres, p.position_converge_thres, 0, mb_dev, launch_word());
+                return;
+            }
             hipLaunchKernelGGL((grid_knn_kernel<1, true>), knn_grid_dim, dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p,
                                first, T0, cg, float(p.point_search_thres), d_nn_pts.p, d_nn_cnt.p, d_kth.p, (unsigned char*)nullptr);
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
