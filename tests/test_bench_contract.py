@@ -1,5 +1,5 @@
 """The bench.py output contract (one JSON line), checked on the line committed from the last GPU run of the round
-(profiles/r02_g_bench_full.json) and on bench.py's own source (metric / config strings = BASELINE.json's)."""
+(profiles/r02_h_bench_full.json) and on bench.py's own source (metric / config strings = BASELINE.json's)."""
 import json
 import os
 
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_g_bench_full.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_h_bench_full.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
