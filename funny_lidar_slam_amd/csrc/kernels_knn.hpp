@@ -357,6 +357,109 @@ ndt_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const flo
     if (COUNT) count_traffic(tc, c_p, c_h, c_c);
 }
 
+// ndt_lanes_kernel: the same per-point lambda with ONE LANE PER NEIGHBOUR VOXEL (8 lanes per point, lane 7 idle): the seven
+// dependent look-up chains of a point (table probe -> mean / information -> Mahalanobis gate -> J^T Sigma^-1 J) run side by side
+// and the launch has eight times the waves of ndt_kernel (which runs 29k points as 457 single-wave workgroups, under one wave
+// per SIMD).  512 threads = 64 points per workgroup: the number of partial rows stays what gn_solve_lu_kernel reads in one pass.
+// Per point the seven contributions are now added by the wave reduction tree instead of sequentially (last-bit differences in H, g;
+// counts and flags are integers).
+constexpr int kNdtLanesBlock = 512;
+__global__ void __launch_bounds__(kNdtLanesBlock)
+ndt_lanes_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
+                 const GnState* __restrict__ st, const int first, const Pose16 T0, const NdtGridDev ng, const double outlier_thr,
+                 int* __restrict__ hit_vid /* [n][7] */, unsigned char* __restrict__ eff7 /* [n][7] */, double* __restrict__ partials) {
+    const int done = first ? 0 : st->done;
+    double P[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) P[k] = first ? T0.m[k] : st->T[k];
+    if (done) return;
+    __shared__ double wsum[kNdtLanesBlock / 64][32];
+    const int i = (blockIdx.x * kNdtLanesBlock + threadIdx.x) >> 3, k = threadIdx.x & 7;
+    double Hc[21], Bc[6], res = 0.0, cnt = 0.0;
+#pragma unroll
+    for (int q = 0; q < 21; ++q) Hc[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) Bc[q] = 0.0;
+    if (i < n && k < 7) {
+        const double p0 = sx[i], p1 = sy[i], p2 = sz[i];
+        const double q0 = ((P[0] * p0 + P[4] * p1) + P[8] * p2) + P[12];
+        const double q1 = ((P[1] * p0 + P[5] * p1) + P[9] * p2) + P[13];
+        const double q2 = ((P[2] * p0 + P[6] * p1) + P[10] * p2) + P[14];
+        const double f0 = q0 * ng.inv_voxel, f1 = q1 * ng.inv_voxel, f2 = q2 * ng.inv_voxel;
+        const bool in_range = fabs(f0) < (double)kKeyLimit && fabs(f1) < (double)kKeyLimit && fabs(f2) < (double)kKeyLimit;
+        const int kx = in_range ? (int)f0 : 0, ky = in_range ? (int)f1 : 0, kz = in_range ? (int)f2 : 0;
+        // neighbour k of {0, -x, +x, +y, -y, -z, +z} (:122-127), branch-free
+        const int ox = k == 1 ? -1 : (k == 2 ? 1 : 0), oy = k == 3 ? 1 : (k == 4 ? -1 : 0), oz = k == 5 ? -1 : (k == 6 ? 1 : 0);
+        int vid = -1;
+        unsigned char ef = 0;
+        if (in_range) {
+            const unsigned long long key = pack_key(kx + ox, ky + oy, kz + oz);
+            unsigned h = hash_key(key) & ng.mask;
+            HashEntry e = ng.table[h];
+            while (e.key != key && e.key != kEmptyKey) { h = (h + 1) & ng.mask; e = ng.table[h]; }
+            if (e.key == key && e.count != 0u) {
+                const unsigned v = e.begin;
+                const double e0 = q0 - ng.mu[3 * v], e1 = q1 - ng.mu[3 * v + 1], e2 = q2 - ng.mu[3 * v + 2];
+                double I[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) I[q] = ng.info[9 * (size_t)v + q];
+                const double ei0 = (e0 * I[0] + e1 * I[1]) + e2 * I[2];
+                const double ei1 = (e0 * I[3] + e1 * I[4]) + e2 * I[5];
+                const double ei2 = (e0 * I[6] + e1 * I[7]) + e2 * I[8];
+                const double r = (ei0 * e0 + ei1 * e1) + ei2 * e2;
+                if (!(r != r) && !(r > outlier_thr)) {
+                    const double hat[9] = {0.0, p2, -p1, -p2, 0.0, p0, p1, -p0, 0.0};
+                    double J[18];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            J[q + j * 3] = -((P[q] * hat[0 + j * 3] + P[q + 4] * hat[1 + j * 3]) + P[q + 8] * hat[2 + j * 3]);
+                            J[q + (j + 3) * 3] = (q == j) ? 1.0 : 0.0;
+                        }
+                    double JtI[18];  // 6x3 col-major
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+                            JtI[a + c * 6] = (J[0 + a * 3] * I[0 + c * 3] + J[1 + a * 3] * I[1 + c * 3]) + J[2 + a * 3] * I[2 + c * 3];
+                    int kk = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int b = a; b < 6; ++b) {
+                            Hc[kk] = (JtI[a + 0 * 6] * J[0 + b * 3] + JtI[a + 1 * 6] * J[1 + b * 3]) + JtI[a + 2 * 6] * J[2 + b * 3];
+                            ++kk;
+                        }
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) Bc[a] = ((-JtI[a + 0 * 6]) * e0 + (-JtI[a + 1 * 6]) * e1) + (-JtI[a + 2 * 6]) * e2;
+                    res = r;
+                    cnt = 1.0;
+                    ef = 1;
+                    vid = ng.vid[v];
+                }
+            }
+        }
+        hit_vid[(size_t)i * 7 + k] = vid;
+        eff7[(size_t)i * 7 + k] = ef;
+    }
+    const int lane = threadIdx.x & 63;
+    double* row = &wsum[threadIdx.x >> 6][0];
+#pragma unroll
+    for (int q = 0; q < 21; ++q) { const double v = wave_sum_dpp(Hc[q]); if (lane == 63) row[q] = v; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { const double v = wave_sum_dpp(Bc[q]); if (lane == 63) row[21 + q] = v; }
+    const double sr = wave_sum_dpp(res), sc = wave_sum_dpp(cnt);
+    if (lane == 63) { row[27] = sr; row[28] = sc; }
+    __syncthreads();
+    if (threadIdx.x < 29) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kNdtLanesBlock / 64; ++w) v += wsum[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // ICP / NDT Gauss-Newton tail.  mode 0 = IcpOptimized (state [dt, dtheta], det==0 skip, converged
 // flag), mode 1 = IncrementalNDT (state [dtheta, dt], min_effective early-out).  Both right-multiply.

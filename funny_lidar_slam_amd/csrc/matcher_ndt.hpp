@@ -69,6 +69,7 @@ struct NdtMatcher final : fls_matcher {
     std::vector<PtI> source;
     SourceFilter src_filter;
     bool host_timing = false;  // FLS_HOST_TIMING=1: print the host-side split of every map update
+    bool lanes_kernel = true;  // FLS_NDT_LANES=0: one lane per point (ndt_kernel) instead of one lane per neighbour voxel
     DevBuf<int> d_hit_vid;
     DevBuf<unsigned char> d_eff7;
     double final_T[16]{};
@@ -85,6 +86,7 @@ struct NdtMatcher final : fls_matcher {
         init_common();
         src_filter.init();
         if (const char* e = std::getenv("FLS_HOST_TIMING")) host_timing = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_NDT_LANES")) lanes_kernel = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_NDT_DEVICE_UPDATE")) allow_device_update = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_NDT_DEVICE_MARGIN")) { const long c = std::atol(e); if (c >= 0) device_margin = size_t(c); }
         if (const char* e = std::getenv("FLS_NDT_DEVICE_SLACK")) { const long c = std::atol(e); if (c >= 0) device_slack = size_t(c); }
@@ -577,7 +579,10 @@ struct NdtMatcher final : fls_matcher {
         std::memcpy(T0.m, T, sizeof(T0.m));
         const unsigned word = run_mailbox_loop(int(p.max_iterations), n, [&](int it, int first) {
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
-            if (nblk > 0) {
+            if (nblk > 0 && lanes_kernel && !count_traffic) {  // one lane per neighbour voxel (64 points per workgroup: same row count)
+                hipLaunchKernelGGL(ndt_lanes_kernel, dim3(nblk), dim3(kNdtLanesBlock), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), (const GnState*)d_state.p, first,
+                                   T0, ng, p.ndt_res_outlier_threshold, d_hit_vid.p, d_eff7.p, d_partials_b.p);
+            } else if (nblk > 0) {
                 if (count_traffic)
                     hipLaunchKernelGGL(ndt_kernel<true>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, first, T0, ng,
                                        p.ndt_res_outlier_threshold, d_hit_vid.p, d_eff7.p, d_partials_b.p, d_tc.p);
