@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SCENARIOS = ("ivox", "ivox_lru", "icp", "ndt", "loam", "icp_loc", "kd_loc", "ivox_loc", "ndt_loc")
+SCENARIOS = ("ivox", "ivox_lru", "icp", "ndt", "ndt_dev", "loam", "icp_loc", "kd_loc", "ivox_loc", "ndt_loc")
 IVOX_LRU_CAPACITY = 9000
 
 
