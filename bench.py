@@ -123,6 +123,35 @@ def cpu_baseline(cfg, y, budget_s=20.0):
                       f"OpenMP per-point stage + sequential reduction, traffic instrumentation off, best of thread counts up to {ncpu} (best: {thr})"}
 
 
+def cpu_baseline_reference(cfg, y, budget_s=8.0):
+    """The reference's OWN LoamPointToPlaneIVOX<double>::Match (oracle/_ref/libref.so: its sources compiled verbatim against the
+    include-shadow shim of oracle/ref_shim) timed on the headline inputs -- SURVEY.md 8d "report both".  What it is and is not:
+    the reference's loops, containers and allocations exactly as written; but PSTL's par / par_unseq run SERIALLY here (no TBB
+    headers in this image, libstdc++ falls back to the sequential backend) and Eigen / PCL calls go through the shim's stand-ins,
+    so this is a 1-core number of the reference's code, not the reference as deployed.  Localization-mode instance: the same
+    Match loop, without the map update the mapping-mode Match appends (loam_point_to_plane_ivox.h:205-207)."""
+    from oracle import oracle as O, ref as R
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref.so")) and not R.available():
+        return None
+    p = O.Params(max_iterations=y["optimization_iter_num"], point_to_planar_thres=y["point_to_planar_thres"], position_converge_thres=y["position_converge_thres"],
+                 rotation_converge_thres=y["rotation_converge_thres"], is_localization_mode=1)
+    m = R.RefMatcher(O.P2PLANE_IVOX, p)
+    m.AddCloudToLocalMap(cfg["map"])
+    ts, t_start, iters = [], time.perf_counter(), 0
+    for rep in range(12):
+        t0 = time.perf_counter()
+        ok, T = m.Match(cfg["scan"], cfg["T_init"])
+        ts.append(time.perf_counter() - t0)
+        iters = int(m.stats.iterations)
+        if rep >= 2 and time.perf_counter() - t_start > budget_s:
+            break
+    t = float(np.median(ts[1:] if len(ts) > 1 else ts))
+    m.close()
+    return {"value": 1.0 / t, "unit": "scans/s", "cores": 1, "kind": "reference",
+            "sample": f"{len(ts)} Match calls (median) of the full 115,200-pt scan into the 1e6-pt iVox map ({iters} GN iterations), the reference's own "
+                      "LoamPointToPlaneIVOX<double> compiled verbatim (oracle/ref_shim): serial PSTL backend (no TBB here), shim Eigen / PCL -- 1 core"}
+
+
 def grid_counters(map_xyz, query_xyz, cell):
     """8d counters of a 27-cell uniform grid (cell = sqrt of the squared-distance gate) for kd-tree kinds: probes, hit cells, candidates."""
     inv = 1.0 / cell
@@ -469,6 +498,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ms_kernel, launches, point_iters = m.kernel_time()
     iters = m.stats.iterations
+    n_valid_head = m.stats.n_valid
     T_head = np.array(T)
     # algorithmic-traffic counters: one extra (untimed) Match with the counting kernel variant
     m.set_profiling(False, counters=True)
@@ -578,14 +608,35 @@ def main():
             o.AddCloudToLocalMap(cfg["map"])
             ok_ref, T_ref = o.Match(cfg["scan"], cfg["T_init"], update_map=False)
             edt, edr = synth.pose_error(T_first, T_ref)
-            for _ in range(2):
-                ok_ref3, T_ref3 = o.Match(cfg["scan"], cfg["T_init"], update_map=False)
+            first_iters = int(o.stats.iterations)
+            # call k of the handle vs call k of the oracle: the handle has run 1 + warmup + steps Matches when T_head is read and one more
+            # (the counting variant) when the device counters are read; the oracle is driven through the same number of calls.
+            # Re-registering one scan on one handle is NOT a fixed point: nearest_points_ persists (Q15) and the state enters a
+            # period-2 cycle after ~4 calls (poses 1.7e-5 m apart, candidate counts 13,415,502 / 13,415,539 on this workload) -- which is
+            # what round 2's "27th call vs the oracle's 3rd" comparison tripped over.  Beyond 64 calls an EVEN number of oracle calls is
+            # skipped (same phase of the cycle); tests/test_gpu_parity.py::test_repeated_match_..._full_size asserts call-by-call equality.
+            n_head = 1 + args.warmup + args.steps
+            n_oracle = n_head + 1
+            while n_oracle > 64:
+                n_oracle -= 2
+            k_head = n_oracle - 1  # the oracle call the timed step's result is compared with
+            T_refk, ok_refk, it_refk, nv_refk = T_ref, ok_ref, first_iters, int(o.stats.n_valid)
+            for call in range(2, n_oracle + 1):
+                ok_k, T_k = o.Match(cfg["scan"], cfg["T_init"], update_map=False)
+                if call == k_head:
+                    T_refk, ok_refk, it_refk, nv_refk = T_k, ok_k, int(o.stats.iterations), int(o.stats.n_valid)
             oc = o.counters()
-            sdt, sdr = synth.pose_error(T_head, T_ref3)
-            line["pose_err_vs_oracle"] = {"dt_m": edt, "dR_rad": edr, "same_iterations": bool(o.stats.iterations == iters), "same_return": bool(ok_ref == ok_first),
+            sdt, sdr = synth.pose_error(T_head, T_refk)
+            counters_equal = (int(oc.probes), int(oc.hit_voxels), int(oc.cand_points)) == (int(probes), int(hits), int(cand))
+            line["pose_err_vs_oracle"] = {"dt_m": edt, "dR_rad": edr, "same_iterations": bool(first_iters == iters), "same_return": bool(ok_ref == ok_first),
                                           "what": "first Match of the handle vs the oracle's first Match (identical inputs and state)",
-                                          "steady_state_step_vs_oracle_third_call": {"dt_m": sdt, "dR_rad": sdr},
-                                          "oracle_counters_third_call": {"probes": int(oc.probes), "hit_voxels": int(oc.hit_voxels), "cand_points": int(oc.cand_points)}}
+                                          "timed_step_vs_oracle_same_call_index": {
+                                              "dt_m": sdt, "dR_rad": sdr, "handle_calls": n_head, "oracle_calls": n_oracle,
+                                              "same_iterations": bool(it_refk == iters), "same_return": bool(ok_refk == ok), "same_n_valid": bool(nv_refk == int(n_valid_head)),
+                                              "device_counters_equal_oracle_counters": bool(counters_equal),
+                                              "note": "the timed region re-registers one resident scan on one handle; nearest_points_ persists (Q15) and the state runs "
+                                                      "into a period-2 cycle, so call k is compared with the oracle's call k (an even number of calls skipped beyond 64)"},
+                                          "oracle_counters_same_call": {"probes": int(oc.probes), "hit_voxels": int(oc.hit_voxels), "cand_points": int(oc.cand_points)}}
             o.close()
             if not args.no_extras:
                 t = time.perf_counter()
@@ -605,6 +656,12 @@ def main():
                 line["extras_wall_s"] = time.perf_counter() - t
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(cfg, y)
+                try:  # the reference's own compiled code beside the port (never at the expense of the line)
+                    ref_line = cpu_baseline_reference(cfg, y)
+                    if ref_line is not None:
+                        line["cpu_baseline_ref"] = ref_line
+                except Exception as e:
+                    line["cpu_baseline_ref"] = {"error": repr(e)[:200]}
         print(json.dumps(line))
     m.close()
     if distributed:

@@ -183,7 +183,7 @@ public:
 
     // Rebuild the mirror from a downloaded device image (the device was authoritative: kernels_ivox_update.hpp).  Voxels are
     // given in any order with their LRU stamp; the list is re-linked so that larger stamps sit nearer the head.
-    struct ImageVoxel { unsigned long long key; unsigned begin, count, cap, stamp; };
+    struct ImageVoxel { unsigned long long key; unsigned begin, count, cap; unsigned long long stamp; };  // 64-bit stamps: 2^32 inserted points is a day or two of mapping
     void rebuild_from_image(std::vector<ImageVoxel>& vox, const Pt4* pts, size_t n_points_total, int next_id_now) {
         clear();
         std::sort(vox.begin(), vox.end(), [](const ImageVoxel& a, const ImageVoxel& b) { return a.stamp < b.stamp; });
@@ -293,7 +293,8 @@ struct GridImage {
     bool want_hash = true;  // build the hash table too (fallback / FLS_IVOX_DENSE=0)
     // per-cell arrays of the device-side AddPoints (kernels_ivox_update.hpp): region capacity, LRU stamp, two scratch words
     DevBuf<unsigned char> d_cap_log2;
-    DevBuf<unsigned> d_stamp, d_pend, d_rank_mm;
+    DevBuf<unsigned long long> d_stamp;  // (64-bit like the NDT path's: the stamp base grows by the inserted points of every batch)
+    DevBuf<unsigned> d_pend, d_rank_mm;
     size_t n_cells_alloc = 0;
 
     static unsigned cap_for(size_t n) {
@@ -386,7 +387,7 @@ struct GridImage {
     unsigned long long upload_update_meta(const HostIvox& m, hipStream_t s) {
         const size_t ncell = size_t(win_n[0]) * size_t(win_n[1]) * size_t(win_n[2]);
         std::vector<unsigned char> cap(ncell, 0);
-        std::vector<unsigned> stamp(ncell, 0u);
+        std::vector<unsigned long long> stamp(ncell, 0ull);
         unsigned long long t = 0;
         for (int v = m.tail; v >= 0; v = m.pool[v].prev) {
             int x, y, z;
@@ -396,7 +397,7 @@ struct GridImage {
             unsigned l = 0;
             while ((1u << l) < m.pool[v].img_cap) ++l;
             cap[idx] = (unsigned char)l;
-            stamp[idx] = unsigned(++t);
+            stamp[idx] = (unsigned long long)(++t);
         }
         d_cap_log2.reserve(ncell);
         d_stamp.reserve(ncell);
@@ -404,7 +405,7 @@ struct GridImage {
         d_rank_mm.reserve(ncell);
         n_cells_alloc = ncell;
         FLS_HIP(hipMemcpyAsync(d_cap_log2.p, cap.data(), ncell, hipMemcpyHostToDevice, s));
-        FLS_HIP(hipMemcpyAsync(d_stamp.p, stamp.data(), ncell * sizeof(unsigned), hipMemcpyHostToDevice, s));
+        FLS_HIP(hipMemcpyAsync(d_stamp.p, stamp.data(), ncell * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
         FLS_HIP(hipMemsetAsync(d_pend.p, 0, ncell * sizeof(unsigned), s));
         FLS_HIP(hipMemsetAsync(d_rank_mm.p, 0xff, ncell * sizeof(unsigned), s));
         FLS_HIP(hipStreamSynchronize(s));  // (the host vectors go out of scope)

@@ -63,7 +63,7 @@ struct IvoxUpdArrays {
     uint2* cells;            // {begin, count} per window cell (the image the kNN kernel reads)
     float4* pts;
     unsigned char* cap_log2;  // per cell: log2 of its slot region's capacity (0: no region)
-    unsigned* stamp;         // per cell: LRU stamp of the last insertion (larger = more recent)
+    unsigned long long* stamp;  // per cell: LRU stamp of the last insertion (larger = more recent); 64-bit, never wraps
     unsigned* pend;          // per cell scratch: points of this batch (0 between batches)
     unsigned* rank_mm;       // per cell scratch: first, later last, rank of this batch (kUpdNoRank between batches)
     int ox, oy, oz, nx, ny, nz;
@@ -302,7 +302,7 @@ ivox_upd_finish(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState*
         }
     }
     if (lane == 0) {
-        a.stamp[cell] = (unsigned)(st->stamp_base + a.rank_mm[cell] + 1ull);
+        a.stamp[cell] = st->stamp_base + a.rank_mm[cell] + 1ull;
         a.pend[cell] = 0u;
         a.rank_mm[cell] = kUpdNoRank;
     }

@@ -158,11 +158,11 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         FLS_HIP(hipStreamSynchronize(stream));
         const size_t ncell = image.n_cells_alloc;
         std::vector<uint2> cells(ncell);
-        std::vector<unsigned> stamp(ncell);
+        std::vector<unsigned long long> stamp(ncell);
         std::vector<unsigned char> cap(ncell);
         std::vector<Pt4> pts(st.used);
         FLS_HIP(hipMemcpyAsync(cells.data(), image.d_cells.p, ncell * sizeof(uint2), hipMemcpyDeviceToHost, stream));
-        FLS_HIP(hipMemcpyAsync(stamp.data(), image.d_stamp.p, ncell * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipMemcpyAsync(stamp.data(), image.d_stamp.p, ncell * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         FLS_HIP(hipMemcpyAsync(cap.data(), image.d_cap_log2.p, ncell, hipMemcpyDeviceToHost, stream));
         if (st.used) FLS_HIP(hipMemcpyAsync(pts.data(), image.d_pts.p, st.used * sizeof(Pt4), hipMemcpyDeviceToHost, stream));
         FLS_HIP(hipStreamSynchronize(stream));
@@ -500,16 +500,29 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         BlobHeader hd;
         std::memcpy(&hd, r, sizeof(hd));
         if (std::memcmp(hd.magic, "FLSIVOX1", 8) != 0 || hd.version != 1 || hd.kind != unsigned(kind)) return FLS_ERR_INVALID;
-        if (n != sizeof(BlobHeader) + hd.n_voxels * sizeof(BlobVoxel) + hd.n_points * sizeof(Pt4)) return FLS_ERR_INVALID;
+        // the header is untrusted (it may come off a broadcast): bound both counts by the payload BEFORE multiplying (no u64 wrap),
+        // the resolution must be this handle's, every voxel non-empty and unique, the counts must add up in 64 bits
+        static_assert(sizeof(BlobVoxel) == 16 && sizeof(Pt4) == 16, "blob records");
+        const unsigned long long payload = (unsigned long long)(n - sizeof(BlobHeader)) / 16ull;
+        if ((n - sizeof(BlobHeader)) % 16u != 0 || hd.n_voxels > payload || hd.n_points > payload || hd.n_voxels + hd.n_points != payload) return FLS_ERR_INVALID;
+        if (!(hd.resolution > 0.f) || !std::isfinite(hd.resolution) || hd.resolution != ivox.resolution) return FLS_ERR_INVALID;
+        if (hd.n_voxels > hd.n_points || hd.next_id < 0 || (unsigned long long)hd.next_id < hd.n_points) return FLS_ERR_INVALID;
         const BlobVoxel* bv = reinterpret_cast<const BlobVoxel*>(r + sizeof(hd));
         const Pt4* bp = reinterpret_cast<const Pt4*>(r + sizeof(hd) + hd.n_voxels * sizeof(BlobVoxel));
         std::vector<HostIvox::ImageVoxel> vox(size_t(hd.n_voxels));
-        size_t q = 0;
+        unsigned long long qsum = 0;
         for (size_t k = 0; k < vox.size(); ++k) {  // stamp = position in the LRU order (tail first)
-            vox[k] = HostIvox::ImageVoxel{bv[k].key, unsigned(q), bv[k].count, 0u, unsigned(k + 1)};
-            q += bv[k].count;
+            if (bv[k].count == 0u || qsum + bv[k].count > hd.n_points) return FLS_ERR_INVALID;
+            vox[k] = HostIvox::ImageVoxel{bv[k].key, unsigned(qsum), bv[k].count, 0u, (unsigned long long)(k + 1)};
+            qsum += bv[k].count;
         }
-        if (q != hd.n_points) return FLS_ERR_INVALID;
+        if (qsum != hd.n_points) return FLS_ERR_INVALID;
+        {
+            std::vector<unsigned long long> keys(vox.size());
+            for (size_t k = 0; k < vox.size(); ++k) keys[k] = vox[k].key;
+            std::sort(keys.begin(), keys.end());
+            if (std::adjacent_find(keys.begin(), keys.end()) != keys.end()) return FLS_ERR_INVALID;  // a voxel listed twice
+        }
         device_map = false;
         const size_t capacity = ivox.capacity;
         ivox.rebuild_from_image(vox, bp, size_t(hd.n_points), int(hd.next_id));

@@ -46,8 +46,10 @@ SCENARIOS = {
 }
 
 
-def make_replay(name: str) -> dict:
-    """returns dict(mode, y, init_clouds=[world clouds for the first AddCloudToLocalMap], frames=[dict(scan, corner, guess_step)])
+def make_replay(name: str, n_frames: int = None, yaw_long_deg: float = 4.0) -> dict:
+    """n_frames / yaw_long_deg: overrides for the long trajectories of tests/test_gpu_long_replay.py (a 9-degree yaw on the long
+    steps bends the path into a circle of ~8.5 m radius that stays inside the 80 x 50 m room for any number of frames).
+    returns dict(mode, y, init_clouds=[world clouds for the first AddCloudToLocalMap], frames=[dict(scan, corner, guess_step)])
     Frame k is Match(scan_k, T = T_prev_result @ guess_step_k): guess_step is the nominal motion, the true motion differs a little
     (what an IMU prediction looks like); `big_jump` frames get a poor prediction on purpose."""
     sc = SCENARIOS[name]
@@ -70,16 +72,23 @@ def make_replay(name: str) -> dict:
     if name == "ivox":  # a prior map around the start (localization.cpp:135 loads one; a single sparse scan makes a poor iVox map)
         init = [synth.sample_map(scene, 60000, synth.rng_for(5, 0, 9), radius=30.0)]
     frames = []
-    for k in range(sc["frames"]):
+    for k in range(n_frames if n_frames is not None else sc["frames"]):
         # alternate long steps (pass the 1.0 m / 0.2 rad keyframe gate) and short ones (fail it)
         long_step = (k % 3) != 1
-        nominal = _step(rng, [1.25 if long_step else 0.25, 0.1 * (k % 2), 0.0], [0.0, 0.0, 4.0 if long_step else 0.5])
+        nominal = _step(rng, [1.25 if long_step else 0.25, 0.1 * (k % 2), 0.0], [0.0, 0.0, yaw_long_deg if long_step else 0.5])
         noise = synth.random_pose(rng, 0.4, 0.06)
         guess_step = nominal
         if name == "icp" and k == 6:
             # a prediction that is off by ~0.9 m / 5 deg: 12 iterations are not enough -> Match returns false (Q10)
             noise = _step(rng, [0.8, -0.45, 0.0], [0.0, 0.0, 5.0])
         T = T @ nominal @ noise
+        if n_frames is not None:
+            # long runs: the per-frame noise must not random-walk the sensor into the ground or onto its side -- keep the
+            # accumulated yaw and x / y, draw roll / pitch / z afresh every frame
+            yaw = np.arctan2(T[1, 0], T[0, 0])
+            tilt = np.deg2rad(rng.uniform(-0.4, 0.4, 2))
+            T[:3, :3] = synth.so3_exp(np.array([0.0, 0.0, yaw])) @ synth.so3_exp(np.array([tilt[0], tilt[1], 0.0]))
+            T[2, 3] = rng.uniform(-0.06, 0.06)
         scan, corner = observe(T)
         frames.append(dict(scan=scan, corner=corner, guess_step=guess_step, T_gt=T.copy()))
     return dict(name=name, mode=mode, y=sc["y"], init_clouds=init, frames=frames)

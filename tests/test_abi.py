@@ -94,10 +94,22 @@ def test_product_does_not_reference_the_oracle():
     assert "oracle" not in out
 
 
-def _build_adapter(tmp_path):
+REF_INCLUDE = "/root/reference/include"
+
+
+def _build_adapter(tmp_path, real_headers=None):
+    """real_headers: None = the reference's real headers when /root/reference exists (this container), else the stand-ins of
+    tests/stubs (the GPU box has no /root/reference)."""
     import subprocess
-    exe = os.path.join(str(tmp_path), "adapter_smoke")
-    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "tests", "stubs"), "-I" + os.path.join(ROOT, "include"),
+    if real_headers is None:
+        real_headers = os.path.isdir(os.path.join(REF_INCLUDE, "registration"))
+    exe = os.path.join(str(tmp_path), "adapter_smoke_real" if real_headers else "adapter_smoke")
+    if real_headers:
+        incs = ["-DFLS_REAL_REFERENCE_HEADERS", "-w", "-I" + os.path.join(ROOT, "oracle", "ref_shim", "include"), "-I" + os.path.join(ROOT, "oracle"),
+                "-I" + REF_INCLUDE]
+    else:
+        incs = ["-Wall", "-Werror", "-I" + os.path.join(ROOT, "tests", "stubs")]
+    cmd = ["g++", "-std=c++17"] + incs + ["-I" + os.path.join(ROOT, "include"),
            os.path.join(ROOT, "tests", "stubs", "adapter_smoke.cpp"), "-o", exe, "-L" + os.path.dirname(_lib.LIB_PATH), "-lfls_reg",
            "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
@@ -105,12 +117,15 @@ def _build_adapter(tmp_path):
 
 
 def test_cpp_adapter_compiles_and_links(built, tmp_path):
-    """include/fls_hip_registration.h (RegistrationInterface on top of the C ABI) builds with plain g++
-    against stand-in reference headers and links to libfls_reg.so."""
+    """include/fls_hip_registration.h (RegistrationInterface on top of the C ABI) builds with plain g++ against the reference's
+    REAL registration/registration_interface.h + common/data_type.h + lidar/pointcloud_cluster.h (through the Eigen / PCL / glog
+    include shadow of oracle/ref_shim) when /root/reference exists, and against the stand-in headers everywhere; links to
+    libfls_reg.so."""
     import subprocess
-    exe = _build_adapter(tmp_path)
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0 and "adapter compiled" in out.stdout
+    for real in ([True, False] if os.path.isdir(os.path.join(REF_INCLUDE, "registration")) else [False]):
+        exe = _build_adapter(tmp_path, real)
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0 and "adapter compiled" in out.stdout, (real, out.stdout, out.stderr)
 
 
 @pytest.mark.gpu

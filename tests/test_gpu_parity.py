@@ -65,6 +65,41 @@ def test_device_traffic_counters_equal_the_oracles():
     m.close()
 
 
+def test_repeated_match_on_one_handle_call_k_equals_oracle_call_k_full_size():
+    """The computation bench.py TIMES -- the same resident 115,200-point scan re-registered on ONE handle, full BASELINE configs[1]
+    size -- against the oracle driven the same way, call k vs call k.  nearest_points_ persists from Match to
+    Match (Q15: a point without candidates keeps its previous list), so call k depends on every earlier call.  Per call: same return, iterations, n_valid, the three traffic counters EXACTLY, pose <= 1e-12 m / rad."""
+    cfg = synth.make_config(1)
+    y = reg.YAML_NCLT_IVOX
+    m = reg.make_matcher("PointToPlane_IVOX", y)
+    o = util.oracle_for("PointToPlane_IVOX", y)
+    m.AddCloudToLocalMap([cfg["map"]])
+    o.AddCloudToLocalMap(cfg["map"])
+    cl = reg.PointcloudCluster(planar_cloud_=cfg["scan"])
+    m.UploadScan(cl)
+    m.set_profiling(False, counters=True)  # the counting variant of the kNN kernel: same results, counters on the device
+    seen = []
+    for call in range(12):
+        T = cfg["T_init"].copy()
+        ok = m.MatchResident(T, update_map=False)
+        ok_ref, T_ref = o.Match(cfg["scan"], cfg["T_init"], update_map=False)
+        c = o.counters()
+        got, want = m.traffic_counters(), (c.probes, c.hit_voxels, c.cand_points)
+        dt, dr = synth.pose_error(T, T_ref)
+        assert ok == ok_ref and m.stats.iterations == o.stats.iterations and m.stats.n_valid == o.stats.n_valid, (call, m.stats.iterations, o.stats.iterations, m.stats.n_valid, o.stats.n_valid)
+        assert got == want, (call, got, want)
+        assert dt <= 1e-12 and dr <= 1e-12, (call, dt, dr)
+        seen.append((want, m.stats.n_valid))
+    # the steady state is NOT a fixed point: the persisting neighbour lists make the repeated Match a period-2 cycle (two poses
+    # 1.7e-5 m apart on this workload) -- round 2's bench compared the 27th call with the oracle's 3rd and read that as a gap.
+    # From some call on, call k equals call k + 2.
+    settled = next(k for k in range(len(seen) - 2) if all(seen[j] == seen[j + 2] for j in range(k, len(seen) - 2)))
+    print("call-by-call (counters, n_valid):", seen[:6], "... period <= 2 from call", settled)
+    assert settled <= 6, seen
+    m.close()
+    o.close()
+
+
 def test_config1_icp_localization():
     """BASELINE configs[0]: 16x900 scan, Optimized-ICP vs the 50k-pt fixed map (localization mode), + GetFitnessScore."""
     cfg = synth.make_config(0)
