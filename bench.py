@@ -336,9 +336,81 @@ def bench_mapping_mode(reg, synth, cfg, n_scans=6):
         res["incremental_ndt"] = bench_ndt_mapping_mode(reg, synth)
     except Exception as e:  # never at the expense of the rest of the line
         res["incremental_ndt"] = {"error": repr(e)[:200]}
+    try:
+        res.update(bench_kd_mapping_mode(reg, synth))
+    except Exception as e:
+        res["icp_optimized"] = {"error": repr(e)[:200]}
     res["note"] = (f"{n_scans} consecutive scans (0.5 m / 0.5 deg steps), scan resident; medians over scans 1..; the scans that follow a map update run more "
                    "iterations against a map the insert rule has densified near the sensor, so ms_match_only here is not the headline step")
     return res
+
+
+def bench_kd_mapping_mode(reg, synth, n_scans=6):
+    """IcpOptimized / LoamFull in mapping mode as the ROS adapter issues them: fls_match from HOST buffers with update_map = 1; every
+    frame passes the keyframe gate, so every Match ends in AddCloudToLocalMap = deque push + VoxelGrid of the concatenated deque +
+    kd-tree (here: cell grid) rebuild (icp_optimized.h:165-189, loam_full_kdtree.h:65-104).  Three settings: the round-2 host path
+    (host filter, host grid build + upload), the default (exact host filter, grid built on the device) and the opt-in device path
+    (deque resident on the device, map-side VoxelGrid + grid build on the device).  The deque is pre-filled so that the timed
+    keyframes see a local map of production size."""
+    out = {}
+    keys = ("FLS_DEVICE_GRID_BUILD", "FLS_DEVICE_VOXELGRID")
+    prev = {k: os.environ.get(k) for k in keys}
+    cases = [("icp_optimized", "IcpOptimized", dict(reg.YAML_NCLT_ICP), 0, 30), ("loam_full", "LoamFull_KdTree", dict(reg.YAML_NCLT_LOAM_FULL), 3, 24)]
+    for label, mode, y, cid, prefill in cases:
+        cfg = synth.make_config(cid)
+        scene = cfg["scene"]
+        rng = synth.rng_for(cid, 777)
+        lid = synth.VELODYNE_16 if cid == 0 else synth.VELODYNE_64
+        Tgt = np.eye(4)
+        frames = []
+        for k in range(n_scans + 1):
+            scan = synth.cast_scan(scene, Tgt, rng=rng, **lid)
+            corner = None
+            if cid == 3:
+                corner = synth.cast_edge_scan(scene, Tgt, 7680, rng)
+                scan = scan[::2].copy()
+            frames.append((scan, corner, Tgt.copy()))
+            step = np.eye(4)
+            step[:3, :3] = synth.so3_exp(np.deg2rad([0.0, 0.0, 3.0]))
+            step[:3, 3] = [1.2, 0.1, 0.0]  # beyond the 1.0 m keyframe gate
+            Tgt = Tgt @ step
+        world = lambda c, T: (c.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+        res = {}
+        for setting, env in (("host_path_round2", ("0", "0")), ("default_device_grid_build", ("1", "0")), ("device_deque_filter_grid_opt_in", ("1", "1"))):
+            os.environ.update(dict(zip(keys, env)))
+            m = reg.make_matcher(mode, y)
+            s0, c0, T0 = frames[0]
+            init = [world(s0, T0)] + ([world(c0, T0)] if c0 is not None else [])
+            for _ in range(prefill + 1):  # the frontend's first AddCloudToLocalMap, then the pre-fill (same clouds: the filter merges them)
+                m.AddCloudToLocalMap(init)
+            t_match, t_both, upd = [], [], 0
+            for scan, corner, Tk in frames[1:]:
+                cl = util_cluster(reg, mode, scan, corner)
+                g = Tk.copy()  # prediction = ground truth of the frame (an IMU-grade guess)
+                T = g.copy(); t = time.perf_counter(); m.Match(cl, T, update_map=False); t_match.append(time.perf_counter() - t)
+                T = g.copy(); t = time.perf_counter(); m.Match(cl, T, update_map=True); t_both.append(time.perf_counter() - t)
+                upd += int(m.stats.map_updated)
+            res[setting] = {"ms_match_only_from_host_buffers": 1e3 * float(np.median(t_match[1:])), "ms_match_plus_keyframe_update": 1e3 * float(np.median(t_both[1:])),
+                            "ms_keyframe_update_only": 1e3 * float(np.median(np.array(t_both[1:]) - np.array(t_match[1:]))), "keyframes": upd,
+                            "map_points_after": [m.map_size(0)] + ([m.map_size(1)] if cid == 3 else []),
+                            "grids_built_on_device": m.map_size(114), "map_filters_on_device": m.map_size(115), "map_filters_on_host": m.map_size(116)}
+            m.close()
+        a, b = res["host_path_round2"]["ms_keyframe_update_only"], res["device_deque_filter_grid_opt_in"]["ms_keyframe_update_only"]
+        res["keyframe_update_speedup_device_vs_host"] = a / b if b > 0 else None
+        res["deque_frames_at_timing"] = prefill + 1
+        out[label] = res
+    for k, v in prev.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    return out
+
+
+def util_cluster(reg, mode, scan, corner):
+    if mode == "IcpOptimized":
+        return reg.PointcloudCluster(ordered_cloud_=scan)
+    return reg.PointcloudCluster(planar_cloud_=scan, corner_cloud_=corner)
 
 
 def baseline_metric():

@@ -5,6 +5,7 @@
 // decides the number of radix passes and the "leaf size too small" refusal, voxel_grid.hpp:69-74) and the output size.
 #pragma once
 #include "kernels_voxelgrid.hpp"
+#include "kernels_gridbuild.hpp"
 #include "matcher_base.hpp"
 #include <cstdlib>
 #include <climits>
@@ -72,7 +73,7 @@ struct DeviceVoxelGrid {
         h_hdr.reserve(2);
         d_hdr.reserve(1);
         for (int a = 0; a < 3; ++a) { h_hdr.p[0].mn[a] = 0xffffffffu; h_hdr.p[0].mx[a] = 0u; }
-        h_hdr.p[0].n_out = 0u; h_hdr.p[0].pad = 0u;
+        h_hdr.p[0].n_out = 0u; h_hdr.p[0].n_bad = 0u;
         FLS_HIP(hipMemcpyAsync(d_hdr.p, &h_hdr.p[0], sizeof(VgHeader), hipMemcpyHostToDevice, s));
         const int ni = int(n);
         const int nb1 = (ni + kVgBlock - 1) / kVgBlock, nb2 = (ni + kVgScanBlock - 1) / kVgScanBlock;
@@ -133,6 +134,184 @@ struct DeviceVoxelGrid {
         FLS_HIP(hipStreamSynchronize(s));
         for (size_t i = 0; i < n_out; ++i) c[i] = PtI{tmp[i], tmp[n_out + i], tmp[2 * n_out + i], tmp[3 * n_out + i]};
         return c;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// The kd-tree kinds' cell grid built on the device (kernels_gridbuild.hpp): exact, so it is the default
+// (FLS_DEVICE_GRID_BUILD=0 restores the host build).  Input: the map cloud as x | y | z planes resident on the device.
+// One short host wait (the bounds decide the window).  false: declined (empty, a non-finite point, cells outside the key
+// range, a window larger than kMaxWindowCells) -- the caller takes the host build, which also produces the error codes.
+// ---------------------------------------------------------------------------------------------
+struct DeviceGridBuilder {
+    DevicePairSort sort;
+    DevBuf<VgHeader> d_hdr;
+    PinnedBuf<VgHeader> h_hdr;
+    unsigned long long builds = 0, declined = 0;
+    bool run(CellGridImage& g, const float* x, const float* y, const float* z, size_t n, float cell_size, int n_rings, bool with_by_id, hipStream_t s) {
+        if (n == 0 || n > size_t(kVgMaxBlocks) * kVgTile) { ++declined; return false; }
+        h_hdr.reserve(2);
+        d_hdr.reserve(1);
+        for (int a = 0; a < 3; ++a) { h_hdr.p[0].mn[a] = 0xffffffffu; h_hdr.p[0].mx[a] = 0u; }
+        h_hdr.p[0].n_out = 0u; h_hdr.p[0].n_bad = 0u;
+        FLS_HIP(hipMemcpyAsync(d_hdr.p, &h_hdr.p[0], sizeof(VgHeader), hipMemcpyHostToDevice, s));
+        const int ni = int(n), nb = (ni + kVgBlock - 1) / kVgBlock;
+        hipLaunchKernelGGL(vg_minmax, dim3(unsigned(std::min(nb, 48))), dim3(kVgBlock), 0, s, x, y, z, ni, d_hdr.p);
+        FLS_HIP(hipMemcpyAsync(&h_hdr.p[1], d_hdr.p, sizeof(VgHeader), hipMemcpyDeviceToHost, s));
+        FLS_HIP(hipStreamSynchronize(s));
+        const VgHeader& hh = h_hdr.p[1];
+        if (hh.n_bad != 0u || hh.mn[0] == 0xffffffffu) { ++declined; return false; }
+        const float inv = 1.0f / cell_size;
+        CgWindow w;
+        w.inv_cell = inv;
+        int mn[3], mx[3];
+        for (int a = 0; a < 3; ++a) {  // floorf(p * inv) is monotone in p: the extreme cells come from the extreme coordinates
+            const float lo = std::floor(vg_unord(hh.mn[a]) * inv), hi = std::floor(vg_unord(hh.mx[a]) * inv);
+            if (!(std::fabs(lo) < float(kKeyLimit) && std::fabs(hi) < float(kKeyLimit))) { ++declined; return false; }
+            mn[a] = int(lo); mx[a] = int(hi);
+        }
+        size_t nc = 1;
+        for (int a = 0; a < 3; ++a) nc *= size_t(mx[a] - mn[a] + 1);
+        if (nc > GridImage::kMaxWindowCells) { ++declined; return false; }
+        w.ox = mn[0]; w.oy = mn[1]; w.oz = mn[2];
+        w.nx = mx[0] - mn[0] + 1; w.ny = mx[1] - mn[1] + 1; w.nz = mx[2] - mn[2] + 1;
+        sort.prepare(n);
+        g.d_pts.reserve(n);
+        g.d_cells.reserve(nc);
+        g.d_table.reserve(1);  // (never probed: every search kernel takes the window path when the window exists)
+        FLS_HIP(hipMemsetAsync(g.d_cells.p, 0, nc * sizeof(uint2), s));
+        hipLaunchKernelGGL(cg_keys, dim3(unsigned(nb)), dim3(kVgBlock), 0, s, x, y, z, ni, w, sort.k0, sort.v0);
+        sort.run(DevicePairSort::passes_for((unsigned long long)(nc - 1)), s);
+        hipLaunchKernelGGL(cg_fill, dim3(unsigned(nb)), dim3(kVgBlock), 0, s, (const unsigned*)sort.k0, (const unsigned*)sort.v0, ni, x, y, z, g.d_pts.p, g.d_cells.p);
+        hipLaunchKernelGGL(cg_count, dim3(unsigned(nb)), dim3(kVgBlock), 0, s, (const unsigned*)sort.k0, ni, g.d_cells.p);
+        if (with_by_id) {
+            g.d_by_id.reserve(n);
+            hipLaunchKernelGGL(cg_by_id, dim3(unsigned(nb)), dim3(kVgBlock), 0, s, x, y, z, ni, g.d_by_id.p);
+        }
+        FLS_HIP(hipGetLastError());
+        g.cell = cell_size;
+        g.inv_cell = inv;
+        g.rings = n_rings;
+        g.table.clear(); g.pts.clear(); g.cells.clear();
+        g.mask = 0;
+        g.used = n;
+        g.have_window = true;
+        g.win_o[0] = w.ox; g.win_o[1] = w.oy; g.win_o[2] = w.oz;
+        g.win_n[0] = w.nx; g.win_n[1] = w.ny; g.win_n[2] = w.nz;
+        g.n_cells = 0;  // (not counted on this path)
+        ++builds;
+        return true;
+    }
+};
+
+// The local-map deque of the kd-tree kinds on the device (icp_optimized.h:173-184, loam_full_kdtree.h:70-91,
+// loam_point_to_plane_kdtree.h:60-71): the clouds of the deque live back to back in four SoA planes, so "concatenate the deque"
+// is a pointer + a length.  push_back appends (one host-to-device copy of the NEW cloud + a de-interleave kernel), pop_front
+// advances the head; the planes are re-packed when the tail reaches the end.  Only used by the opt-in device map filter.
+struct DeviceCloudRing {
+    DevBuf<float> planes;  // x | y | z | i, `cap` floats each
+    DevBuf<float4> rows;   // staging of the cloud being appended
+    PinnedBuf<float4> h_rows;
+    size_t cap = 0, head = 0, tail = 0;
+    std::deque<size_t> sizes;
+    const float* x() const { return planes.p + head; }
+    const float* y() const { return planes.p + cap + head; }
+    const float* z() const { return planes.p + 2 * cap + head; }
+    const float* in() const { return planes.p + 3 * cap + head; }
+    size_t size() const { return tail - head; }
+    void clear() { head = tail = 0; sizes.clear(); }
+    void pop_front() {
+        if (sizes.empty()) return;
+        head += sizes.front();
+        sizes.pop_front();
+        if (sizes.empty()) head = tail = 0;
+    }
+    void make_room(size_t extra, hipStream_t s) {
+        if (tail + extra <= cap) return;
+        const size_t live = tail - head;
+        size_t ncap = cap;
+        while (live + extra > ncap || ncap < 65536) ncap = ncap ? ncap * 2 : 65536;
+        if (ncap == cap && head >= live) {  // re-pack in place: source and destination do not overlap
+            for (int a = 0; a < 4 && live; ++a)
+                FLS_HIP(hipMemcpyAsync(planes.p + size_t(a) * cap, planes.p + size_t(a) * cap + head, live * sizeof(float), hipMemcpyDeviceToDevice, s));
+        } else {
+            if (ncap == cap) ncap *= 2;
+            DevBuf<float> np;
+            np.reserve(4 * ncap);
+            for (int a = 0; a < 4 && live; ++a)
+                FLS_HIP(hipMemcpyAsync(np.p + size_t(a) * ncap, planes.p + size_t(a) * cap + head, live * sizeof(float), hipMemcpyDeviceToDevice, s));
+            FLS_HIP(hipStreamSynchronize(s));  // the old planes are freed below
+            std::swap(planes.p, np.p);  // (np now owns the old planes and frees them)
+            std::swap(planes.cap, np.cap);
+            cap = ncap;
+        }
+        head = 0;
+        tail = live;
+    }
+    void push_back(const std::vector<PtI>& c, hipStream_t s) {
+        const size_t n = c.size();
+        make_room(n, s);
+        if (n) {
+            static_assert(sizeof(PtI) == sizeof(float4), "PtI rows are float4 rows");
+            h_rows.reserve(n);
+            rows.reserve(n);
+            std::memcpy(h_rows.p, c.data(), n * sizeof(PtI));
+            FLS_HIP(hipMemcpyAsync(rows.p, h_rows.p, n * sizeof(float4), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(soa_append, dim3(unsigned((n + kVgBlock - 1) / kVgBlock)), dim3(kVgBlock), 0, s, (const float4*)rows.p, int(n),
+                               planes.p + tail, planes.p + cap + tail, planes.p + 2 * cap + tail, planes.p + 3 * cap + tail);
+            FLS_HIP(hipGetLastError());
+            FLS_HIP(hipStreamSynchronize(s));  // the pinned staging rows are reused by the next push
+        }
+        tail += n;
+        sizes.push_back(n);
+    }
+};
+
+// Map maintenance of one kd-tree kind on the device: the cell-grid build (exact: default) and, opt-in with
+// FLS_DEVICE_VOXELGRID=1, the deque + map-side pcl::VoxelGrid (same centroid contract as the source filter,
+// kernels_voxelgrid.hpp).  The host deque stays authoritative: whatever the device declines is redone by the host path.
+struct KdMapDevice {
+    bool grid_on_device = true;  // FLS_DEVICE_GRID_BUILD=0: host std::sort + bucket loop + upload (A/B)
+    bool vg_on_device = false;   // FLS_DEVICE_VOXELGRID=1
+    DeviceGridBuilder builder;
+    DeviceVoxelGrid vg;
+    PinnedBuf<float> stage;
+    DevBuf<float> xyz;
+    unsigned long long device_filters = 0, host_filters = 0;
+    void init() {
+        if (const char* e = std::getenv("FLS_DEVICE_GRID_BUILD")) grid_on_device = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_DEVICE_VOXELGRID")) vg_on_device = std::atoi(e) != 0;
+    }
+    // grid over a HOST cloud (the exact host filter's output, or an unfiltered cloud)
+    fls_status build_from_host(CellGridImage& grid, const std::vector<PtI>& cloud, float cell, hipStream_t s, int rings = 1, bool by_id = false) {
+        const size_t n = cloud.size();
+        if (grid_on_device && n != 0) {
+            stage.reserve(3 * n);
+            xyz.reserve(3 * n);
+            for (size_t i = 0; i < n; ++i) { stage.p[i] = cloud[i].x; stage.p[n + i] = cloud[i].y; stage.p[2 * n + i] = cloud[i].z; }
+            FLS_HIP(hipMemcpyAsync(xyz.p, stage.p, 3 * n * sizeof(float), hipMemcpyHostToDevice, s));
+            if (builder.run(grid, xyz.p, xyz.p + n, xyz.p + 2 * n, n, cell, rings, by_id, s)) return FLS_OK;  // (run() synchronises: the staging is free)
+            FLS_HIP(hipStreamSynchronize(s));
+        }
+        return grid.build(cloud, cell, s, rings, by_id);
+    }
+    // local map = [VoxelGrid of] the concatenated deque, then the grid: all on the device.  false: declined, nothing changed.
+    bool filter_and_build(CellGridImage& grid, const DeviceCloudRing& ring, bool filter, float leaf, float cell, int rings, bool by_id, size_t& n_map,
+                          hipStream_t s) {
+        if (!vg_on_device || !grid_on_device) return false;
+        size_t n = ring.size();
+        if (n == 0) return false;
+        const float *x = ring.x(), *y = ring.y(), *z = ring.z();
+        if (filter) {
+            if (!vg.run(x, y, z, ring.in(), n, leaf, s)) return false;
+            x = vg.ox(); y = vg.oy(); z = vg.oz();
+            n = vg.n_out;
+            if (n == 0) return false;
+        }
+        if (!builder.run(grid, x, y, z, n, cell, rings, by_id, s)) return false;
+        n_map = n;
+        ++device_filters;
+        return true;
     }
 };
 

@@ -419,16 +419,17 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
 // lane takes a ticket with an agent-scope atomic; the workgroup that draws the last ticket reads all rows with sc1
 // (relaxed agent-scope) loads.  No release fence: an agent-scope release writes back the XCD's whole L2, which
 // this kernel has just dirtied with 28 KB of Jacobian rows per workgroup (measured: 7 us on the critical path).
-// `ticket` is reset by the last workgroup, so it is zero at every launch.
+// The ticket counters (kTicketWords unsigned words) are reset by their last arrivers, so they are zero at every launch.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFitThreads = 512;
+constexpr int kTicketWords = 32 * 10;  // [0] single counter (shards <= 1) | [32 (1 + s)] shard s | [32 * 9] top counter
 template <bool FIRST>
 __global__ void __launch_bounds__(kFitThreads)
 p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
                          GnState* __restrict__ st, const Pose16 T0, const float4* __restrict__ nn_pts,
                          const unsigned char* __restrict__ nn_cnt, double* __restrict__ Jst /* [7][n] */, unsigned char* __restrict__ flag,
                          double* __restrict__ partials, unsigned* __restrict__ ticket, Mailbox* __restrict__ mb, const unsigned match_id,
-                         const double plane_thres, const double rot_thr, const double pos_thr) {
+                         const double plane_thres, const double rot_thr, const double pos_thr, const int shards) {
     const int i = blockIdx.x * kFitThreads + threadIdx.x;
     const int done = FIRST ? 0 : st->done;
     double T44[16];
@@ -495,15 +496,37 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
     __syncthreads();
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Sharded fan-in: 225 arrivals on ONE device-scope counter serialise at ~12 ns each (the last arriver waits ~3 us behind the
+    // others -- all workgroups finish their fit phase within 0.4 us of each other); eight counters (shard = blockIdx & 7, the XCD the
+    // workgroup normally runs on -- a speed matter only, every atomic is agent scope) take ~28 arrivals each in parallel, the last
+    // arriver of a shard moves on to the top counter, and the last of those is the reducer.  Counters sit 128 bytes apart and are
+    // reset by their last arriver, so they are zero at every launch.
+    if (threadIdx.x == 0) {
+        unsigned last = 0u;
+        if (shards <= 1) {
+            last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+            if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const unsigned sh = blockIdx.x & 7u, nsh = (gridDim.x - sh + 7u) >> 3, ntop = gridDim.x < 8u ? gridDim.x : 8u;
+            unsigned* const cs = ticket + 32u * (1u + sh);
+            unsigned* const ct = ticket + 32u * 9u;
+            if (__hip_atomic_fetch_add(cs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1u) {
+                __hip_atomic_store(cs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_fetch_add(ct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ntop - 1u) {
+                    __hip_atomic_store(ct, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = 1u;
+                }
+            }
+        }
+        s_ticket = last;
+    }
     __syncthreads();
-    if (s_ticket != gridDim.x - 1) return;
+    if (!s_ticket) return;
     // ---- last workgroup: Gauss-Newton tail (reads the rows with sc1 loads: no acquire fence either) ----
 #ifdef FLS_TIMING
     if (threadIdx.x == 0) { st->dbg[0] = t_begin; st->dbg[13] = t_fit; st->dbg[14] = t_red; }
 #endif
     FLS_STAMP(1);
-    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     loam_tail<kFitThreads, true>(st, sm, nullptr, 0, partials, (int)gridDim.x, rot_thr, pos_thr, T44, last_rot, last_pos, it, mb, match_id);
 }
 

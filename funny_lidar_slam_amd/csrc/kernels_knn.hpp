@@ -59,18 +59,28 @@ __device__ __forceinline__ void knn_insert(KnnResult<K>& r, const float dc, cons
 }
 
 template <int K>
-__device__ __forceinline__ void knn_scan_cell(const DevGrid& g, const int cx, const int cy, const int cz, const float qx,
+__device__ __forceinline__ void knn_scan_cell(const CellGridDev& cgd, const int cx, const int cy, const int cz, const float qx,
                                               const float qy, const float qz, KnnResult<K>& r, unsigned long long& hits,
                                               unsigned long long& cand) {
+    const DevGrid& g = cgd.g;
     if (!(abs(cx) < kKeyLimit && abs(cy) < kKeyLimit && abs(cz) < kKeyLimit)) return;
-    const unsigned long long key = pack_key(cx, cy, cz);
-    unsigned h = hash_key(key) & g.mask;
-    HashEntry e = g.table[h];
-    while (e.key != key && e.key != kEmptyKey) {
-        h = (h + 1) & g.mask;
+    HashEntry e{kEmptyKey, 0u, 0u};
+    if (cgd.win.cells) {  // dense cell window (always present for grids built on the device, which have no hash table)
+        const int wx = cx - cgd.win.ox, wy = cy - cgd.win.oy, wz = cz - cgd.win.oz;
+        if (!((unsigned)wx < (unsigned)cgd.win.nx && (unsigned)wy < (unsigned)cgd.win.ny && (unsigned)wz < (unsigned)cgd.win.nz)) return;
+        const uint2 c = cgd.win.cells[(unsigned)((wz * cgd.win.ny + wy) * cgd.win.nx + wx)];
+        if (c.y == 0u) return;
+        e.begin = c.x; e.count = c.y;
+    } else {
+        const unsigned long long key = pack_key(cx, cy, cz);
+        unsigned h = hash_key(key) & g.mask;
         e = g.table[h];
+        while (e.key != key && e.key != kEmptyKey) {
+            h = (h + 1) & g.mask;
+            e = g.table[h];
+        }
+        if (e.key != key) return;
     }
-    if (e.key != key) return;
     hits++;
     cand += e.count;
     const unsigned end = e.begin + e.count;
@@ -101,7 +111,7 @@ __device__ __forceinline__ void knn_grid(const CellGridDev& cg, const float qx, 
                     const int m = max(abs(dx), max(abs(dy), abs(dz)));
                     if (m != rho) continue;
                     probes++;
-                    knn_scan_cell<K>(cg.g, cx + dx, cy + dy, cz + dz, qx, qy, qz, r, hits, cand);
+                    knn_scan_cell<K>(cg, cx + dx, cy + dy, cz + dz, qx, qy, qz, r, hits, cand);
                 }
         const double rad = (double)rho * cg.cell;
         const double rad2 = rad * rad * (1.0 - 1e-5);

@@ -26,13 +26,13 @@ namespace fls {
 constexpr int kVgBlock = 256;
 constexpr int kVgItems = 4;
 constexpr int kVgTile = kVgBlock * kVgItems;  // keys per block of a radix pass
-constexpr int kVgMaxBlocks = 1024;            // n <= 1,048,576
+constexpr int kVgMaxBlocks = 4096;            // n <= 4,194,304 (vg_scan_rows walks its row in chunks of 1024 tiles)
 constexpr int kVgScanBlock = 1024;
 
 struct VgHeader {
     unsigned mn[3], mx[3];  // ordered-uint encoded float bounds of the finite points
     unsigned n_out;
-    unsigned pad;
+    unsigned n_bad;  // points with a non-finite coordinate (vg_minmax)
 };
 
 __device__ __forceinline__ unsigned vg_ord(float f) {
@@ -52,10 +52,10 @@ __device__ __forceinline__ bool vg_finite3(float x, float y, float z) {
 __global__ void __launch_bounds__(kVgBlock)
 vg_minmax(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int n, VgHeader* __restrict__ h) {
     __shared__ unsigned red[kVgBlock / 64][6];
-    unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+    unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u}, bad = 0u;
     for (int i = blockIdx.x * kVgBlock + threadIdx.x; i < n; i += gridDim.x * kVgBlock) {
         const float px = x[i], py = y[i], pz = z[i];
-        if (!vg_finite3(px, py, pz)) continue;
+        if (!vg_finite3(px, py, pz)) { ++bad; continue; }
         const unsigned ox = vg_ord(px), oy = vg_ord(py), oz = vg_ord(pz);
         lo[0] = min(lo[0], ox); hi[0] = max(hi[0], ox);
         lo[1] = min(lo[1], oy); hi[1] = max(hi[1], oy);
@@ -69,6 +69,7 @@ vg_minmax(const float* __restrict__ x, const float* __restrict__ y, const float*
             hi[a] = max(hi[a], (unsigned)__shfl_xor((int)hi[a], o, 64));
         }
     }
+    if (bad) atomicAdd(&h->n_bad, bad);  // non-finite points (rare): the cell-grid build refuses such a cloud like the host build does
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) {
 #pragma unroll
@@ -136,17 +137,29 @@ vg_scan_rows(const unsigned* __restrict__ hist, unsigned* __restrict__ out, cons
     unsigned lower = ((int)threadIdx.x < d && threadIdx.x < 256u) ? dig_tot[threadIdx.x] : 0u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lower += __shfl_xor(lower, o, 64);
-    const unsigned v = (int)threadIdx.x < nb ? hist[d * nb + threadIdx.x] : 0u;
-    unsigned inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-    if (lane == 63) wsum[w] = inc;
     if (lane == 0) bsum[w] = lower;
     __syncthreads();
-    unsigned wbase = 0u, base = 0u;
+    unsigned base = 0u;
 #pragma unroll
-    for (int q = 0; q < kVgScanBlock / 64; ++q) { if (q < w) wbase += wsum[q]; if (q < 4) base += bsum[q]; }
-    if ((int)threadIdx.x < nb) out[d * nb + threadIdx.x] = base + wbase + inc - v;
+    for (int q = 0; q < 4; ++q) base += bsum[q];
+    // rows longer than one workgroup (more than 1024 tiles = 1,048,576 keys: the map-side filters of the LOAM deques) go in
+    // chunks of 1024 tile counters with a carried running total
+    unsigned carry = 0u;
+    for (int b0 = 0; b0 < nb; b0 += kVgScanBlock) {
+        const int idx = b0 + (int)threadIdx.x;
+        const unsigned v = idx < nb ? hist[d * nb + idx] : 0u;
+        unsigned inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        unsigned wbase = 0u, tot = 0u;
+#pragma unroll
+        for (int q = 0; q < kVgScanBlock / 64; ++q) { const unsigned t = wsum[q]; if (q < w) wbase += t; tot += t; }
+        if (idx < nb) out[d * nb + idx] = base + carry + wbase + inc - v;
+        carry += tot;
+        __syncthreads();  // wsum is rewritten by the next chunk
+    }
 }
 
 // one workgroup: exclusive scan of `m` counters, in -> out, in coalesced tiles of 1024 with a carried running total.  The

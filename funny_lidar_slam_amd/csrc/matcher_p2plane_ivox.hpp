@@ -52,6 +52,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     int xcd_chunk = 8;     // workgroups per XCD chunk of the kNN block re-map (FLS_IVOX_XCD_CHUNK)
     bool balanced = true;  // equal candidate ranges per lane through an LDS voxel table (FLS_IVOX_BALANCED=0: whole voxels per lane)
     int variant = 4;       // lanes cooperating on one query in ivox_knn_kernel: 4 or 8 (FLS_IVOX_VARIANT)
+    int ticket_shards = 8; // fan-in of the fit kernel's workgroups: 8 per-XCD counters + a top counter (FLS_TICKET_SHARDS=1: one counter)
     bool prof_fit = false; // FLS_PROF_FIT=1 (diagnosis): the profiling events bracket the fit+solve kernel instead of the kNN kernel
     bool is_first = true;  // the reference's function-static flag (:62), per handle here
     const double filter_size_map_min = 0.5;  // :351
@@ -92,8 +93,9 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         std::memset(upd_mb_host, 0, sizeof(IvoxUpdMailbox));
         FLS_HIP(hipHostGetDevicePointer((void**)&upd_mb_dev, upd_mb_host, 0));
         if (const char* e = std::getenv("FLS_IVOX_XCD_CHUNK")) { const int c = std::atoi(e); if (c >= 1 && c <= 4096) xcd_chunk = c; }
-        d_ticket.reserve(1);
-        FLS_HIP(hipMemsetAsync(d_ticket.p, 0, sizeof(unsigned), stream));
+        d_ticket.reserve(kTicketWords);
+        FLS_HIP(hipMemsetAsync(d_ticket.p, 0, kTicketWords * sizeof(unsigned), stream));
+        if (const char* e = std::getenv("FLS_TICKET_SHARDS")) ticket_shards = std::atoi(e) > 1 ? 8 : 1;
         ivox.resolution = 0.5f;       // InitIVox :53-58
         ivox.inv_resolution = 1.0f / 0.5f;
         ivox.capacity = 1000000;
@@ -430,7 +432,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
 #define FLS_FIT(F)                                                                                                                   \
     hipExtLaunchKernelGGL(p2plane_fit_solve_kernel<F>, dim3(nwg), dim3(kFitThreads), 0, stream, f0, f1, 0, scan.x.p, scan.y.p, scan.z.p, int(n),  \
                        d_state.p, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,     \
-                       d_ticket.p, mb_dev, launch_word(), p.point_to_planar_thres, p.rotation_converge_thres, p.position_converge_thres)
+                       d_ticket.p, mb_dev, launch_word(), p.point_to_planar_thres, p.rotation_converge_thres, p.position_converge_thres, ticket_shards)
             if (first) FLS_FIT(true); else FLS_FIT(false);
 #undef FLS_FIT
         });
@@ -549,7 +551,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     }
     void tune_lane(fls_matcher& l) override {
         auto& q = static_cast<P2PlaneIvoxMatcher&>(l);
-        q.use_dense = use_dense; q.variant = variant; q.balanced = balanced; q.xcd_chunk = xcd_chunk; q.prof_fit = prof_fit;
+        q.use_dense = use_dense; q.variant = variant; q.balanced = balanced; q.xcd_chunk = xcd_chunk; q.prof_fit = prof_fit; q.ticket_shards = ticket_shards;
     }
 
     fls_status fitness(float max_range, float* score) override {

@@ -29,6 +29,9 @@ struct IcpMatcher final : fls_matcher {
     std::vector<PtI> local_map, source;
     SourceFilter src_filter;
     CellGridImage grid;
+    KdMapDevice mapdev;      // cell-grid build on the device (default); deque + map-side VoxelGrid on the device (opt-in)
+    DeviceCloudRing ring;    // the deque's clouds back to back on the device (opt-in path only)
+    size_t local_map_n = 0;  // points of the local map (the host vector is not produced on the device path)
     bool have_map = false;
     bool fused = true;  // FLS_ICP_FUSED=0: separate correspondence and fit launches
     const IcpMatcher* owner = nullptr;  // batch lane: reads the owner's map grid
@@ -50,22 +53,36 @@ struct IcpMatcher final : fls_matcher {
         if (!(p.point_search_thres > 0.0) || !(p.map_cloud_filter_size > 0.f) || !(p.source_cloud_filter_size > 0.f)) return FLS_ERR_INVALID;
         init_common();
         src_filter.init();
+        mapdev.init();
         if (const char* e = std::getenv("FLS_ICP_FUSED")) fused = std::atoi(e) != 0;
         return FLS_OK;
     }
     fls_status add_cloud_impl(const std::vector<PtI>& new_cloud) {  // :165-189
+        const bool dev = mapdev.vg_on_device && mapdev.grid_on_device;
         if (p.is_localization_mode) {
-            local_map = new_cloud;
+            cloud_deque.clear();
+            cloud_deque.push_back(new_cloud);
+            if (dev) { ring.clear(); ring.push_back(new_cloud, stream); }
         } else {
             cloud_deque.push_back(new_cloud);
-            if (cloud_deque.size() > p.local_map_size) cloud_deque.pop_front();
-            local_map.clear();
-            for (const auto& c : cloud_deque) local_map.insert(local_map.end(), c.begin(), c.end());
+            if (dev) ring.push_back(new_cloud, stream);
+            if (cloud_deque.size() > p.local_map_size) { cloud_deque.pop_front(); if (dev) ring.pop_front(); }
         }
-        local_map = voxel_grid(local_map, p.map_cloud_filter_size);  // Q13: always
         // gate-sized cells here: the ICP scan starts far from the map (1-NN often beyond half the gate in the early
         // iterations), the two-stage search would run its second stage for most queries (measured 25 vs 13.5 us / launch)
-        const fls_status rc = grid.build(local_map, cell_for_gate(p.point_search_thres), stream);
+        const float cell = cell_for_gate(p.point_search_thres);
+        // opt-in device path: the deque is resident, VoxelGrid (Q13: always) + grid build never leave the device
+        if (dev && mapdev.filter_and_build(grid, ring, true, p.map_cloud_filter_size, cell, 1, false, local_map_n, stream)) {
+            local_map.clear();
+            have_map = true;
+            return FLS_OK;
+        }
+        local_map.clear();
+        for (const auto& c : cloud_deque) local_map.insert(local_map.end(), c.begin(), c.end());
+        local_map = voxel_grid(local_map, p.map_cloud_filter_size);  // Q13: always
+        ++mapdev.host_filters;
+        local_map_n = local_map.size();
+        const fls_status rc = mapdev.build_from_host(grid, local_map, cell, stream);
         have_map = rc == FLS_OK;
         return rc;
     }
@@ -163,7 +180,10 @@ struct IcpMatcher final : fls_matcher {
     size_t map_size(int slot) const override {
         if (slot == 105) return size_t(src_filter.device_runs);  // source filters run on the device / on the host
         if (slot == 106) return size_t(src_filter.host_runs);
-        return local_map.size();
+        if (slot == 114) return size_t(mapdev.builder.builds);    // cell grids built on the device / map updates filtered on the device /
+        if (slot == 115) return size_t(mapdev.device_filters);    // ... filtered on the host
+        if (slot == 116) return size_t(mapdev.host_filters);
+        return local_map_n;
     }
 };
 
@@ -219,6 +239,9 @@ struct LoamFullMatcher final : fls_matcher {
     std::deque<std::vector<PtI>> corner_deque, planar_deque;
     std::vector<PtI> local_corner, local_planar;
     CellGridImage corner_grid, planar_grid;
+    KdMapDevice mapdev_planar, mapdev_corner;
+    DeviceCloudRing ring_planar, ring_corner;
+    size_t local_planar_n = 0, local_corner_n = 0;
     bool have_map = false;
     const LoamFullMatcher* owner = nullptr;  // batch lane: reads the owner's two map grids
     FeatureDev corner, planar;
@@ -236,25 +259,35 @@ struct LoamFullMatcher final : fls_matcher {
         if (p.local_planar_size == 0 || p.local_corner_size == 0) return FLS_ERR_INVALID;  // CHECK_GT :55-56
         if (!(p.point_search_thres > 0.0) || !(p.corner_voxel_filter_size > 0.f) || !(p.planar_voxel_filter_size > 0.f)) return FLS_ERR_INVALID;
         init_common();
+        mapdev_planar.init();
+        mapdev_corner.init();
         return FLS_OK;
     }
     fls_status add_cloud_impl(const std::vector<PtI>& planar_cloud, const std::vector<PtI>& corner_cloud) {  // :65-104
+        const bool dev = mapdev_planar.vg_on_device && mapdev_planar.grid_on_device;
         corner_deque.push_back(corner_cloud);
         planar_deque.push_back(planar_cloud);
-        if (planar_deque.size() > p.local_planar_size) planar_deque.pop_front();
-        if (corner_deque.size() > p.local_corner_size) corner_deque.pop_front();
-        local_planar.clear();
-        local_corner.clear();
-        for (const auto& c : planar_deque) local_planar.insert(local_planar.end(), c.begin(), c.end());
-        for (const auto& c : corner_deque) local_corner.insert(local_corner.end(), c.begin(), c.end());
-        if (planar_deque.size() > 5) local_planar = voxel_grid(local_planar, p.planar_voxel_filter_size);
-        if (corner_deque.size() > 5) local_corner = voxel_grid(local_corner, p.corner_voxel_filter_size);
+        if (dev) { ring_corner.push_back(corner_cloud, stream); ring_planar.push_back(planar_cloud, stream); }
+        if (planar_deque.size() > p.local_planar_size) { planar_deque.pop_front(); if (dev) ring_planar.pop_front(); }
+        if (corner_deque.size() > p.local_corner_size) { corner_deque.pop_front(); if (dev) ring_corner.pop_front(); }
         // FLS_GRID27=1: gate-sized cells + the one-stage 27-cell kernel; default: half-gate cells + the two-stage kernel
         const bool g27 = grid27;
         const float cs = (g27 ? 1.0f : 0.5f) * cell_for_gate(p.point_search_thres);
-        fls_status rc = planar_grid.build(local_planar, cs, stream, g27 ? 1 : kGridRings, g27);
+        const int rings = g27 ? 1 : kGridRings;
+        // one feature class: [VoxelGrid of] the concatenated deque (the filter only once the deque holds more than 5 frames, :92-100)
+        auto rebuild = [&](std::deque<std::vector<PtI>>& dq, DeviceCloudRing& ring, KdMapDevice& md, CellGridImage& grid, std::vector<PtI>& local, size_t& n_local,
+                           float leaf) -> fls_status {
+            const bool filter = dq.size() > 5;
+            if (dev && md.filter_and_build(grid, ring, filter, leaf, cs, rings, g27, n_local, stream)) { local.clear(); return FLS_OK; }
+            local.clear();
+            for (const auto& c : dq) local.insert(local.end(), c.begin(), c.end());
+            if (filter) { local = voxel_grid(local, leaf); ++md.host_filters; }
+            n_local = local.size();
+            return md.build_from_host(grid, local, cs, stream, rings, g27);
+        };
+        fls_status rc = rebuild(planar_deque, ring_planar, mapdev_planar, planar_grid, local_planar, local_planar_n, p.planar_voxel_filter_size);
         if (rc != FLS_OK) return rc;
-        rc = corner_grid.build(local_corner, cs, stream, g27 ? 1 : kGridRings, g27);
+        rc = rebuild(corner_deque, ring_corner, mapdev_corner, corner_grid, local_corner, local_corner_n, p.corner_voxel_filter_size);
         have_map = rc == FLS_OK;
         return rc;
     }
@@ -331,7 +364,12 @@ struct LoamFullMatcher final : fls_matcher {
     int correspondences(int slot, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) override {
         return (slot == 1 ? corner : planar).fetch(stream, ids, cnt, valid, cap);
     }
-    size_t map_size(int slot) const override { return slot == 1 ? local_corner.size() : local_planar.size(); }
+    size_t map_size(int slot) const override {
+        if (slot == 114) return size_t(mapdev_planar.builder.builds + mapdev_corner.builder.builds);
+        if (slot == 115) return size_t(mapdev_planar.device_filters + mapdev_corner.device_filters);
+        if (slot == 116) return size_t(mapdev_planar.host_filters + mapdev_corner.host_filters);
+        return slot == 1 ? local_corner_n : local_planar_n;
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -339,6 +377,9 @@ struct P2PlaneKdMatcher final : fls_matcher {
     std::deque<std::vector<PtI>> cloud_deque;
     std::vector<PtI> local_map;
     CellGridImage grid;
+    KdMapDevice mapdev;
+    DeviceCloudRing ring;
+    size_t local_map_n = 0;
     bool have_map = false;
     const P2PlaneKdMatcher* owner = nullptr;  // batch lane: reads the owner's map grid
     FeatureDev planar;
@@ -352,20 +393,33 @@ struct P2PlaneKdMatcher final : fls_matcher {
             return FLS_ERR_INVALID;  // CHECK_NE block loam_point_to_plane_kdtree.h:43-50
         if (!(p.map_cloud_filter_size > 0.f)) return FLS_ERR_INVALID;
         init_common();
+        mapdev.init();
         return FLS_OK;
     }
     fls_status add_cloud_impl(const std::vector<PtI>& planar_cloud) {  // :56-79
+        const bool dev = mapdev.vg_on_device && mapdev.grid_on_device;
         if (p.is_localization_mode) {
-            local_map = planar_cloud;
+            cloud_deque.clear();
+            cloud_deque.push_back(planar_cloud);
+            if (dev) { ring.clear(); ring.push_back(planar_cloud, stream); }
         } else {
             cloud_deque.push_back(planar_cloud);
-            if (cloud_deque.size() > p.local_map_size) cloud_deque.pop_front();
-            local_map.clear();
-            for (const auto& c : cloud_deque) local_map.insert(local_map.end(), c.begin(), c.end());
+            if (dev) ring.push_back(planar_cloud, stream);
+            if (cloud_deque.size() > p.local_map_size) { cloud_deque.pop_front(); if (dev) ring.pop_front(); }
         }
-        local_map = voxel_grid(local_map, p.map_cloud_filter_size);
         // un-gated 5-NN: ring search with a cell of two map leaves (>= 1 point per leaf after VoxelGrid)
-        const fls_status rc = grid.build(local_map, std::max(2.0f * p.map_cloud_filter_size, 0.5f), stream);
+        const float cell = std::max(2.0f * p.map_cloud_filter_size, 0.5f);
+        if (dev && mapdev.filter_and_build(grid, ring, true, p.map_cloud_filter_size, cell, 1, false, local_map_n, stream)) {
+            local_map.clear();
+            have_map = true;
+            return FLS_OK;
+        }
+        local_map.clear();
+        for (const auto& c : cloud_deque) local_map.insert(local_map.end(), c.begin(), c.end());
+        local_map = voxel_grid(local_map, p.map_cloud_filter_size);
+        ++mapdev.host_filters;
+        local_map_n = local_map.size();
+        const fls_status rc = mapdev.build_from_host(grid, local_map, cell, stream);
         have_map = rc == FLS_OK;
         return rc;
     }
@@ -428,7 +482,12 @@ struct P2PlaneKdMatcher final : fls_matcher {
         return fitness_score_device(*this, grid, planar.scan, final_T, max_range, score);
     }
     int correspondences(int, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) override { return planar.fetch(stream, ids, cnt, valid, cap); }
-    size_t map_size(int) const override { return local_map.size(); }
+    size_t map_size(int slot) const override {
+        if (slot == 114) return size_t(mapdev.builder.builds);
+        if (slot == 115) return size_t(mapdev.device_filters);
+        if (slot == 116) return size_t(mapdev.host_filters);
+        return local_map_n;
+    }
 };
 
 }  // namespace fls

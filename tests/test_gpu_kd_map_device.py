@@ -1,0 +1,91 @@
+"""Map maintenance of the kd-tree kinds on the device (VERDICT r2 missing #2):
+
+  * the cell-grid build (the stand-in for KdTreeFLANN::setInputCloud) -- a total-order sort of (cell, map index), so the device
+    build is EXACT and the default: every parity / replay test of the suite now runs on device-built grids; here the host build
+    (FLS_DEVICE_GRID_BUILD=0) is replayed next to it and must give identical ids, flags, poses (bit for bit);
+  * opt-in (FLS_DEVICE_VOXELGRID=1): the deque of map clouds resident on the device + the map-side pcl::VoxelGrid
+    (icp_optimized.h:187, loam_full_kdtree.h:92-100, loam_point_to_plane_kdtree.h:72-77) on the device.  Same contract as the
+    device source filter (kernels_voxelgrid.hpp): leaves, order and every integer exact, centroids summed in ascending point index
+    -> the replay must agree with the default path on every return value, iteration count, n_valid, keyframe decision and map
+    size, poses within 1e-6 m / rad.
+"""
+import numpy as np
+import pytest
+
+from funny_lidar_slam_amd import _lib, registration as reg, synth
+from tests import replay, util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(built):
+    assert _lib.device_count() >= 1, "gpu tests need an MI355X (gfx950): the HIP path has no CPU fallback"
+
+
+def _run(name, env, monkeypatch, n_frames=None):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = replay.make_replay(name, n_frames=n_frames, yaw_long_deg=9.0) if n_frames else replay.make_replay(name)
+    mode, y = r["mode"], r["y"]
+    m = reg.make_matcher(mode, y)
+    m.AddCloudToLocalMap(r["init_clouds"])
+    slots = (0, 1) if mode == "LoamFull_KdTree" else (0,)
+    out, Tp = [], np.eye(4)
+    for f in r["frames"]:
+        T = Tp @ f["guess_step"]
+        ok = m.Match(util.cluster_for(mode, f["scan"], f["corner"]), T, update_map=True)
+        Tp = T
+        out.append(dict(ok=ok, T=T.copy(), it=int(m.stats.iterations), nv=int(m.stats.n_valid), nvc=int(m.stats.n_valid_corner), upd=int(m.stats.map_updated),
+                        sizes=tuple(m.map_size(s) for s in slots), corr=[m.correspondences(s) for s in slots]))
+    counters = (m.map_size(114), m.map_size(115), m.map_size(116))
+    m.close()
+    for k in env:
+        monkeypatch.delenv(k)
+    return out, counters
+
+
+@pytest.mark.parametrize("name", ["icp", "loam"])
+def test_device_grid_build_equals_host_grid_build(name, monkeypatch):
+    dev, cd = _run(name, {"FLS_DEVICE_GRID_BUILD": "1"}, monkeypatch)
+    host, ch = _run(name, {"FLS_DEVICE_GRID_BUILD": "0"}, monkeypatch)
+    assert cd[0] > 0 and ch[0] == 0, (cd, ch)  # which build ran
+    for k, (a, b) in enumerate(zip(dev, host)):
+        assert (a["ok"], a["it"], a["nv"], a["nvc"], a["upd"], a["sizes"]) == (b["ok"], b["it"], b["nv"], b["nvc"], b["upd"], b["sizes"]), (name, k)
+        assert np.array_equal(a["T"], b["T"]), (name, k)  # the same arithmetic on the same neighbours: bit-identical poses
+        for ca, cb in zip(a["corr"], b["corr"]):
+            for u, v in zip(ca, cb):
+                assert np.array_equal(u, v), (name, k)
+
+
+@pytest.mark.parametrize("name,n_frames", [("icp", None), ("loam", None), ("icp", 40)])
+def test_device_map_filter_replay(name, n_frames, monkeypatch):
+    """deque + map-side VoxelGrid + grid build on the device (opt-in) vs the default (exact host filter + device grid build)"""
+    dev, cd = _run(name, {"FLS_DEVICE_VOXELGRID": "1"}, monkeypatch, n_frames)
+    host, ch = _run(name, {"FLS_DEVICE_VOXELGRID": "0"}, monkeypatch, n_frames)
+    assert cd[1] > 0 and ch[1] == 0 and ch[2] > 0, (cd, ch)  # map filters on the device / on the host
+    worst = 0.0
+    for k, (a, b) in enumerate(zip(dev, host)):
+        assert (a["ok"], a["it"], a["nv"], a["nvc"], a["upd"], a["sizes"]) == (b["ok"], b["it"], b["nv"], b["nvc"], b["upd"], b["sizes"]), (name, k, a["sizes"], b["sizes"])
+        dt, dr = synth.pose_error(a["T"], b["T"])
+        worst = max(worst, dt, dr)
+        assert dt < 1e-6 and dr < 1e-6, (name, k, dt, dr)
+    print(f"{name}: {len(dev)} frames, device map filter vs exact host filter: worst pose difference {worst:.2e}; device filters {cd[1]}, host filters {cd[2]}")
+
+
+def test_kd_localization_kind_on_device_built_grid():
+    """LoamPointToPlaneKdtree (un-gated ring search + the window-aware fitness kernel) on a device-built grid vs the oracle"""
+    cfg = synth.make_config(1, scale=0.1)
+    y = reg.YAML_NCLT_LOC_KDTREE
+    m = reg.make_matcher("PointToPlane_KdTree", y, is_localization_mode=True)
+    o = util.oracle_for("PointToPlane_KdTree", y, True)
+    m.AddCloudToLocalMap([cfg["map"]])
+    o.AddCloudToLocalMap(cfg["map"])
+    assert m.map_size(114) == 1
+    T = np.eye(4)
+    ok = m.Match(reg.PointcloudCluster(planar_cloud_=cfg["scan"]), T, update_map=False)
+    ok_ref, T_ref = o.Match(cfg["scan"], np.eye(4), update_map=False)
+    util.assert_same_registration(m, o, ok, T, ok_ref, T_ref, sets_only_tail=False)
+    assert m.GetFitnessScore(2.0) == pytest.approx(o.GetFitnessScore(2.0), rel=1e-6)
+    m.close()
+    o.close()
