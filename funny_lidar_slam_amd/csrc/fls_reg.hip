@@ -253,6 +253,20 @@ fls_status fls_debug_voxel_grid(int device_id, const float* pts, size_t n, int s
     });
 }
 
+fls_status fls_voxel_grid_cloud(int device_id, fls_voxelgrid_mode mode, const float* pts, size_t n, int stride, float leaf, float* out, size_t cap,
+                                size_t* n_out) {
+    if (mode == FLS_VOXELGRID_DEVICE) return fls_debug_voxel_grid(device_id, pts, n, stride, leaf, out, cap, n_out);
+    if (mode != FLS_VOXELGRID_EXACT || (!pts && n) || !n_out || stride < 3 || !(leaf > 0.f) || (cap && !out)) return FLS_ERR_INVALID;
+    *n_out = 0;
+    return guarded([&]() -> fls_status {
+        const std::vector<PtI> c = voxel_grid_strided(pts, n, stride, leaf);  // host_maps.hpp: the exact filter (pooled introsort order)
+        *n_out = c.size();
+        if (c.size() > cap) return FLS_ERR_INVALID;
+        if (!c.empty()) std::memcpy(out, c.data(), c.size() * sizeof(PtI));
+        return FLS_OK;
+    });
+}
+
 fls_status fls_get_traffic_counters(fls_handle h, uint64_t* probes, uint64_t* hit_voxels, uint64_t* cand_points) {
     if (!h) return FLS_ERR_INVALID;
     if (probes) *probes = h->last_tc.probes;

@@ -328,6 +328,28 @@ class LoamPointToPlaneKdtree(RegistrationInterface):
                                 is_localization_mode=int(is_localization_mode)), device_id)
 
 
+def VoxelGridCloud(cloud: np.ndarray, voxel_size: float = 0.1, on_device: bool = False, device_id: int = 0) -> np.ndarray:
+    """include/common/pointcloud_utility.h:216-271 (pcl::VoxelGrid<PointXYZI>::filter): the stand-alone filter of the preprocessing
+    thread (preprocessing.cpp:224-237) and of loop closure.  (n, 3|4|8) float32 -> (m, 4) {x, y, z, intensity}.
+    on_device = False: the reference's arithmetic bit for bit on the host worker pool (needs no GPU);
+    on_device = True:  the device filter (contract: csrc/kernels_voxelgrid.hpp); falls back to the exact filter when it declines."""
+    a, ptr, n, stride = _cloud(cloud)
+    out = np.zeros((max(n, 1), 4), np.float32)
+    n_out = C.c_size_t(0)
+    fp = C.POINTER(C.c_float)
+    L = _lib.lib()
+    rc = _lib.FLS_ERR_STATE
+    if on_device:
+        rc = L.fls_voxel_grid_cloud(device_id, 1, ptr, n, stride, np.float32(voxel_size), out.ctypes.data_as(fp), out.shape[0], C.byref(n_out))
+        if rc not in (_lib.FLS_OK, _lib.FLS_ERR_STATE):
+            raise FlsError(rc, "fls_voxel_grid_cloud(device)")
+    if rc != _lib.FLS_OK:
+        rc = L.fls_voxel_grid_cloud(device_id, 0, ptr, n, stride, np.float32(voxel_size), out.ctypes.data_as(fp), out.shape[0], C.byref(n_out))
+        if rc != _lib.FLS_OK:
+            raise FlsError(rc, "fls_voxel_grid_cloud")
+    return out[: n_out.value].copy()
+
+
 def make_matcher(mode: str, cfg: dict, is_localization_mode: bool = False, device_id: int = 0) -> RegistrationInterface:
     """FrontEnd::InitMatcher / Localization::InitMatcher (src/slam/frontend.cpp:30-88, localization.cpp:43-92):
     choose the implementation from the YAML mode string, arguments from the `registration` YAML block."""

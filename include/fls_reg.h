@@ -153,6 +153,21 @@ fls_status fls_match_batch(fls_handle h, size_t n_jobs, const float* const* src0
 size_t fls_map_export(fls_handle h, void* blob, size_t cap_bytes);
 fls_status fls_map_import(fls_handle h, const void* blob, size_t n_bytes);
 
+/* ---- VoxelGridCloud  (include/common/pointcloud_utility.h:216-271 = pcl::VoxelGrid<PointXYZI>::filter) -------------------------
+ * The stand-alone filter the pipeline applies OUTSIDE the matchers: the planar / corner voxel filters of the preprocessing
+ * thread that feed Match (src/slam/preprocessing.cpp:224-237) and the sub-map / multi-resolution filters of loop closure
+ * (src/slam/loop_closure.cpp:215,251-252,258-259).  pts: n x stride floats (intensity as in fls_match); out: cap x 4 floats
+ * {x, y, z, intensity}, one centroid per occupied leaf in ascending leaf index; *n_out = number of leaves (set even when out
+ * is too small -> FLS_ERR_INVALID).
+ *   FLS_VOXELGRID_EXACT   the reference's arithmetic bit for bit (leaf sums in libstdc++'s std::sort order) on the host worker pool;
+ *                         needs no device.  PCL's "leaf size too small" case copies the input, as PCL does.
+ *   FLS_VOXELGRID_DEVICE  on the GPU: leaves, order and integers exact, a leaf's float sum in ascending point index (contract:
+ *                         csrc/kernels_voxelgrid.hpp).  FLS_ERR_STATE when the device path declines (empty / no finite point /
+ *                         the "leaf size too small" case / n > 4,194,304): call again with FLS_VOXELGRID_EXACT.            */
+typedef enum fls_voxelgrid_mode { FLS_VOXELGRID_EXACT = 0, FLS_VOXELGRID_DEVICE = 1 } fls_voxelgrid_mode;
+fls_status fls_voxel_grid_cloud(int device_id, fls_voxelgrid_mode mode, const float* pts, size_t n, int stride_floats, float leaf_size,
+                                float* out, size_t cap_points, size_t* n_out);
+
 /* ---- RegistrationInterface::GetFitnessScore  (registration_interface.h:19) ---------------------- */
 fls_status fls_get_fitness_score(fls_handle h, float max_range, float* score);
 
@@ -192,10 +207,10 @@ fls_status fls_get_debug_stamps(fls_handle h, int64_t out[16]);
  * against the oracle's restatement, rank-deficient systems included.                                                      */
 fls_status fls_debug_fullpiv_qr6(int device_id, const double* H, const double* g, int n, double* x);
 
-/* test hook: the device VoxelGrid (pcl::VoxelGrid<PointXYZI>::filter semantics; opt-in source filter of the ICP / NDT kinds,
+/* test hook (= fls_voxel_grid_cloud(..., FLS_VOXELGRID_DEVICE, ...)): the device VoxelGrid (pcl::VoxelGrid<PointXYZI>::filter semantics; opt-in source filter of the ICP / NDT kinds,
  * FLS_DEVICE_VOXELGRID=1) on a caller-supplied cloud: pts (n x stride floats, intensity as in fls_match) -> out (cap x 4
  * floats x, y, z, intensity), *n_out = number of leaves.  FLS_ERR_STATE when the device path declines (empty / no finite
- * point / PCL's "leaf size too small" case / n > 1,048,576: the matchers then run the host filter), FLS_ERR_INVALID when
+ * point / PCL's "leaf size too small" case / n > 4,194,304: the matchers then run the host filter), FLS_ERR_INVALID when
  * out is too small (*n_out is still set).  Contract: csrc/kernels_voxelgrid.hpp; tests/test_gpu_voxelgrid.py.          */
 fls_status fls_debug_voxel_grid(int device_id, const float* pts, size_t n, int stride, float leaf, float* out, size_t cap, size_t* n_out);
 

@@ -174,3 +174,25 @@ def test_cpp_features_adapter_runs_on_gpu(built, tmp_path):
     for name in ("ordered", "corner", "planar"):
         got = np.fromfile(outp + "." + name, dtype=np.float32).reshape(-1, 4)
         assert np.array_equal(got, f.get(name)), name
+
+
+def test_voxel_grid_cloud_exact_mode_equals_the_reference_filter_without_a_gpu(built):
+    """fls_voxel_grid_cloud(FLS_VOXELGRID_EXACT) -- the VoxelGridCloud / preprocessing filter entry point (pointcloud_utility.h:216-271,
+    preprocessing.cpp:224-237) -- is host code and must equal the oracle's pcl::VoxelGrid restatement (itself pinned by the compiled
+    reference's replays) bit for bit: small cloud (sequential path), 120k points (worker pool), stride 8 (PCL rows), the
+    "leaf size too small" case (input copied), non-finite points dropped."""
+    import numpy as np
+    from funny_lidar_slam_amd import registration as reg
+    rng = np.random.default_rng(11)
+    for n, leaf in ((3000, 0.4), (120000, 0.5), (120000, 0.2)):
+        c = np.concatenate([rng.uniform(-40, 40, (n, 2)), rng.uniform(-2, 6, (n, 1)), rng.uniform(0, 255, (n, 1))], axis=1).astype(np.float32)
+        c[::97, 0] = np.nan
+        ref = O.voxel_grid(c, leaf)
+        got = reg.VoxelGridCloud(c, leaf)
+        assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (n, leaf)
+        pcl = np.zeros((n, 8), np.float32)
+        pcl[:, :3], pcl[:, 4] = c[:, :3], c[:, 3]
+        assert np.array_equal(reg.VoxelGridCloud(pcl, leaf).view(np.uint32), ref.view(np.uint32))
+    far = np.array([[0, 0, 0, 1], [1e6, 1e6, 1e6, 2]], np.float32)
+    assert np.array_equal(reg.VoxelGridCloud(far, 0.1), np.asarray(O.voxel_grid(far, 0.1)))
+    assert reg.VoxelGridCloud(np.zeros((0, 4), np.float32), 0.5).shape == (0, 4)

@@ -69,7 +69,8 @@ def test_device_map_filter_replay(name, n_frames, monkeypatch):
         assert (a["ok"], a["it"], a["nv"], a["nvc"], a["upd"], a["sizes"]) == (b["ok"], b["it"], b["nv"], b["nvc"], b["upd"], b["sizes"]), (name, k, a["sizes"], b["sizes"])
         dt, dr = synth.pose_error(a["T"], b["T"])
         worst = max(worst, dt, dr)
-        assert dt < 1e-6 and dr < 1e-6, (name, k, dt, dr)
+        tol = 1e-6 if n_frames is None else 1e-5  # (each handle follows its own pose chain: the centroid rounding noise accumulates in the map)
+        assert dt < tol and dr < tol, (name, k, dt, dr)
     print(f"{name}: {len(dev)} frames, device map filter vs exact host filter: worst pose difference {worst:.2e}; device filters {cd[1]}, host filters {cd[2]}")
 
 

@@ -161,3 +161,17 @@ def test_match_with_device_source_filter(mode, y, cid, loc, monkeypatch):
     assert h[6] == d[6]  # map size after the updates
     if mode == "IncrementalNDT":  # with the device filter the whole update chain (transform, second VoxelGrid, UpdateVoxel) stays on the device
         assert h[9] == 0 and d[9] == 2, (h[9], d[9])
+
+
+def test_voxel_grid_cloud_entry_point_device_mode():
+    """fls_voxel_grid_cloud(FLS_VOXELGRID_DEVICE) = the preprocessing / loop-closure filter entry point on the GPU: same output as the
+    test hook, the contract against the exact mode, and the documented fall-back when the device path declines."""
+    cfg = synth.make_config(1, scale=0.3)
+    cloud = np.concatenate([cfg["scan"], np.linspace(0, 1, len(cfg["scan"]), dtype=np.float32)[:, None]], axis=1)
+    dev = reg.VoxelGridCloud(cloud, 0.5, on_device=True)
+    exact = reg.VoxelGridCloud(cloud, 0.5, on_device=False)
+    rc, hook = device_voxel_grid(cloud, 0.5)
+    assert rc == 0 and np.array_equal(dev.view(np.uint32), hook.view(np.uint32))
+    assert dev.shape == exact.shape and np.allclose(dev, exact, rtol=0, atol=2e-4)
+    far = np.array([[0, 0, 0, 1], [1e6, 1e6, 1e6, 2]], np.float32)  # "leaf size too small": the device declines, the exact filter copies the input
+    assert np.array_equal(reg.VoxelGridCloud(far, 0.1, on_device=True), far)
