@@ -123,6 +123,25 @@ void flo_feat_set_sort_mode(void* h, int mode);
 int flo_col_index(float x, float y, float h_res, int cols);
 float flo_fast_atan2f(float y, float x);
 
+/* ---- loop-closure matcher (src/slam/loop_closure.cpp:233-267: 4-resolution pcl NDT + pcl GICP + getFitnessScore): flo_loop.h ---- */
+typedef struct flo_loop_stats {
+    int32_t ndt_iterations[4], ndt_evaluations[4], ndt_source_points[4], ndt_target_leaves[4];
+    int32_t gicp_iterations, gicp_inner_iterations, gicp_evaluations, gicp_correspondences, gicp_source_points, gicp_target_points, gicp_failed, reserved;
+    double ndt_score[4];
+    double T_after_ndt[16];
+} flo_loop_stats;
+float flo_loop_match(const float* src, size_t ns, const float* tgt, size_t nt, int stride_floats, double T_colmajor[16], flo_loop_stats* st);
+/* pieces: NDT score / gradient / Hessian at pose vector p (x, y, z, rx, ry, rz) for the clouds AS GIVEN (leaf Gaussians at `resolution`) */
+int flo_ndt_derivatives(const float* src, size_t ns, const float* tgt, size_t nt, int stride_floats, float resolution, const double p[6], double* score,
+                        double grad[6], double hess[36]);
+size_t flo_ndt_leaves(const float* tgt, size_t nt, int stride_floats, float resolution, int32_t* idx, int32_t* nr, double* mean3, double* icov9,
+                      float* centroid3, size_t cap);
+void flo_gicp_covariances(const float* c, size_t n, int stride_floats, int k, double eps, double* out9);
+/* correspondences + Mahalanobis matrices for `guess` (transformation_ = identity), then f and g of the BFGS functor at x */
+int flo_gicp_fdf(const float* src, size_t ns, const float* tgt, size_t nt, int stride_floats, const double guess[16], double corr_dist, const double x[6],
+                 double* f, double g[6], int32_t* n_corr);
+void flo_jacobi_svd_solve6(const double A[36], const double b[6], double x[6]);
+
 /* stand-alone pieces for unit tests */
 size_t flo_voxel_grid(const float* in, size_t n, int stride_floats, float leaf, float* out_xyzi /* n x 4 */);
 void flo_so3_exp(const double v[3], double R_colmajor[9]);

@@ -26,6 +26,7 @@
 #include "flo_api.h"
 #include "flo_common.h"
 #include "flo_features.h"
+#include "flo_loop.h"
 #include <deque>
 #include <set>
 #include <memory>
@@ -1114,6 +1115,64 @@ size_t flo_feat_get(void* h, int what, void* out, size_t cap) {
         default: return 0;
     }
 }
+
+float flo_loop_match(const float* src, size_t ns, const float* tgt, size_t nt, int stride, double T[16], flo_loop_stats* st) {
+    static_assert(sizeof(flo_loop_stats) == sizeof(loop::LoopStats), "flo_loop_stats mirrors loop::LoopStats");
+    loop::LoopStats ls{};
+    const float f = loop::loop_match(make_cloud(src, ns, stride), make_cloud(tgt, nt, stride), T, &ls);
+    if (st) std::memcpy(st, &ls, sizeof(ls));
+    return f;
+}
+int flo_ndt_derivatives(const float* src, size_t ns, const float* tgt, size_t nt, int stride, float resolution, const double p[6], double* score,
+                        double grad[6], double hess[36]) {
+    loop::Ndt ndt;
+    ndt.resolution = resolution;
+    const Cloud s = make_cloud(src, ns, stride), t = make_cloud(tgt, nt, stride);
+    ndt.set_target(t);
+    if (!ndt.cells.ok) return -1;
+    ndt.source = &s;
+    const double c1 = 10.0 * (1.0 - ndt.outlier_ratio), c2 = ndt.outlier_ratio / std::pow(double(resolution), 3), d3 = -std::log(c2);
+    ndt.gauss_d1 = -std::log(c1 + c2) - d3;
+    ndt.gauss_d2 = -2.0 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / ndt.gauss_d1);
+    *score = ndt.derivatives(grad, hess, loop::pose_from_p(p), p, true);
+    return 0;
+}
+size_t flo_ndt_leaves(const float* tgt, size_t nt, int stride, float resolution, int32_t* idx, int32_t* nr, double* mean3, double* icov9, float* centroid3,
+                      size_t cap) {
+    loop::TargetCells tc;
+    tc.build(make_cloud(tgt, nt, stride), resolution);
+    size_t k = 0;
+    for (int li : tc.searchable) {
+        if (k < cap) {
+            const loop::Leaf& l = tc.leaves[li];
+            idx[k] = li; nr[k] = l.nr;
+            for (int a = 0; a < 3; ++a) { mean3[3 * k + a] = l.mean[a]; centroid3[3 * k + a] = l.centroid[a]; }
+            for (int a = 0; a < 9; ++a) icov9[9 * k + a] = l.icov[a];
+        }
+        ++k;
+    }
+    return k;
+}
+void flo_gicp_covariances(const float* c, size_t n, int stride, int k, double eps, double* out9) {
+    std::vector<double> out;
+    loop::Gicp::covariances(make_cloud(c, n, stride), k, eps, out);
+    std::memcpy(out9, out.data(), out.size() * sizeof(double));
+}
+int flo_gicp_fdf(const float* src, size_t ns, const float* tgt, size_t nt, int stride, const double guess[16], double corr_dist, const double x[6], double* f,
+                 double g[6], int32_t* n_corr) {
+    loop::Gicp gi;
+    gi.corr_dist_threshold = corr_dist;
+    gi.max_iterations = 0;  // build the correspondences of the first outer iteration only: align() stops after estimate()
+    const Cloud s = make_cloud(src, ns, stride), t = make_cloud(tgt, nt, stride);
+    if (s.size() < size_t(gi.k_correspondences) || t.size() < size_t(gi.k_correspondences)) return -1;
+    gi.max_inner_iterations = 0;
+    gi.align(s, t, loop::m4f_from_d(guess));
+    if (gi.idx_src.size() < 4) return -1;
+    *n_corr = int32_t(gi.idx_src.size());
+    gi.fdf(x, f, g);
+    return 0;
+}
+void flo_jacobi_svd_solve6(const double A[36], const double b[6], double x[6]) { loop::jacobi_svd_solve<6>(A, b, x); }
 
 size_t flo_voxel_grid(const float* in, size_t n, int stride, float leaf, float* out) {
     const Cloud o = voxel_grid(make_cloud(in, n, stride), leaf);

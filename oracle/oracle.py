@@ -182,6 +182,16 @@ def lib():
         L.flo_map_dump.argtypes = [C.c_void_p, C.c_int, fp, C.c_size_t]
         L.flo_ndt_dump.restype = C.c_size_t
         L.flo_ndt_dump.argtypes = [C.c_void_p, ip, dp, dp, bp, ip, C.c_size_t]
+        L.flo_loop_match.restype = C.c_float
+        L.flo_loop_match.argtypes = [fp, C.c_size_t, fp, C.c_size_t, C.c_int, dp, C.POINTER(LoopStats)]
+        L.flo_ndt_derivatives.argtypes = [fp, C.c_size_t, fp, C.c_size_t, C.c_int, C.c_float, dp, dp, dp, dp]
+        L.flo_ndt_leaves.restype = C.c_size_t
+        L.flo_ndt_leaves.argtypes = [fp, C.c_size_t, C.c_int, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, fp, C.c_size_t]
+        L.flo_gicp_covariances.restype = None
+        L.flo_gicp_covariances.argtypes = [fp, C.c_size_t, C.c_int, C.c_int, C.c_double, dp]
+        L.flo_gicp_fdf.argtypes = [fp, C.c_size_t, fp, C.c_size_t, C.c_int, dp, C.c_double, dp, dp, dp, C.POINTER(C.c_int32)]
+        L.flo_jacobi_svd_solve6.restype = None
+        L.flo_jacobi_svd_solve6.argtypes = [dp, dp, dp]
         L.flo_voxel_grid.restype = C.c_size_t
         L.flo_voxel_grid.argtypes = [fp, C.c_size_t, C.c_int, C.c_float, fp]
         L.flo_so3_exp.argtypes = [dp, dp]
@@ -393,6 +403,77 @@ def svd3(A):
     lib().flo_svd3(pa, U.ctypes.data_as(C.POINTER(C.c_double)), S.ctypes.data_as(C.POINTER(C.c_double)),
                    V.ctypes.data_as(C.POINTER(C.c_double)))
     return U.reshape(3, 3, order="F"), S, V.reshape(3, 3, order="F")
+
+
+class LoopStats(C.Structure):
+    """flo_loop_stats (flo_api.h) == fls_loop_stats (include/fls_reg.h)"""
+    _fields_ = [("ndt_iterations", C.c_int32 * 4), ("ndt_evaluations", C.c_int32 * 4), ("ndt_source_points", C.c_int32 * 4), ("ndt_target_leaves", C.c_int32 * 4),
+                ("gicp_iterations", C.c_int32), ("gicp_inner_iterations", C.c_int32), ("gicp_evaluations", C.c_int32), ("gicp_correspondences", C.c_int32),
+                ("gicp_source_points", C.c_int32), ("gicp_target_points", C.c_int32), ("gicp_failed", C.c_int32), ("reserved", C.c_int32),
+                ("ndt_score", C.c_double * 4), ("T_after_ndt", C.c_double * 16)]
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def loop_match(source, target, T_init):
+    """LoopClosure::Match (loop_closure.cpp:233-267): returns (fitness, T (4,4), LoopStats)"""
+    a, pa, na, sa = _cloud(source)
+    b, pb, nb, sb = _cloud(target)
+    assert sa == sb
+    T = np.ascontiguousarray(np.asarray(T_init, np.float64).reshape(4, 4).T).reshape(-1).copy()
+    st = LoopStats()
+    f = lib().flo_loop_match(pa, na, pb, nb, sa, _dp(T), C.byref(st))
+    return float(f), T.reshape(4, 4).T.copy(), st
+
+
+def ndt_derivatives(source, target, resolution, p):
+    a, pa, na, sa = _cloud(source)
+    b, pb, nb, sb = _cloud(target)
+    p = np.ascontiguousarray(p, np.float64)
+    score = C.c_double()
+    g = np.zeros(6); H = np.zeros(36)
+    rc = lib().flo_ndt_derivatives(pa, na, pb, nb, sa, resolution, _dp(p), C.byref(score), _dp(g), _dp(H))
+    if rc != 0:
+        raise RuntimeError("flo_ndt_derivatives: no leaf with >= 6 points")
+    return score.value, g, H.reshape(6, 6, order="F")
+
+
+def ndt_leaves(target, resolution):
+    b, pb, nb, sb = _cloud(target)
+    cap = max(nb, 1)
+    idx = np.zeros(cap, np.int32); nr = np.zeros(cap, np.int32); mean = np.zeros((cap, 3)); icov = np.zeros((cap, 9)); cen = np.zeros((cap, 3), np.float32)
+    n = lib().flo_ndt_leaves(pb, nb, sb, resolution, idx.ctypes.data_as(C.POINTER(C.c_int32)), nr.ctypes.data_as(C.POINTER(C.c_int32)), _dp(mean), _dp(icov),
+                             cen.ctypes.data_as(C.POINTER(C.c_float)), cap)
+    return idx[:n], nr[:n], mean[:n], icov[:n].reshape(n, 3, 3).transpose(0, 2, 1), cen[:n]
+
+
+def gicp_covariances(cloud, k=20, eps=0.001):
+    a, pa, na, sa = _cloud(cloud)
+    out = np.zeros((na, 9))
+    lib().flo_gicp_covariances(pa, na, sa, k, eps, _dp(out))
+    return out.reshape(na, 3, 3).transpose(0, 2, 1)
+
+
+def gicp_fdf(source, target, guess, corr_dist, x):
+    a, pa, na, sa = _cloud(source)
+    b, pb, nb, sb = _cloud(target)
+    G = np.ascontiguousarray(np.asarray(guess, np.float64).reshape(4, 4).T).reshape(-1).copy()
+    x = np.ascontiguousarray(x, np.float64)
+    f = C.c_double(); g = np.zeros(6); nc = C.c_int32()
+    rc = lib().flo_gicp_fdf(pa, na, pb, nb, sa, _dp(G), corr_dist, _dp(x), C.byref(f), _dp(g), C.byref(nc))
+    if rc != 0:
+        raise RuntimeError("flo_gicp_fdf: too few points / correspondences")
+    return f.value, g, nc.value
+
+
+def jacobi_svd_solve6(A, b):
+    A = np.ascontiguousarray(np.asarray(A, np.float64).T).reshape(-1).copy()
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros(6)
+    lib().flo_jacobi_svd_solve6(_dp(A), _dp(b), _dp(x))
+    return x
 
 
 def voxel_grid(cloud, leaf):
