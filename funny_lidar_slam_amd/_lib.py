@@ -17,7 +17,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 EXPORTED_SYMBOLS = [
     "fls_create", "fls_destroy", "fls_add_cloud_to_local_map", "fls_match", "fls_get_fitness_score",
     "fls_scan_upload", "fls_match_resident", "fls_match_batch", "fls_map_export", "fls_map_import", "fls_get_iteration_log", "fls_get_correspondences", "fls_map_size",
-    "fls_set_profiling", "fls_get_kernel_time", "fls_get_traffic_counters", "fls_get_debug_stamps", "fls_debug_fullpiv_qr6", "fls_debug_voxel_grid", "fls_voxel_grid_cloud", "fls_status_string", "fls_abi_version",
+    "fls_set_profiling", "fls_get_kernel_time", "fls_get_traffic_counters", "fls_get_debug_stamps", "fls_debug_fullpiv_qr6", "fls_debug_voxel_grid", "fls_voxel_grid_cloud", "fls_loop_match", "fls_status_string", "fls_abi_version",
     "fls_device_count",
     # include/fls_features.h
     "fls_features_create", "fls_features_destroy", "fls_features_project", "fls_features_extract", "fls_features_get", "fls_features_get_time",
@@ -162,6 +162,9 @@ def lib():
         L.fls_map_export.argtypes = [hp, C.c_void_p, C.c_size_t]
         L.fls_map_import.restype = C.c_int
         L.fls_map_import.argtypes = [hp, C.c_void_p, C.c_size_t]
+        L.fls_loop_match.restype = C.c_int
+        L.fls_loop_match.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float),
+                                     C.c_void_p]
         L.fls_voxel_grid_cloud.restype = C.c_int
         L.fls_voxel_grid_cloud.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_float, C.POINTER(C.c_float), C.c_size_t,
                                            C.POINTER(C.c_size_t)]

@@ -6,6 +6,7 @@
 #include "matchers_kd.hpp"
 #include "matcher_ndt.hpp"
 #include "features_host.hpp"
+#include "loop_closure.hpp"
 #include <new>
 
 using namespace fls;
@@ -264,6 +265,25 @@ fls_status fls_voxel_grid_cloud(int device_id, fls_voxelgrid_mode mode, const fl
         if (c.size() > cap) return FLS_ERR_INVALID;
         if (!c.empty()) std::memcpy(out, c.data(), c.size() * sizeof(PtI));
         return FLS_OK;
+    });
+}
+
+fls_status fls_loop_match(int device_id, const float* source, size_t n_source, const float* target, size_t n_target, int stride, double T[16], float* fitness,
+                          fls_loop_stats* stats) {
+    if (!T || !fitness || stride < 3 || (!source && n_source) || (!target && n_target)) return FLS_ERR_INVALID;
+    *fitness = std::numeric_limits<float>::max();
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    return guarded([&]() -> fls_status {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return FLS_ERR_DEVICE;
+        hipDeviceProp_t prop;
+        FLS_HIP(hipGetDeviceProperties(&prop, device_id));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FLS_ERR_DEVICE;
+        LoopMatcher m;
+        m.init(device_id);
+        const fls_status rc = m.run(cloud_from(source, n_source, stride), cloud_from(target, n_target, stride), T, fitness);
+        if (stats) *stats = m.st;
+        return rc;
     });
 }
 

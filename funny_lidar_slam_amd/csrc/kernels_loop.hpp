@@ -1,0 +1,303 @@
+// kernels_loop.hpp -- device kernels of the loop-closure matcher, LoopClosure::Match (src/slam/loop_closure.cpp:233-267:
+// pcl::NormalDistributionsTransform at 10 / 5 / 3 / 2 m, then pcl::GeneralizedIterativeClosestPoint, then getFitnessScore).
+// SURVEY.md 8f rank 4.  PCL is absent from /root/reference: the algorithms are the published ones as PCL 1.10 implements them
+// (host side + citations: loop_closure.hpp).  gfx950 only; no MFMA (per point: a 6-vector and a 6x6 of FP64 sums).
+//
+//   ndt_p2d_kernel<HESS>   computeDerivatives / computeHessian (ndt.hpp): one lane per source point: float transform, the <= 27
+//                          leaf Gaussians whose centroid lies within `resolution` (radiusSearch on the voxel centroids), score +
+//                          gradient (+ Hessian) of Magnusson eq. 6.9 / 6.12 / 6.13 -> one partial row per workgroup
+//   gicp_cov_kernel        computeCovariances (gicp.hpp): exact 20-NN in the cloud's own cell grid (ring search, (d2, index) order),
+//                          moments in neighbour order, JacobiSVD, singular values replaced by (1, 1, gicp_epsilon)
+//   gicp_corr_kernel       one outer GICP iteration's correspondences: 1-NN of the transformed source point in the target grid, gate
+//                          on d2, Mahalanobis matrix (C2 + R C1 R^T)^-1
+//   gicp_fdf_kernel        OptimizationFunctorWithIndices f / df: sum of res^T M res, translation gradient, sum of p (M res)^T
+//   loop_fitness_kernel    getFitnessScore: squared distance to the nearest target point
+//   loop_reduce_kernel     fixed-order column sums of the partial rows -> host-mapped result block + sequence word
+// Every sum has a fixed tree (DPP wave sum -> LDS -> rows in index order): results are bit-reproducible run to run.
+#pragma once
+#include "kernels_knn.hpp"
+#include "host_math.hpp"
+
+namespace fls {
+
+constexpr int kLoopBlock = 256;
+constexpr int kLoopMaxV = 48;  // doubles per partial row (score + 6 + 36 + count = 44 used)
+
+struct LoopMat4f { float m[16]; };  // column-major
+// pcl::transformPointCloud, float (SSE form): c0 * x + (c1 * y + (c2 * z + c3))
+__host__ __device__ __forceinline__ void loop_xform(const LoopMat4f& t, const float x, const float y, const float z, float (&o)[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = t.m[i] * x + (t.m[i + 4] * y + (t.m[i + 8] * z + t.m[i + 12]));
+}
+
+// result block in host-mapped pinned memory
+struct LoopMail {
+    double v[kLoopMaxV];
+    unsigned seq;
+    unsigned pad;
+};
+
+// block sums of NV per-lane values -> row[NV] (wave DPP sums, then the waves in order)
+template <int NV>
+__device__ __forceinline__ void loop_block_reduce(const double (&acc)[NV], double* __restrict__ row, double (*lds)[kLoopMaxV]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double s = wave_sum_dpp(acc[k]);
+        if (lane == 63) lds[w][k] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NV) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < kLoopBlock / 64; ++q) s += lds[q][threadIdx.x];
+        row[threadIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+loop_reduce_kernel(const double* __restrict__ rows, const int nrows, const int nv, LoopMail* __restrict__ mail, const unsigned seq) {
+    const int c = threadIdx.x;
+    if (c < nv) {
+        double s = 0.0;
+        for (int r = 0; r < nrows; ++r) s += rows[(size_t)r * kLoopMaxV + c];  // fixed order
+        __hip_atomic_store((unsigned long long*)&mail->v[c], (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (c == 0) __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- P2D-NDT -----------------------------------------------------------------------------------------------------------------
+struct NdtP2dTarget {
+    const int* leaf_row;       // [div2][div1][div0]: row of the leaf's Gaussian, -1 when the leaf holds fewer than 6 points
+    const double* mean;        // [rows][3]
+    const double* icov;        // [rows][9] column-major
+    const float* centroid;     // [rows][3]
+    int min_b[3], div_b[3];
+    float inv_leaf, radius2;   // 1 / resolution (float), resolution^2 (float)
+};
+struct NdtP2dPose {
+    LoopMat4f T;
+    double gauss_d1, gauss_d2;
+    double j_ang[8][3];
+    double h_ang[15][3];
+};
+
+template <bool HESS>
+__global__ void __launch_bounds__(kLoopBlock)
+ndt_p2d_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n, const NdtP2dTarget tg,
+               const NdtP2dPose ps, double* __restrict__ rows) {
+    constexpr int NV = HESS ? 44 : 8;  // score, grad[6], (hess[36],) count of contributing (point, leaf) pairs
+    __shared__ double lds[kLoopBlock / 64][kLoopMaxV];
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    const int i = blockIdx.x * kLoopBlock + threadIdx.x;
+    if (i < n) {
+        const float px = sx[i], py = sy[i], pz = sz[i];
+        float xt[3];
+        loop_xform(ps.T, px, py, pz, xt);
+        const int c0 = (int)(floorf(xt[0] * tg.inv_leaf) - (float)tg.min_b[0]), c1 = (int)(floorf(xt[1] * tg.inv_leaf) - (float)tg.min_b[1]),
+                  c2 = (int)(floorf(xt[2] * tg.inv_leaf) - (float)tg.min_b[2]);
+        const double x[3] = {(double)px, (double)py, (double)pz};
+        // computePointDerivatives: the eight non-trivial entries of the 3 x 6 point gradient, the 18 of the point Hessian
+        double pg[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) pg[r][c] = (r == c) ? 1.0 : 0.0;
+        auto dotj = [&](const int k) { return (x[0] * ps.j_ang[k][0] + x[1] * ps.j_ang[k][1]) + x[2] * ps.j_ang[k][2]; };
+        auto doth = [&](const int k) { return (x[0] * ps.h_ang[k][0] + x[1] * ps.h_ang[k][1]) + x[2] * ps.h_ang[k][2]; };
+        pg[1][3] = dotj(0); pg[2][3] = dotj(1);
+        pg[0][4] = dotj(2); pg[1][4] = dotj(3); pg[2][4] = dotj(4);
+        pg[0][5] = dotj(5); pg[1][5] = dotj(6); pg[2][5] = dotj(7);
+        double ph[6][3];  // (3,3) (3,4) (3,5) (4,4) (4,5) (5,5)
+        if (HESS) {
+            ph[0][0] = 0.0; ph[0][1] = doth(0); ph[0][2] = doth(1);
+            ph[1][0] = 0.0; ph[1][1] = doth(2); ph[1][2] = doth(3);
+            ph[2][0] = 0.0; ph[2][1] = doth(4); ph[2][2] = doth(5);
+            ph[3][0] = doth(6); ph[3][1] = doth(7); ph[3][2] = doth(8);
+            ph[4][0] = doth(9); ph[4][1] = doth(10); ph[4][2] = doth(11);
+            ph[5][0] = doth(12); ph[5][1] = doth(13); ph[5][2] = doth(14);
+        }
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int cx = c0 + dx, cy = c1 + dy, cz = c2 + dz;
+                    if ((unsigned)cx >= (unsigned)tg.div_b[0] || (unsigned)cy >= (unsigned)tg.div_b[1] || (unsigned)cz >= (unsigned)tg.div_b[2]) continue;
+                    const int row = tg.leaf_row[(cz * tg.div_b[1] + cy) * tg.div_b[0] + cx];
+                    if (row < 0) continue;
+                    const float ex = xt[0] - tg.centroid[3 * row], ey = xt[1] - tg.centroid[3 * row + 1], ez = xt[2] - tg.centroid[3 * row + 2];
+                    float d2 = 0.0f;  // flann::L2_Simple
+                    d2 += ex * ex; d2 += ey * ey; d2 += ez * ez;
+                    if (!(d2 < tg.radius2)) continue;
+                    const double xq[3] = {(double)xt[0] - tg.mean[3 * row], (double)xt[1] - tg.mean[3 * row + 1], (double)xt[2] - tg.mean[3 * row + 2]};
+                    double ci[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) ci[q] = tg.icov[9 * (size_t)row + q];
+                    auto cmul = [&](const double (&v)[3], double (&o)[3]) {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) o[r] = (ci[r] * v[0] + ci[r + 3] * v[1]) + ci[r + 6] * v[2];
+                    };
+                    double cxq[3];
+                    cmul(xq, cxq);
+                    double e_x = exp(-ps.gauss_d2 * ((xq[0] * cxq[0] + xq[1] * cxq[1]) + xq[2] * cxq[2]) / 2.0);
+                    const double score_inc = -ps.gauss_d1 * e_x;
+                    e_x = ps.gauss_d2 * e_x;
+                    if (e_x > 1.0 || e_x < 0.0 || e_x != e_x) continue;
+                    e_x *= ps.gauss_d1;
+                    double cg[6][3], xcg[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        const double col[3] = {pg[0][c], pg[1][c], pg[2][c]};
+                        cmul(col, cg[c]);
+                        xcg[c] = (xq[0] * cg[c][0] + xq[1] * cg[c][1]) + xq[2] * cg[c][2];
+                        acc[1 + c] += xcg[c] * e_x;
+                    }
+                    if (HESS) {
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+#pragma unroll
+                            for (int b = 0; b < 6; ++b) {
+                                double t2 = 0.0;
+                                if (a >= 3 && b >= 3) {
+                                    const int lo = a < b ? a : b, hi = a < b ? b : a;
+                                    const int k = lo == 3 ? hi - 3 : (lo == 4 ? hi - 1 : 5);  // (3,3)->0 (3,4)->1 (3,5)->2 (4,4)->3 (4,5)->4 (5,5)->5
+                                    double chv[3];
+                                    cmul(ph[k], chv);
+                                    t2 = (xq[0] * chv[0] + xq[1] * chv[1]) + xq[2] * chv[2];
+                                }
+                                const double t3 = (pg[0][b] * cg[a][0] + pg[1][b] * cg[a][1]) + pg[2][b] * cg[a][2];
+                                acc[7 + a + 6 * b] += e_x * ((-ps.gauss_d2 * xcg[a] * xcg[b] + t2) + t3);
+                            }
+                    }
+                    acc[0] += score_inc;
+                    acc[NV - 1] += 1.0;
+                }
+    }
+    loop_block_reduce<NV>(acc, rows + (size_t)blockIdx.x * kLoopMaxV, lds);
+}
+
+// ---- GICP --------------------------------------------------------------------------------------------------------------------
+// 20-NN covariance of every point of a cloud held in its own cell grid (ids = cloud indices)
+__global__ void __launch_bounds__(64)
+gicp_cov_kernel(const float* __restrict__ cx, const float* __restrict__ cy, const float* __restrict__ cz, const int n, const CellGridDev cg,
+                const double gicp_epsilon, double* __restrict__ cov_out /* [n][9] column-major */) {
+    constexpr int K = 20;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    KnnResult<K> r;
+    unsigned long long a = 0, b = 0, c = 0;
+    knn_grid<K>(cg, cx[i], cy[i], cz[i], INFINITY, r, a, b, c);
+    double mean[3] = {0.0, 0.0, 0.0}, cov[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < K; ++j) {
+        if (j >= r.found) break;
+        const float4 p = cg.g.pts[r.slot[j]];
+        mean[0] += p.x; mean[1] += p.y; mean[2] += p.z;
+        cov[0] += p.x * p.x;  // float products, double sums (gicp.hpp computeCovariances)
+        cov[1] += p.y * p.x; cov[4] += p.y * p.y;
+        cov[2] += p.z * p.x; cov[5] += p.z * p.y; cov[8] += p.z * p.z;
+    }
+    for (int q = 0; q < 3; ++q) mean[q] /= (double)K;
+    for (int rr = 0; rr < 3; ++rr)
+        for (int l = 0; l <= rr; ++l) {
+            double v = cov[rr + 3 * l] / (double)K;
+            v -= mean[rr] * mean[l];
+            cov[rr + 3 * l] = v;
+            cov[l + 3 * rr] = v;
+        }
+    double U[9], S[3], V[9];
+    hm::svd3(cov, U, S, V);
+    double* o = cov_out + (size_t)i * 9;
+    for (int q = 0; q < 9; ++q) o[q] = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        const double v = k == 2 ? gicp_epsilon : 1.0;
+        for (int cc = 0; cc < 3; ++cc)
+            for (int rr = 0; rr < 3; ++rr) o[rr + 3 * cc] += v * U[rr + 3 * k] * U[cc + 3 * k];
+    }
+}
+
+struct GicpRot { double R[9]; };  // rotation of transformation_ * guess, column-major
+
+__global__ void __launch_bounds__(64)
+gicp_corr_kernel(const float* __restrict__ mx, const float* __restrict__ my, const float* __restrict__ mz, const int n, const LoopMat4f T,
+                 const CellGridDev cg_tgt, const float gate /* squared */, const double dist_threshold, const GicpRot rot, const double* __restrict__ cov_src,
+                 const double* __restrict__ cov_tgt, int* __restrict__ corr, double* __restrict__ mahal) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    float q[3];
+    loop_xform(T, mx[i], my[i], mz[i], q);
+    KnnResult<1> r;
+    unsigned long long a = 0, b = 0, c = 0;
+    knn_grid<1>(cg_tgt, q[0], q[1], q[2], gate, r, a, b, c);
+    int id = -1;
+    if (r.found && (double)r.d[0] < dist_threshold) {
+        id = r.id[0];
+        const double* C1 = cov_src + (size_t)i * 9;
+        const double* C2 = cov_tgt + (size_t)id * 9;
+        double M1[9], Rt[9], tmp[9];
+        hm::mul3(rot.R, C1, M1);
+        for (int cc = 0; cc < 3; ++cc)
+            for (int rr = 0; rr < 3; ++rr) Rt[rr + 3 * cc] = rot.R[cc + 3 * rr];
+        hm::mul3(M1, Rt, tmp);
+        for (int k = 0; k < 9; ++k) tmp[k] += C2[k];
+        hm::inv3(tmp, mahal + (size_t)i * 9);
+    }
+    corr[i] = id;
+}
+
+template <bool GRAD>
+__global__ void __launch_bounds__(kLoopBlock)
+gicp_fdf_kernel(const float* __restrict__ mx, const float* __restrict__ my, const float* __restrict__ mz, const int n, const LoopMat4f T,
+                const float4* __restrict__ tgt_by_id, const int* __restrict__ corr, const double* __restrict__ mahal, double* __restrict__ rows) {
+    constexpr int NV = GRAD ? 14 : 2;  // f, (g_t[3], Racc[9],) count
+    __shared__ double lds[kLoopBlock / 64][kLoopMaxV];
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    const int i = blockIdx.x * kLoopBlock + threadIdx.x;
+    const int id = i < n ? corr[i] : -1;
+    if (id >= 0) {
+        const float px = mx[i], py = my[i], pz = mz[i];
+        float pp[3];
+        loop_xform(T, px, py, pz, pp);
+        const float4 t = tgt_by_id[id];
+        const double res[3] = {(double)(pp[0] - t.x), (double)(pp[1] - t.y), (double)(pp[2] - t.z)};
+        const double* M = mahal + (size_t)i * 9;
+        double tmp[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) tmp[r] = (M[r] * res[0] + M[r + 3] * res[1]) + M[r + 6] * res[2];
+        acc[0] = (res[0] * tmp[0] + res[1] * tmp[1]) + res[2] * tmp[2];
+        if (GRAD) {
+            const double p3[3] = {(double)px, (double)py, (double)pz};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[1 + a] = tmp[a];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) acc[4 + rr + 3 * cc] = p3[rr] * tmp[cc];
+        }
+        acc[NV - 1] = 1.0;
+    }
+    loop_block_reduce<NV>(acc, rows + (size_t)blockIdx.x * kLoopMaxV, lds);
+}
+
+__global__ void __launch_bounds__(kLoopBlock)
+loop_fitness_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n, const LoopMat4f T,
+                    const CellGridDev cg_tgt, double* __restrict__ rows) {
+    __shared__ double lds[kLoopBlock / 64][kLoopMaxV];
+    double acc[2] = {0.0, 0.0};
+    const int i = blockIdx.x * kLoopBlock + threadIdx.x;
+    if (i < n) {
+        float q[3];
+        loop_xform(T, sx[i], sy[i], sz[i], q);
+        KnnResult<1> r;
+        unsigned long long a = 0, b = 0, c = 0;
+        knn_grid<1>(cg_tgt, q[0], q[1], q[2], INFINITY, r, a, b, c);
+        if (r.found) { acc[0] = (double)r.d[0]; acc[1] = 1.0; }
+    }
+    loop_block_reduce<2>(acc, rows + (size_t)blockIdx.x * kLoopMaxV, lds);
+}
+
+}  // namespace fls

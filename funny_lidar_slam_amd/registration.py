@@ -328,6 +328,31 @@ class LoamPointToPlaneKdtree(RegistrationInterface):
                                 is_localization_mode=int(is_localization_mode)), device_id)
 
 
+class LoopStats(C.Structure):
+    """fls_loop_stats (include/fls_reg.h)"""
+    _fields_ = [("ndt_iterations", C.c_int32 * 4), ("ndt_evaluations", C.c_int32 * 4), ("ndt_source_points", C.c_int32 * 4), ("ndt_target_leaves", C.c_int32 * 4),
+                ("gicp_iterations", C.c_int32), ("gicp_inner_iterations", C.c_int32), ("gicp_evaluations", C.c_int32), ("gicp_correspondences", C.c_int32),
+                ("gicp_source_points", C.c_int32), ("gicp_target_points", C.c_int32), ("gicp_failed", C.c_int32), ("reserved", C.c_int32),
+                ("ndt_score", C.c_double * 4), ("T_after_ndt", C.c_double * 16)]
+
+
+def LoopClosureMatch(source_cloud: np.ndarray, target_cloud: np.ndarray, pose: np.ndarray, device_id: int = 0):
+    """LoopClosure::Match (src/slam/loop_closure.cpp:233-267): 4-resolution NDT + GICP.  `pose` (4,4) is in/out like the reference's
+    Mat4d&; returns (fitness, LoopStats)."""
+    a, pa, na, sa = _cloud(source_cloud)
+    b, pb, nb, sb = _cloud(target_cloud)
+    if sa != sb:
+        raise ValueError("clouds must share a stride")
+    Tf = np.ascontiguousarray(np.asarray(pose, dtype=np.float64).reshape(4, 4).T).reshape(-1).copy()
+    fit = C.c_float()
+    st = LoopStats()
+    rc = _lib.lib().fls_loop_match(device_id, pa, na, pb, nb, sa, Tf.ctypes.data_as(C.POINTER(C.c_double)), C.byref(fit), C.byref(st))
+    if rc != _lib.FLS_OK:
+        raise FlsError(rc, "fls_loop_match")
+    pose[...] = Tf.reshape(4, 4).T
+    return float(fit.value), st
+
+
 def VoxelGridCloud(cloud: np.ndarray, voxel_size: float = 0.1, on_device: bool = False, device_id: int = 0) -> np.ndarray:
     """include/common/pointcloud_utility.h:216-271 (pcl::VoxelGrid<PointXYZI>::filter): the stand-alone filter of the preprocessing
     thread (preprocessing.cpp:224-237) and of loop closure.  (n, 3|4|8) float32 -> (m, 4) {x, y, z, intensity}.

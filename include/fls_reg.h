@@ -168,6 +168,28 @@ typedef enum fls_voxelgrid_mode { FLS_VOXELGRID_EXACT = 0, FLS_VOXELGRID_DEVICE 
 fls_status fls_voxel_grid_cloud(int device_id, fls_voxelgrid_mode mode, const float* pts, size_t n, int stride_floats, float leaf_size,
                                 float* out, size_t cap_points, size_t* n_out);
 
+/* ---- LoopClosure::Match  (src/slam/loop_closure.cpp:233-267) -----------------------------------------------------------------
+ * The other registration consumer of the pipeline; it bypasses RegistrationInterface, so it gets its own entry point:
+ *     float LoopClosure::Match(source_cloud, target_cloud, Mat4d& pose)
+ * = pcl::NormalDistributionsTransform at resolutions 10 / 5 / 3 / 2 m (step size 0.5, 30 iterations) over
+ * VoxelGridCloud(cloud, r * 0.2) clouds, then pcl::GeneralizedIterativeClosestPoint (30 iterations, 2.0 m correspondence
+ * distance) over VoxelGridCloud(source, 0.5) / VoxelGridCloud(target, 0.4), return value gicp.getFitnessScore().
+ * source / target: n x stride floats (as fls_match); T_colmajor: the initial guess in, the aligned pose out (target <- source);
+ * *fitness: mean squared nearest-neighbour distance (FLT_MAX when GICP could not run: fewer than 20 filtered points).
+ * Per-point work runs on the device, the six-parameter optimisers on the host (csrc/loop_closure.hpp).  Stateless: no handle. */
+typedef struct fls_loop_stats {
+    int32_t ndt_iterations[4];     /* per resolution stage: Newton iterations                       */
+    int32_t ndt_evaluations[4];    /*                       score / derivative evaluations          */
+    int32_t ndt_source_points[4];  /*                       source points after VoxelGridCloud      */
+    int32_t ndt_target_leaves[4];  /*                       leaf Gaussians (>= 6 points)            */
+    int32_t gicp_iterations, gicp_inner_iterations, gicp_evaluations, gicp_correspondences;
+    int32_t gicp_source_points, gicp_target_points, gicp_failed, reserved;
+    double ndt_score[4];           /* trans_probability_ of the stage                               */
+    double T_after_ndt[16];        /* pose handed from the NDT stages to GICP                       */
+} fls_loop_stats;
+fls_status fls_loop_match(int device_id, const float* source, size_t n_source, const float* target, size_t n_target, int stride_floats,
+                          double T_colmajor[16], float* fitness, fls_loop_stats* stats);
+
 /* ---- RegistrationInterface::GetFitnessScore  (registration_interface.h:19) ---------------------- */
 fls_status fls_get_fitness_score(fls_handle h, float max_range, float* score);
 

@@ -40,6 +40,8 @@ def test_struct_layouts_match_header(built):
     assert names == [f[0] for f in _lib.Params._fields_]
     assert [f[0] for f in O.Params._fields_] == names  # the oracle mirrors the same layout independently
     assert C.sizeof(_lib.Params) == 128 and C.sizeof(_lib.Stats) == 96
+    from funny_lidar_slam_amd import registration as reg
+    assert C.sizeof(reg.LoopStats) == C.sizeof(O.LoopStats) == 256 and [f[0] for f in reg.LoopStats._fields_] == [f[0] for f in O.LoopStats._fields_]
     src = open(os.path.join(ROOT, "include", "fls_features.h")).read()
     body = re.search(r"typedef struct fls_feature_params \{(.*?)\} fls_feature_params;", src, re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)

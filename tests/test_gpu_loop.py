@@ -1,0 +1,90 @@
+"""fls_loop_match (LoopClosure::Match, src/slam/loop_closure.cpp:233-267: 4-resolution P2D-NDT + GICP + getFitnessScore) on the
+GPU against the CPU oracle's restatement of the same published algorithms (oracle/flo_loop.h; PCL itself is absent: parity
+unpinned against PCL, see its header).  Device sums have a fixed tree but not the oracle's sequential order, and exp() comes
+from a different libm, so the comparison is to BASELINE's floating-point bar (1e-4 m / 1e-4 rad); everything discrete must
+match: filtered cloud sizes, leaf counts, iterations and evaluation counts of every stage, the number of correspondences."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from funny_lidar_slam_amd import _lib, registration as reg, synth
+from oracle import oracle as O
+from tests import loopdata
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(built):
+    assert _lib.device_count() >= 1, "gpu tests need an MI355X (gfx950): the HIP path has no CPU fallback"
+
+
+def _compare(src, tgt, guess, Tt=None, label=""):
+    fo, To, so = O.loop_match(src, tgt, guess)
+    T = np.array(guess, dtype=np.float64)
+    fg, sg = reg.LoopClosureMatch(src, tgt, T)
+    for k in range(4):
+        assert sg.ndt_source_points[k] == so.ndt_source_points[k] and sg.ndt_target_leaves[k] == so.ndt_target_leaves[k], (label, k)
+        assert sg.ndt_iterations[k] == so.ndt_iterations[k] and sg.ndt_evaluations[k] == so.ndt_evaluations[k], (label, k, list(sg.ndt_iterations), list(so.ndt_iterations),
+                                                                                                               list(sg.ndt_evaluations), list(so.ndt_evaluations))
+        assert sg.ndt_score[k] == pytest.approx(so.ndt_score[k], rel=1e-6), (label, k)
+    Ta, Tb = np.array(sg.T_after_ndt).reshape(4, 4).T, np.array(so.T_after_ndt).reshape(4, 4).T
+    dt, dr = synth.pose_error(Ta, Tb)
+    assert dt <= 1e-4 and dr <= 1e-4, (label, "after NDT", dt, dr)
+    assert (sg.gicp_source_points, sg.gicp_target_points, sg.gicp_failed) == (so.gicp_source_points, so.gicp_target_points, so.gicp_failed), label
+    assert sg.gicp_iterations == so.gicp_iterations and sg.gicp_correspondences == so.gicp_correspondences, (label, sg.gicp_iterations, so.gicp_iterations,
+                                                                                                               sg.gicp_correspondences, so.gicp_correspondences)
+    dt2, dr2 = synth.pose_error(T, To)
+    assert dt2 <= 1e-4 and dr2 <= 1e-4, (label, "final", dt2, dr2)
+    assert fg == pytest.approx(fo, rel=1e-4), (label, fg, fo)
+    if Tt is not None:
+        et, er = synth.pose_error(T, Tt)
+        assert et < 0.02 and er < 2e-3, (label, et, er)
+    print(f"{label}: NDT iterations {list(sg.ndt_iterations)} evaluations {list(sg.ndt_evaluations)}, GICP {sg.gicp_iterations} outer / {sg.gicp_inner_iterations} inner / "
+          f"{sg.gicp_evaluations} evaluations, {sg.gicp_correspondences} correspondences; GPU vs oracle: after NDT {dt:.1e} m {dr:.1e} rad, final {dt2:.1e} m {dr2:.1e} rad, "
+          f"fitness {fg:.6f} vs {fo:.6f}")
+    return T, fg, sg
+
+
+def test_loop_match_equals_the_oracle_on_synthetic_submaps():
+    src, tgt, Tt = loopdata.make_pair(job=1, n_az=450, n_t=5, n_s=3)
+    _compare(src, tgt, np.eye(4), Tt, "submaps 58k / 96k points, guess = identity")
+
+
+def test_loop_match_other_displacements_and_guesses():
+    src, tgt, Tt = loopdata.make_pair(job=2, n_az=300, n_t=3, n_s=2, rot_deg=(-1.0, 0.6, -4.0), trans=(-1.0, 0.7, -0.15))
+    _compare(src, tgt, np.eye(4), Tt, "job 2, guess = identity")
+    g = Tt.copy()
+    g[:3, 3] += [0.2, -0.1, 0.05]
+    _compare(src, tgt, g, Tt, "job 2, guess near the truth")
+
+
+def test_loop_match_is_deterministic_and_takes_pcl_rows():
+    src, tgt, _ = loopdata.make_pair(job=3, n_az=200, n_t=2, n_s=2)
+    T1, T2 = np.eye(4), np.eye(4)
+    f1, s1 = reg.LoopClosureMatch(src, tgt, T1)
+    f2, s2 = reg.LoopClosureMatch(src, tgt, T2)
+    assert f1 == f2 and np.array_equal(T1, T2) and list(s1.ndt_evaluations) == list(s2.ndt_evaluations)
+    pcl = lambda c: np.concatenate([c[:, :3], np.zeros((len(c), 5), np.float32)], axis=1)  # pcl::PointXYZI rows (stride 8)
+    T3 = np.eye(4)
+    f3, _ = reg.LoopClosureMatch(pcl(src), pcl(tgt), T3)
+    assert f3 == f1 and np.array_equal(T3, T1)
+
+
+def test_loop_match_degenerate_inputs():
+    rng = np.random.default_rng(0)
+    few = rng.uniform(-5, 5, (15, 3)).astype(np.float32)
+    T = np.eye(4)
+    f, st = reg.LoopClosureMatch(few, few, T)
+    fo, To, so = O.loop_match(few, few, np.eye(4))
+    assert f == fo == float(np.finfo(np.float32).max) and st.gicp_iterations == 0  # fewer than 20 points: GICP does not run
+    assert np.allclose(T, To, atol=1e-6)
+    L = _lib.lib()
+    fit = C.c_float()
+    Tf = np.eye(4).reshape(-1).copy()
+    assert L.fls_loop_match(0, None, 5, None, 0, 3, Tf.ctypes.data_as(C.POINTER(C.c_double)), C.byref(fit), None) == _lib.FLS_ERR_INVALID
+    empty = np.zeros((0, 3), np.float32)
+    T = np.eye(4)
+    f, st = reg.LoopClosureMatch(empty, few, T)
+    assert f == float(np.finfo(np.float32).max) and np.array_equal(T, np.eye(4))
