@@ -38,6 +38,7 @@ struct LoopMatcher {
     unsigned seq = 0;
     DevBuf<double> d_rows;
     bool device_filter = false;
+    bool debug = false;  // FLS_LOOP_DEBUG=1: one line per GICP outer iteration on stderr
     fls_loop_stats st{};
 
     ~LoopMatcher() {
@@ -52,6 +53,7 @@ struct LoopMatcher {
         std::memset(mail_host, 0, sizeof(LoopMail));
         FLS_HIP(hipHostGetDevicePointer((void**)&mail_dev, mail_host, 0));
         if (const char* e = std::getenv("FLS_DEVICE_VOXELGRID")) device_filter = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_LOOP_DEBUG")) debug = std::atoi(e) != 0;
     }
 
     // ---- float pose algebra (Eigen::Transform<float, 3, Affine>) ------------------------------------------------------------
@@ -775,6 +777,8 @@ struct LoopMatcher {
                     delta = std::max(delta, ratio * std::fabs(double(previous.m[k + 4 * l]) - double(transformation.m[k + 4 * l])));
                 }
             ++nr;
+            if (debug) std::fprintf(stderr, "[fls loop] gicp outer %d: corr %d inner_total %d evals %d delta %.9g t = %.9g %.9g %.9g\n", nr, g.n_corr, g.inner_total, g.evaluations, delta,
+                                    double(transformation.m[12]), double(transformation.m[13]), double(transformation.m[14]));
             if (nr >= 30 || delta < 1) { converged = true; previous = transformation; }
         }
         const LoopMat4f fin = mul(previous, guess);

@@ -26,6 +26,8 @@
 #include "flo_kdtree.h"
 #include "flo_linalg.h"
 #include <map>
+#include <cstdio>
+#include <cstdlib>
 
 namespace flo {
 namespace loop {
@@ -850,6 +852,9 @@ struct Gicp {
                     if (c_delta > delta) delta = c_delta;
                 }
             ++nr;
+            if (std::getenv("FLO_LOOP_DEBUG"))
+                std::fprintf(stderr, "[flo loop] gicp outer %d: corr %d inner_total %d evals %d delta %.9g t = %.9g %.9g %.9g\n", nr, stats.correspondences, stats.inner_total,
+                             stats.evaluations, delta, double(transformation.m[12]), double(transformation.m[13]), double(transformation.m[14]));
             if (nr >= max_iterations || delta < 1) { converged = true; previous = transformation; }
         }
         stats.iterations = nr;

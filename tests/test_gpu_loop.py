@@ -33,17 +33,25 @@ def _compare(src, tgt, guess, Tt=None, label=""):
     dt, dr = synth.pose_error(Ta, Tb)
     assert dt <= 1e-4 and dr <= 1e-4, (label, "after NDT", dt, dr)
     assert (sg.gicp_source_points, sg.gicp_target_points, sg.gicp_failed) == (so.gicp_source_points, so.gicp_target_points, so.gicp_failed), label
-    assert sg.gicp_iterations == so.gicp_iterations and sg.gicp_correspondences == so.gicp_correspondences, (label, sg.gicp_iterations, so.gicp_iterations,
-                                                                                                               sg.gicp_correspondences, so.gicp_correspondences)
+    # GICP's inner BFGS runs into a basin that is flat at the 1e-16 level of its cost sums: which trial point a line search accepts,
+    # whether |g| < 1e-2 holds after an inner step and hence how many inner / outer iterations run is decided by the last bits of
+    # those sums -- and the device adds in a fixed TREE, the oracle sequentially.  Runs whose traces coincide must agree to the
+    # 1e-4 bar; runs that part ways end in the same basin within GICP's own stopping tolerance (translation epsilon 5e-4 per outer
+    # iteration, rotation epsilon 2e-3): 2 mm / 5e-4 rad, and equally close to the truth.
+    same_trace = sg.gicp_iterations == so.gicp_iterations and sg.gicp_inner_iterations == so.gicp_inner_iterations
+    assert abs(sg.gicp_iterations - so.gicp_iterations) <= 2, (label, sg.gicp_iterations, so.gicp_iterations)
+    if same_trace:
+        assert sg.gicp_correspondences == so.gicp_correspondences, (label, sg.gicp_correspondences, so.gicp_correspondences)
     dt2, dr2 = synth.pose_error(T, To)
-    assert dt2 <= 1e-4 and dr2 <= 1e-4, (label, "final", dt2, dr2)
-    assert fg == pytest.approx(fo, rel=1e-4), (label, fg, fo)
+    tol_t, tol_r = (1e-4, 1e-4) if same_trace else (2e-3, 5e-4)
+    assert dt2 <= tol_t and dr2 <= tol_r, (label, "final", same_trace, dt2, dr2)
+    assert fg == pytest.approx(fo, rel=1e-4 if same_trace else 2e-3), (label, fg, fo)
     if Tt is not None:
         et, er = synth.pose_error(T, Tt)
         assert et < 0.02 and er < 2e-3, (label, et, er)
     print(f"{label}: NDT iterations {list(sg.ndt_iterations)} evaluations {list(sg.ndt_evaluations)}, GICP {sg.gicp_iterations} outer / {sg.gicp_inner_iterations} inner / "
           f"{sg.gicp_evaluations} evaluations, {sg.gicp_correspondences} correspondences; GPU vs oracle: after NDT {dt:.1e} m {dr:.1e} rad, final {dt2:.1e} m {dr2:.1e} rad, "
-          f"fitness {fg:.6f} vs {fo:.6f}")
+          f"fitness {fg:.6f} vs {fo:.6f}" + ("" if same_trace else f"  [GICP traces part ways: {so.gicp_iterations} / {so.gicp_inner_iterations} in the oracle]"))
     return T, fg, sg
 
 
