@@ -27,6 +27,8 @@ namespace fls {
 constexpr unsigned kNdtNewBit = 0x80000000u;  // HashEntry.begin of an EMPTY or freshly claimed entry: 2^31 | (2^31 - 1 - first index)
 constexpr int kNdtCarry = 8;                  // unconsumed points kept per voxel between scans (min_points <= kNdtCarry)
 constexpr unsigned kNdtOk = 0u, kNdtNeedHost = 1u;
+constexpr unsigned long long kNdtTombKey = ~0ull - 1ull;  // table entry of an evicted voxel: probes walk past it (never equal to a packed key, not EMPTY)
+constexpr unsigned long long kNdtDeadKey = ~0ull - 2ull;  // r.key of an evicted row
 
 struct NdtRows {
     unsigned long long* key;   // packed voxel key
@@ -40,6 +42,7 @@ struct NdtRows {
     double* info;              // [row][9]   (read by ndt_kernel)
     int* vid;                  // [row]      (read by ndt_kernel)
     unsigned long long* stamp; // LRU: larger = touched later
+    unsigned* touch;           // sequence number of the last batch that touched the row (eviction conflict test)
 };
 
 struct NdtUpdState {
@@ -49,12 +52,14 @@ struct NdtUpdState {
     unsigned long long epoch;
     unsigned capacity, row_cap;
     unsigned n_new, status, apply, touched;
+    unsigned evict, seq, evict_ready, dead_hi;  // voxels this batch evicts; batch sequence number; the host queued the selection; hi word given to dead rows' sort key
 };
 
 // per point: voxel key, find or claim its table entry; for a claimed (new) entry remember the smallest cloud index
 __global__ void __launch_bounds__(256)
 ndt_upd_locate(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int n, const double inv_voxel,
-               HashEntry* __restrict__ table, const unsigned mask, unsigned* __restrict__ slot_h, NdtUpdState* __restrict__ st) {
+               HashEntry* __restrict__ table, const unsigned mask, unsigned* __restrict__ slot_h, NdtUpdState* __restrict__ st, unsigned* __restrict__ touch,
+               const unsigned seq) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double f0 = (double)x[i] * inv_voxel, f1 = (double)y[i] * inv_voxel, f2 = (double)z[i] * inv_voxel;
@@ -75,8 +80,9 @@ ndt_upd_locate(const float* __restrict__ x, const float* __restrict__ y, const f
         h = (h + 1) & mask;
     }
     slot_h[i] = h;
-    if (__hip_atomic_load(&table[h].begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kNdtNewBit)
-        atomicMax(&table[h].begin, kNdtNewBit | (0x7fffffffu - (unsigned)i));
+    const unsigned b = __hip_atomic_load(&table[h].begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b >= kNdtNewBit) atomicMax(&table[h].begin, kNdtNewBit | (0x7fffffffu - (unsigned)i));
+    else touch[b] = seq;  // an existing voxel this batch appends to (every toucher stores the same word)
 }
 
 // creators (first point of a new voxel): block-local exclusive rank + block totals
@@ -102,13 +108,62 @@ ndt_upd_creators(const int n, const HashEntry* __restrict__ table, const unsigne
     if (threadIdx.x == 0) bt[blockIdx.x] = tot;
 }
 
-// all-or-nothing decision (n_new was written by the scan of the block totals)
-__global__ void ndt_upd_decide(NdtUpdState* __restrict__ st) {
+// LRU evictions inside a batch (incremental_ndt.h:202-206: a creation that brings the count to the capacity pops the list's back).
+// With n alive voxels and k creations the batch evicts E = max(0, n + k - (capacity - 1)) voxels: the tail at each eviction.  As long
+// as the E least recently touched voxels (smallest stamps over ALL alive rows) are not touched by this batch, the tails are exactly
+// those E voxels whatever the timing -- touched voxels only move to the front, new voxels are born there.  Anything else (one of
+// them is touched: the reference would skip it or evict it and re-create it, depending on the order inside the batch) is refused
+// and replayed by the exact sequential host code.  The host sorts the rows by stamp (two stable 32-bit radix rounds: low word,
+// then high word; dead rows get the largest key) before this kernel whenever the batch COULD reach the capacity.
+__global__ void ndt_upd_predecide(NdtUpdState* __restrict__ st) {
     unsigned status = st->status;
-    if ((unsigned long long)st->n_alive + st->n_new >= (unsigned long long)st->capacity) status |= kNdtNeedHost;  // :202-205 would evict
+    const unsigned long long total = (unsigned long long)st->n_alive + st->n_new;
+    unsigned e = 0u;
+    if (total >= (unsigned long long)st->capacity) {
+        e = (unsigned)(total - (unsigned long long)st->capacity + 1ull);
+        if (!st->evict_ready || e > st->n_alive) status |= kNdtNeedHost;
+    }
     if ((unsigned long long)st->n_rows + st->n_new > (unsigned long long)st->row_cap) status |= kNdtNeedHost;
+    st->evict = e;
     st->status = status;
-    st->apply = status == kNdtOk ? 1u : 0u;
+}
+// sort keys of the eviction selection: the stamp of every row, one 32-bit half per round (dead rows sort last)
+__global__ void __launch_bounds__(256)
+ndt_evict_keys(const NdtRows r, const unsigned n_rows, const unsigned dead_hi, const int round, const unsigned* __restrict__ order, unsigned* __restrict__ key,
+               unsigned* __restrict__ val) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows) return;
+    const unsigned row = round == 0 ? i : order[i];
+    const bool dead = r.key[row] == kNdtDeadKey;
+    const unsigned long long s = r.stamp[row];
+    key[i] = round == 0 ? (dead ? 0xffffffffu : (unsigned)s) : (dead ? dead_hi : (unsigned)(s >> 32));
+    if (round == 0) val[i] = row;
+}
+// the E oldest rows must be alive and untouched by this batch
+__global__ void __launch_bounds__(256)
+ndt_evict_check(const NdtRows r, const unsigned* __restrict__ order, const unsigned n_rows, NdtUpdState* __restrict__ st) {
+    const unsigned j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= st->evict) return;
+    bool bad = j >= n_rows;
+    if (!bad) {
+        const unsigned row = order[j];
+        bad = r.key[row] == kNdtDeadKey || r.touch[row] == st->seq;
+    }
+    if (bad) atomicOr(&st->status, kNdtNeedHost);
+}
+__global__ void ndt_upd_decide(NdtUpdState* __restrict__ st) { st->apply = st->status == kNdtOk ? 1u : 0u; }
+// evict: tombstone the table entry, retire the row
+__global__ void __launch_bounds__(256)
+ndt_evict_apply(const NdtRows r, const unsigned* __restrict__ order, HashEntry* __restrict__ table, const NdtUpdState* __restrict__ st) {
+    const unsigned j = blockIdx.x * 256 + threadIdx.x;
+    if (!st->apply || j >= st->evict) return;
+    const unsigned row = order[j];
+    const unsigned h = r.hslot[row];
+    table[h].key = kNdtTombKey;
+    table[h].count = 0u;
+    r.key[row] = kNdtDeadKey;
+    r.estimated[row] = 0;
+    r.carry_cnt[row] = 0;
 }
 
 // creators initialise their voxel's row (applied) or give the claimed entry back (refused)
@@ -135,6 +190,7 @@ ndt_upd_create(const float* __restrict__ x, const float* __restrict__ y, const f
     r.carry_cnt[row] = 0;
     r.vid[row] = st->next_vid + (int)rank;
     r.stamp[row] = 0ull;
+    r.touch[row] = st->seq;
     table[h].begin = row;
     table[h].count = 0u;  // not estimated yet: ndt_kernel skips it
 }
@@ -174,6 +230,7 @@ ndt_table_rehash_kernel(HashEntry* __restrict__ table, const unsigned mask, cons
     const unsigned row = blockIdx.x * 256 + threadIdx.x;
     if (row >= n_rows) return;
     const unsigned long long key = r.key[row];
+    if (key == kNdtDeadKey) return;  // evicted
     unsigned h = hash_key(key) & mask;
     while (atomicCAS(&table[h].key, kEmptyKey, key) != kEmptyKey) h = (h + 1) & mask;  // keys are distinct
     table[h].begin = row;
@@ -241,6 +298,7 @@ __global__ void ndt_upd_commit(NdtUpdState* __restrict__ st, const unsigned n) {
     if (st->apply) {
         st->n_rows += st->n_new;
         st->n_alive += st->n_new;
+        st->n_alive -= st->evict;
         st->next_vid += (int)st->n_new;
         st->epoch += (unsigned long long)n + 1ull;
     }

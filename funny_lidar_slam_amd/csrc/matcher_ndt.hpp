@@ -89,6 +89,7 @@ struct NdtMatcher final : fls_matcher {
         if (const char* e = std::getenv("FLS_NDT_LANES")) lanes_kernel = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_NDT_DEVICE_UPDATE")) allow_device_update = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_NDT_DEVICE_MARGIN")) { const long c = std::atol(e); if (c >= 0) device_margin = size_t(c); }
+        if (const char* e = std::getenv("FLS_NDT_DEVICE_EVICT")) device_evict = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_NDT_DEVICE_SLACK")) { const long c = std::atol(e); if (c >= 0) device_slack = size_t(c); }
         inv_voxel = 1.0 / p.ndt_voxel_size;
         return FLS_OK;
@@ -259,8 +260,14 @@ struct NdtMatcher final : fls_matcher {
     size_t device_margin = 4096;      // FLS_NDT_DEVICE_MARGIN: voxels below the LRU capacity at which device mode is not entered
     size_t device_slack = 65536;      // FLS_NDT_DEVICE_SLACK: spare table entries / rows allocated ahead (test hook: small values force growth)
     bool device_mode = false, device_left = false;
+    bool device_evict = true;         // FLS_NDT_DEVICE_EVICT=0: a batch that reaches the LRU capacity is refused (round-2 behaviour; with it the margin rule applies)
+    unsigned host_updates_since_left = 0;  // device mode is re-entered after a refusal once eight host-path updates went by (hysteresis)
+    unsigned upd_seq = 0;
+    size_t dev_entries = 0;           // table entries in use (alive voxels + tombstones since the last re-hash)
+    unsigned long long device_evictions = 0, device_compactions = 0;
     DevBuf<unsigned long long> r_key, r_stamp;
-    DevBuf<unsigned> r_hslot;
+    DevBuf<unsigned> r_hslot, r_touch;
+    DevicePairSort ev_sort;
     DevBuf<int> r_np;
     DevBuf<unsigned char> r_est, r_cc;
     DevBuf<double> r_carry, d_sigma;
@@ -274,16 +281,21 @@ struct NdtMatcher final : fls_matcher {
     int dev_next_vid = 0;
     unsigned long long dev_epoch = 0, device_batches = 0, refused_batches = 0;
     size_t alive() const { return device_mode ? dev_alive : n_alive; }
-    NdtRows rows_dev() { return NdtRows{r_key.p, r_hslot.p, r_np.p, r_est.p, r_cc.p, r_carry.p, d_mu.p, d_sigma.p, d_info.p, d_vid.p, r_stamp.p}; }
+    NdtRows rows_dev() { return NdtRows{r_key.p, r_hslot.p, r_np.p, r_est.p, r_cc.p, r_carry.p, d_mu.p, d_sigma.p, d_info.p, d_vid.p, r_stamp.p, r_touch.p}; }
     void reserve_rows(size_t cap, bool keep) {
         r_key.reserve(cap, keep, stream); r_stamp.reserve(cap, keep, stream); r_hslot.reserve(cap, keep, stream); r_np.reserve(cap, keep, stream);
+        r_touch.reserve(cap, keep, stream, /*zero_new=*/true);
         r_est.reserve(cap, keep, stream); r_cc.reserve(cap, keep, stream); r_carry.reserve(cap * kNdtCarry * 3, keep, stream);
         d_sigma.reserve(cap * 9, keep, stream); d_mu.reserve(cap * 3, keep, stream); d_info.reserve(cap * 9, keep, stream); d_vid.reserve(cap, keep, stream);
         row_cap = cap;
     }
     bool can_enter_device_mode() const {
-        return allow_device_update && !device_left && !device_mode && !owner && !p.is_localization_mode && !flag_first_scan &&
-               p.ndt_min_points_in_voxel <= kNdtCarry && p.ndt_min_points_in_voxel >= 0 && n_alive + device_margin < size_t(p.ndt_capacity);
+        // after a refusal (device_left) the handle comes back once eight host-path updates went by: a scan that left the key range or
+        // an eviction the device could not order exactly is an episode, not a reason to stay on the 2 ms host path for good
+        const bool left = device_left && host_updates_since_left < 8;
+        const bool room = device_evict ? true : n_alive + device_margin < size_t(p.ndt_capacity);  // (without device evictions: stay clear of the capacity)
+        return allow_device_update && !left && !device_mode && !owner && !p.is_localization_mode && !flag_first_scan &&
+               p.ndt_min_points_in_voxel <= kNdtCarry && p.ndt_min_points_in_voxel >= 0 && room && p.ndt_capacity > 2;
     }
     // uploads the whole host mirror as rows (LRU order: row 0 = least recently touched) + a table holding every alive voxel
     void enter_device_mode(size_t batch_hint) {
@@ -321,7 +333,9 @@ struct NdtMatcher final : fls_matcher {
         up(d_vid.p, vid.data(), na * 4); up(r_est.p, est.data(), na); up(r_cc.p, cc.data(), na); up(r_carry.p, carry.data(), carry.size() * 8);
         up(d_mu.p, mu.data(), mu.size() * 8); up(d_sigma.p, sg.data(), sg.size() * 8); up(d_info.p, inf.data(), inf.size() * 8);
         FLS_HIP(hipStreamSynchronize(stream));
-        dev_rows = dev_alive = na;
+        FLS_HIP(hipMemsetAsync(r_touch.p, 0, r_touch.cap * sizeof(unsigned), stream));
+        dev_rows = dev_alive = dev_entries = na;
+        device_left = false;
         dev_table = ts;
         dev_next_vid = next_vid;
         dev_epoch = na + 1;
@@ -346,6 +360,7 @@ struct NdtMatcher final : fls_matcher {
         std::swap(d_table.cap, nt.cap);
         mask = ts - 1;
         dev_table = ts;
+        dev_entries = dev_alive;  // the re-hash dropped the tombstones
     }
     // one map update on the device; false = refused (nothing changed): the caller syncs the host mirror and replays on the host
     bool device_add_cloud(const std::vector<PtI>& cloud) {
@@ -361,20 +376,36 @@ struct NdtMatcher final : fls_matcher {
     bool device_add_cloud_dev(const float* x, const float* y, const float* z, const size_t n) {
         if (n == 0) return true;
         if (n > size_t(kVgMaxBlocks) * kVgTile) return false;
-        if ((dev_alive + n) * 2 + 2 > dev_table) grow_table_device(dev_alive + n);
+        if ((dev_entries + n) * 2 + 2 > dev_table) grow_table_device(dev_alive + n);
         if (dev_rows + n > row_cap) { reserve_rows(device_slack ? dev_rows + dev_rows / 2 + 2 * n : dev_rows + n, true); ++row_growths; }
+        upd_seq = upd_seq + 1u ? upd_seq + 1u : 1u;
+        const bool may_evict = device_evict && dev_alive + n >= size_t(p.ndt_capacity);  // every point a new voxel: the worst case
         NdtUpdState& hs = h_upd.p[0];
         hs = NdtUpdState{};
         hs.n_rows = unsigned(dev_rows); hs.n_alive = unsigned(dev_alive); hs.next_vid = dev_next_vid; hs.epoch = dev_epoch;
         hs.capacity = unsigned(p.ndt_capacity); hs.row_cap = unsigned(std::min<size_t>(row_cap, 0x7fffffffu));
+        hs.seq = upd_seq; hs.evict_ready = may_evict ? 1u : 0u; hs.dead_hi = unsigned((dev_epoch + n + 2) >> 32) + 1u;
         FLS_HIP(hipMemcpyAsync(d_upd.p, &hs, sizeof(NdtUpdState), hipMemcpyHostToDevice, stream));
         const int ni = int(n), nb1 = (ni + 255) / 256, nb2 = (ni + kVgScanBlock - 1) / kVgScanBlock;
         u_slot.reserve(n); u_lx.reserve(n); u_bt.reserve(size_t(2 * nb2));
         const NdtRows R = rows_dev();
-        hipLaunchKernelGGL(ndt_upd_locate, dim3(unsigned(nb1)), dim3(256), 0, stream, x, y, z, ni, inv_voxel, d_table.p, mask, u_slot.p, d_upd.p);
+        hipLaunchKernelGGL(ndt_upd_locate, dim3(unsigned(nb1)), dim3(256), 0, stream, x, y, z, ni, inv_voxel, d_table.p, mask, u_slot.p, d_upd.p, r_touch.p, upd_seq);
         hipLaunchKernelGGL(ndt_upd_creators, dim3(unsigned(nb2)), dim3(kVgScanBlock), 0, stream, ni, (const HashEntry*)d_table.p, (const unsigned*)u_slot.p, u_lx.p, u_bt.p);
         hipLaunchKernelGGL(vg_scan, dim3(1), dim3(kVgScanBlock), 0, stream, (const unsigned*)u_bt.p, u_bt.p + nb2, nb2, &d_upd.p->n_new);
+        hipLaunchKernelGGL(ndt_upd_predecide, dim3(1), dim3(1), 0, stream, d_upd.p);
+        if (may_evict && dev_rows > 0) {
+            // rows in LRU order: stable radix sort by the low, then by the high word of the 64-bit stamps (dead rows last)
+            const unsigned nr = unsigned(dev_rows), nbr = (nr + 255u) / 256u;
+            ev_sort.prepare(dev_rows);
+            hipLaunchKernelGGL(ndt_evict_keys, dim3(nbr), dim3(256), 0, stream, R, nr, hs.dead_hi, 0, (const unsigned*)nullptr, ev_sort.k0, ev_sort.v0);
+            ev_sort.run(4, stream);
+            hipLaunchKernelGGL(ndt_evict_keys, dim3(nbr), dim3(256), 0, stream, R, nr, hs.dead_hi, 1, (const unsigned*)ev_sort.v0, ev_sort.k0, ev_sort.v0);
+            ev_sort.run(DevicePairSort::passes_for((unsigned long long)hs.dead_hi), stream);
+            hipLaunchKernelGGL(ndt_evict_check, dim3(unsigned(nb1)), dim3(256), 0, stream, R, (const unsigned*)ev_sort.v0, nr, d_upd.p);
+        }
         hipLaunchKernelGGL(ndt_upd_decide, dim3(1), dim3(1), 0, stream, d_upd.p);
+        if (may_evict && dev_rows > 0)
+            hipLaunchKernelGGL(ndt_evict_apply, dim3(unsigned(nb1)), dim3(256), 0, stream, R, (const unsigned*)ev_sort.v0, d_table.p, (const NdtUpdState*)d_upd.p);
         hipLaunchKernelGGL(ndt_upd_create, dim3(unsigned(nb1)), dim3(256), 0, stream, x, y, z, ni, inv_voxel, d_table.p, (const unsigned*)u_slot.p,
                            (const unsigned*)u_lx.p, (const unsigned*)(u_bt.p + nb2), R, (const NdtUpdState*)d_upd.p);
         u_sort.prepare(n);
@@ -389,9 +420,13 @@ struct NdtMatcher final : fls_matcher {
         FLS_HIP(hipGetLastError());
         const NdtUpdState& o = h_upd.p[1];
         if (!o.apply) { ++refused_batches; return false; }
+        dev_entries += size_t(o.n_rows) - dev_rows;  // one table entry per created voxel (an evicted voxel's entry stays as a tombstone)
         dev_rows = o.n_rows; dev_alive = o.n_alive; dev_next_vid = o.next_vid; dev_epoch = o.epoch;
         last_touched = o.touched;
+        device_evictions += o.evict;
         ++device_batches;
+        // retired rows pile up at the capacity (hundreds per scan): drop them through the host mirror now and then
+        if (dev_rows - dev_alive > std::max<size_t>(2 * dev_alive, 262144)) compact_device_rows(n);
         return true;
     }
     unsigned last_touched = 0;
@@ -444,6 +479,7 @@ struct NdtMatcher final : fls_matcher {
         n_alive = 0;
         pool.reserve(nr);
         for (const size_t r : order) {  // oldest first: every push_front leaves the most recent at the head
+            if (k[r] == kNdtDeadKey) continue;  // evicted on the device
             pool.emplace_back();
             Voxel& v = pool.back();
             unpack_key(k[r], v.kx, v.ky, v.kz);
@@ -458,8 +494,15 @@ struct NdtMatcher final : fls_matcher {
         next_vid = dev_next_vid;
         device_mode = false;
         device_left = true;
+        host_updates_since_left = 0;
         have_map = false;  // the host-path image (estimated voxels only, host-assigned rows) is rebuilt from the mirror
         rebuild_image();
+    }
+    void compact_device_rows(size_t batch_hint) {
+        sync_host_from_device();
+        device_left = false;
+        ++device_compactions;
+        if (can_enter_device_mode()) enter_device_mode(batch_hint);
     }
 
     fls_status add_cloud_impl(const std::vector<PtI>& cloud_world_full) {  // :182-227
@@ -545,6 +588,7 @@ struct NdtMatcher final : fls_matcher {
         flag_first_scan = p.is_localization_mode ? true : false;  // :222-226
         const auto t3 = std::chrono::steady_clock::now();
         sync_image(touched);
+        if (device_left) ++host_updates_since_left;
         if (can_enter_device_mode()) enter_device_mode(cloud_world.size());
         if (host_timing) {
             const auto t4 = std::chrono::steady_clock::now();
@@ -665,6 +709,8 @@ struct NdtMatcher final : fls_matcher {
         if (slot == 111) return size_t(resident_updates);  // map updates fed by the device-resident filtered scan
         if (slot == 112) return size_t(table_growths);     // device-side table rebuilds / row-array growths
         if (slot == 113) return size_t(row_growths);
+        if (slot == 117) return size_t(device_evictions);    // voxels evicted by device batches / row compactions through the host mirror
+        if (slot == 118) return size_t(device_compactions);
         return alive();
     }
 };

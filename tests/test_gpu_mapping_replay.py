@@ -49,6 +49,7 @@ def run_replay(name, monkeypatch=None):
         r["image_syncs"] = (m.map_size(107), m.map_size(108))  # full rebuilds, incremental updates of the device image
         r["device_updates"] = (m.map_size(109), m.map_size(110))  # map updates applied on the device / refused
         r["device_growths"] = (m.map_size(112), m.map_size(113))  # device-side table rebuilds / row-array growths
+        r["device_evictions"] = (m.map_size(117), m.map_size(118))  # voxels evicted by device batches / row compactions
     m.close()
     return r, hist
 
@@ -62,9 +63,11 @@ def test_icp_mapping_replay():
     assert all(x["upd"] == 0 for x in h if not x["ok"]), "Q10: no map update without convergence"
 
 
-def test_ndt_mapping_replay():
+def test_ndt_mapping_replay(monkeypatch):
     """IncrementalNDT in mapping mode: non-first-scan UpdateVoxel (min / max points, pooled mean + covariance, SVD clamp),
-    LRU eviction at the (shrunk) capacity, Q11 (map update with the input pose -- every guess differs from the result)."""
+    LRU eviction at the (shrunk) capacity, Q11 (map update with the input pose -- every guess differs from the result).
+    HOST path of the evictions (FLS_NDT_DEVICE_EVICT=0: the margin rule keeps a handle this close to its capacity off the device)."""
+    monkeypatch.setenv("FLS_NDT_DEVICE_EVICT", "0")
     r, h = run_replay("ndt")
     cap = r["y"]["ndt_capacity"]
     assert all(x["upd"] == 1 for x in h)
@@ -99,11 +102,27 @@ def test_ndt_mapping_replay_device_refusal(monkeypatch):
     refused without side effects, the device state comes back to the host mirror (LRU order from the stamps, pending points
     from the carry buffers) and the exact sequential path takes over -- including the evictions."""
     monkeypatch.setenv("FLS_NDT_DEVICE_MARGIN", "0")
+    monkeypatch.setenv("FLS_NDT_DEVICE_EVICT", "0")  # (with device evictions the batch would simply be applied: next test)
     r, h = run_replay("ndt")
     applied, refused = r["device_updates"]
     cap = r["y"]["ndt_capacity"]
     assert refused == 1 and applied >= 1, (applied, refused)
     assert h[-1]["size"] == cap - 1
+
+
+def test_ndt_mapping_replay_device_evictions():
+    """Capacity 2,600, default settings (round 3): the handle enters device mode after the first host update and STAYS there at the
+    capacity -- a batch whose creations reach the capacity evicts the least recently touched voxels on the device (rows sorted by
+    their 64-bit LRU stamp; incremental_ndt.h:202-206) as long as none of them is touched by the batch itself.  Every frame equals
+    the oracle (ids = voxel ids, n_valid, poses, map sizes), no batch is refused."""
+    r, h = run_replay("ndt")
+    applied, refused = r["device_updates"]
+    evicted, compactions = r["device_evictions"]
+    cap = r["y"]["ndt_capacity"]
+    assert h[-1]["size"] == cap - 1 and sum(1 for x in h if x["size"] == cap - 1) >= 4, "the LRU list must sit at capacity for several scans"
+    assert refused == 0 and applied >= len(h) - 1, (applied, refused)
+    assert evicted > 100, evicted
+    print(f"ndt at capacity {cap}: {applied} device batches, {refused} refused, {evicted} voxels evicted on the device, {compactions} compactions")
 
 
 def test_ndt_mapping_replay_host_path_ab(monkeypatch):
