@@ -49,7 +49,9 @@ struct IvoxUpdState {
     unsigned n1, n2;          // batch: points of code 1 / code 2
     unsigned alloc, creations, touched, relocated_garbage;  // batch totals (ivox_upd_scan2)
     unsigned apply;           // 1: the batch passes every check and is applied
-    unsigned pad;
+    unsigned evict;           // voxels this batch evicts (LRU capacity reached inside the batch)
+    unsigned evict_ready, n_list;  // the host queued the eviction selection; entries of the stamp-sorted list of alive cells
+    unsigned long long evicted_points, evicted_slots;  // totals of the evicted voxels (ivox_evict_apply)
 };
 // what the host reads back (host-mapped pinned memory, written by ivox_upd_commit)
 struct IvoxUpdMailbox {
@@ -57,6 +59,7 @@ struct IvoxUpdMailbox {
     unsigned n_alive, status, added, touched;
     int next_id;
     unsigned seq;
+    unsigned evicted, pad;
 };
 
 struct IvoxUpdArrays {
@@ -206,13 +209,85 @@ ivox_upd_scan2(const IvoxUpdBatch b, IvoxUpdState* __restrict__ st) {
     if (threadIdx.x == 0) {
         st->alloc = tot[0]; st->creations = tot[1]; st->touched = tot[2]; st->relocated_garbage = tot[3];
         unsigned status = st->status;
-        // all-or-nothing: room in the point array, and no LRU eviction inside the batch (ivox_map.cpp:133-136 evicts when the
-        // count REACHES the capacity after a creation)
+        // all-or-nothing: room in the point array.  LRU evictions inside the batch (ivox_map.cpp:133-136 evicts the list's back when
+        // the count REACHES the capacity after a creation): with n alive voxels and k creations the batch evicts
+        // E = max(0, n + k - (capacity - 1)) voxels; they are the E least recently touched ones as long as none of those is touched by
+        // this batch (ivox_evict_check) -- the host queues the selection (alive cells sorted by stamp) whenever the batch could get there.
         if (st->used + (unsigned long long)tot[0] > st->pts_capacity) status |= kUpdNeedHost;
-        if ((unsigned long long)st->n_alive + tot[1] >= (unsigned long long)st->lru_capacity) status |= kUpdNeedHost;
+        const unsigned long long total = (unsigned long long)st->n_alive + tot[1];
+        unsigned e = 0u;
+        if (total >= (unsigned long long)st->lru_capacity) {
+            e = (unsigned)(total - (unsigned long long)st->lru_capacity + 1ull);
+            if (!st->evict_ready || e > st->n_list) status |= kUpdNeedHost;
+        }
+        st->evict = e;
+        st->evicted_points = 0ull;
+        st->evicted_slots = 0ull;
         st->status = status;
-        st->apply = status == kUpdOk ? 1u : 0u;
     }
+}
+
+// ---- eviction selection: the alive cells of the window as a list sorted by LRU stamp ------------------------------------------
+constexpr int kEvBlock = 1024;
+// pass 1: alive cells per block of kEvBlock cells
+__global__ void __launch_bounds__(kEvBlock)
+ivox_evict_count(const uint2* __restrict__ cells, const unsigned ncell, unsigned* __restrict__ bt) {
+    __shared__ unsigned wsum[kEvBlock / 64];
+    const unsigned c = blockIdx.x * kEvBlock + threadIdx.x;
+    const bool alive = c < ncell && cells[c].y != 0u;
+    const unsigned long long m = __ballot(alive);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned t = 0; for (int q = 0; q < kEvBlock / 64; ++q) t += wsum[q]; bt[blockIdx.x] = t; }
+}
+// pass 2: {low word of the stamp, cell} of every alive cell, in cell order (bt holds the scanned block offsets)
+__global__ void __launch_bounds__(kEvBlock)
+ivox_evict_list(const uint2* __restrict__ cells, const unsigned long long* __restrict__ stamp, const unsigned ncell, const unsigned* __restrict__ bt,
+                unsigned* __restrict__ key, unsigned* __restrict__ val) {
+    __shared__ unsigned wsum[kEvBlock / 64];
+    const unsigned c = blockIdx.x * kEvBlock + threadIdx.x;
+    const bool alive = c < ncell && cells[c].y != 0u;
+    const unsigned long long m = __ballot(alive);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wsum[w] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned base = bt[blockIdx.x];
+    for (int q = 0; q < w; ++q) base += wsum[q];
+    if (alive) {
+        const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        key[pos] = (unsigned)stamp[c];
+        val[pos] = c;
+    }
+}
+// second sort round: the high word of the stamps, read through the order of the first round
+__global__ void __launch_bounds__(256)
+ivox_evict_hikeys(const unsigned long long* __restrict__ stamp, const unsigned* __restrict__ order, const unsigned n, unsigned* __restrict__ key) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) key[i] = (unsigned)(stamp[order[i]] >> 32);
+}
+// the E oldest voxels must not be touched by this batch (pend counts the batch's arrivals per cell)
+__global__ void __launch_bounds__(256)
+ivox_evict_check(const unsigned* __restrict__ order, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st) {
+    const unsigned j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= st->evict) return;
+    if (j >= st->n_list || a.pend[order[j]] != 0u) atomicOr(&st->status, kUpdNeedHost);
+}
+__global__ void ivox_upd_set_evict(IvoxUpdState* __restrict__ st, const unsigned ready, const unsigned n_list) { st->evict_ready = ready; st->n_list = n_list; }
+__global__ void ivox_upd_decide(IvoxUpdState* __restrict__ st) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) st->apply = st->status == kUpdOk ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256)
+ivox_evict_apply(const unsigned* __restrict__ order, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st) {
+    const unsigned j = blockIdx.x * 256 + threadIdx.x;
+    if (!st->apply || j >= st->evict) return;
+    const unsigned cell = order[j];
+    const uint2 e = a.cells[cell];
+    const unsigned cl = a.cap_log2[cell];
+    atomicAdd(&st->evicted_points, (unsigned long long)e.y);
+    atomicAdd(&st->evicted_slots, cl ? (unsigned long long)(1u << cl) : 0ull);
+    a.cells[cell] = make_uint2(0u, 0u);  // the region's slots are garbage from here on (never read: count 0)
+    a.cap_log2[cell] = 0;
+    a.stamp[cell] = 0ull;
 }
 
 // the scratch word of every touched cell turns from the FIRST into the LAST rank of the batch (max >= min: one atomicMax);
@@ -313,10 +388,12 @@ __global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* _
     const unsigned A = st->n1 + st->n2;
     if (st->apply) {
         st->n_alive += st->creations;
+        st->n_alive -= st->evict;
         st->n_points += A;
+        st->n_points -= st->evicted_points;
         st->next_id += (int)A;
         st->used += st->alloc;
-        st->garbage += st->relocated_garbage;
+        st->garbage += st->relocated_garbage + st->evicted_slots;
         st->stamp_base += A;
     }
     __hip_atomic_store(&mb->n_points, st->n_points, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -327,6 +404,7 @@ __global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* _
     __hip_atomic_store(&mb->added, st->apply ? A : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&mb->touched, st->touched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&mb->next_id, st->next_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mb->evicted, st->apply ? st->evict : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -13,6 +13,7 @@
 #include "kernels_ivox_coop.hpp"
 #include "kernels_ivox_update.hpp"
 #include "fitness_host.hpp"
+#include "device_voxelgrid.hpp"
 #include <thread>
 #include <chrono>
 #include <hip/hip_ext.h>
@@ -32,12 +33,16 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     bool device_map = false;
     bool allow_device_map = true;  // FLS_IVOX_DEVICE_UPDATE=0: always the host path (A/B)
     size_t device_margin = 4096;   // voxels of head-room below the LRU capacity required to (re-)enter device mode (FLS_IVOX_DEVICE_MARGIN: test hook)
-    size_t n_device_updates = 0, n_host_fallbacks = 0;
+    size_t n_device_updates = 0, n_host_fallbacks = 0, n_device_evictions = 0;
+    bool device_evict = true;      // FLS_IVOX_DEVICE_EVICT=0: a batch that reaches the LRU capacity is refused (round-2 behaviour, with the margin rule)
+    DevicePairSort ev_sort;
+    DevBuf<unsigned> d_ev_bt;
     DevBuf<IvoxUpdState> d_upd_state;
     IvoxUpdMailbox* upd_mb_host = nullptr;
     IvoxUpdMailbox* upd_mb_dev = nullptr;
     unsigned upd_seq = 0;
     size_t dev_n_points = 0, dev_n_alive = 0;  // mirrored from the update mailbox
+    unsigned long long stamp_bound = 0;        // upper bound of every LRU stamp on the device (sizes the second sort round)
     DevBuf<uint2> d_lx, d_bt;
     DevBuf<unsigned> d_seq_src, d_seq_cell, d_jj, d_tlist;
     DevBuf<uint4> d_px, d_bt2;
@@ -88,6 +93,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (const char* e = std::getenv("FLS_HOST_TIMING")) host_timing = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_DEVICE_UPDATE")) allow_device_map = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_DEVICE_MARGIN")) { const long c = std::atol(e); if (c >= 0) device_margin = size_t(c); }
+        if (const char* e = std::getenv("FLS_IVOX_DEVICE_EVICT")) device_evict = std::atoi(e) != 0;
         d_upd_state.reserve(1);
         FLS_HIP(hipHostMalloc((void**)&upd_mb_host, sizeof(IvoxUpdMailbox), hipHostMallocMapped));
         std::memset(upd_mb_host, 0, sizeof(IvoxUpdMailbox));
@@ -140,7 +146,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     void enter_device_mode() {
         device_map = false;
         if (!allow_device_map || borrowed || !use_dense || !image.have_window || image.want_hash || p.is_localization_mode) return;
-        if (ivox.n_alive + device_margin >= ivox.capacity) return;  // evictions are near: the host path is the exact one
+        if (!device_evict && ivox.n_alive + device_margin >= ivox.capacity) return;  // without device evictions: stay clear of the capacity
+        if (ivox.capacity < 4) return;
         const unsigned long long stamp_base = image.upload_update_meta(ivox, stream);
         IvoxUpdState st{};
         st.n_points = ivox.n_points; st.used = image.used; st.garbage = image.garbage; st.stamp_base = stamp_base;
@@ -149,6 +156,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         FLS_HIP(hipMemcpyAsync(d_upd_state.p, &st, sizeof(st), hipMemcpyHostToDevice, stream));
         FLS_HIP(hipStreamSynchronize(stream));
         dev_n_points = ivox.n_points; dev_n_alive = ivox.n_alive;
+        stamp_bound = stamp_base;
         device_map = true;
     }
 
@@ -203,7 +211,29 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         hipLaunchKernelGGL(ivox_upd_scan1, dim3(1), dim3(kUpdMaxBlocks), 0, stream, b, nb, d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_seq, g, t, 0, stream, b, a, d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_plan, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
+        // LRU evictions inside the batch: whenever the batch COULD reach the capacity (every point a new voxel), the alive cells are
+        // listed and sorted by their 64-bit stamp (two stable 32-bit radix rounds) so that scan2 / ivox_evict_check can pick the tail
+        const bool may_evict = device_evict && dev_n_alive + n >= ivox.capacity && dev_n_alive > 0;
+        unsigned n_list = 0;
+        if (may_evict) {
+            const unsigned ncell = unsigned(image.n_cells_alloc), nbe = (ncell + kEvBlock - 1) / kEvBlock;
+            n_list = unsigned(dev_n_alive);
+            d_ev_bt.reserve(size_t(2) * nbe);
+            ev_sort.prepare(n_list);
+            hipLaunchKernelGGL(ivox_evict_count, dim3(nbe), dim3(kEvBlock), 0, stream, (const uint2*)image.d_cells.p, ncell, d_ev_bt.p);
+            hipLaunchKernelGGL(vg_scan, dim3(1), dim3(kVgScanBlock), 0, stream, (const unsigned*)d_ev_bt.p, d_ev_bt.p + nbe, int(nbe), (unsigned*)nullptr);
+            hipLaunchKernelGGL(ivox_evict_list, dim3(nbe), dim3(kEvBlock), 0, stream, (const uint2*)image.d_cells.p, (const unsigned long long*)image.d_stamp.p, ncell,
+                               (const unsigned*)(d_ev_bt.p + nbe), ev_sort.k0, ev_sort.v0);
+            ev_sort.run(4, stream);
+            hipLaunchKernelGGL(ivox_evict_hikeys, dim3((n_list + 255u) / 256u), dim3(256), 0, stream, (const unsigned long long*)image.d_stamp.p,
+                               (const unsigned*)ev_sort.v0, n_list, ev_sort.k0);
+            ev_sort.run(DevicePairSort::passes_for((unsigned long long)((stamp_bound + n) >> 32) + 1ull), stream);
+        }
+        hipLaunchKernelGGL(ivox_upd_set_evict, dim3(1), dim3(1), 0, stream, d_upd_state.p, may_evict ? 1u : 0u, n_list);
         hipLaunchKernelGGL(ivox_upd_scan2, dim3(1), dim3(kUpdMaxBlocks), 0, stream, b, d_upd_state.p);
+        if (may_evict) hipLaunchKernelGGL(ivox_evict_check, g, t, 0, stream, (const unsigned*)ev_sort.v0, a, d_upd_state.p);
+        hipLaunchKernelGGL(ivox_upd_decide, dim3(1), dim3(64), 0, stream, d_upd_state.p);
+        if (may_evict) hipLaunchKernelGGL(ivox_evict_apply, g, t, 0, stream, (const unsigned*)ev_sort.v0, a, d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_last, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_regions, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_points, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
@@ -225,6 +255,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (upd_mb_host->status != kUpdOk) return false;
         dev_n_points = size_t(upd_mb_host->n_points);
         dev_n_alive = size_t(upd_mb_host->n_alive);
+        stamp_bound += n;
+        n_device_evictions += upd_mb_host->evicted;
         ++n_device_updates;
         return true;
     }
@@ -580,6 +612,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (slot == 101) return n_full_rebuilds;  //                ... as full re-flatten + upload
         if (slot == 103) return n_device_updates;  //                ... by the device-side AddPoints
         if (slot == 104) return n_host_fallbacks;  //                batches the device refused (replayed on the host)
+        if (slot == 117) return n_device_evictions;  //              voxels evicted inside device batches
         if (slot == 102) return device_map ? dev_n_alive : ivox.n_alive;     // occupied voxels
         return device_map ? dev_n_points : ivox.n_points;
     }

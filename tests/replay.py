@@ -46,8 +46,9 @@ SCENARIOS = {
 }
 
 
-def make_replay(name: str, n_frames: int = None, yaw_long_deg: float = 4.0) -> dict:
-    """n_frames / yaw_long_deg: overrides for the long trajectories of tests/test_gpu_long_replay.py (a 9-degree yaw on the long
+def make_replay(name: str, n_frames: int = None, yaw_long_deg: float = 4.0, start=None, max_range: float = None, y_over=None) -> dict:
+    """start (4x4) / max_range / y_over (YAML overrides): a straight run with a short sensor range, for the LRU-at-capacity tests.
+    n_frames / yaw_long_deg: overrides for the long trajectories of tests/test_gpu_long_replay.py (a 9-degree yaw on the long
     steps bends the path into a circle of ~8.5 m radius that stays inside the 80 x 50 m room for any number of frames).
     returns dict(mode, y, init_clouds=[world clouds for the first AddCloudToLocalMap], frames=[dict(scan, corner, guess_step)])
     Frame k is Match(scan_k, T = T_prev_result @ guess_step_k): guess_step is the nominal motion, the true motion differs a little
@@ -57,7 +58,9 @@ def make_replay(name: str, n_frames: int = None, yaw_long_deg: float = 4.0) -> d
     rng = synth.rng_for(5, sc["rng_job"])
     lid = dict(synth.VELODYNE_64 if sc["lidar"] == "v64" else synth.VELODYNE_16, n_az=sc["n_az"])
     mode = sc["mode"]
-    T = np.eye(4)
+    if max_range is not None or y_over is not None:
+        sc = dict(sc, max_range=max_range if max_range is not None else sc["max_range"], y=dict(sc["y"], **(y_over or {})))
+    T = np.eye(4) if start is None else np.array(start, dtype=np.float64)
 
     def observe(Tw):
         scan = synth.cast_scan(scene, Tw, rng=rng, max_range=sc["max_range"], **lid)

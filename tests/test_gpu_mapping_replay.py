@@ -20,8 +20,8 @@ def _need_gpu(built):
     assert _lib.device_count() >= 1, "gpu tests need an MI355X (gfx950): the HIP path has no CPU fallback"
 
 
-def run_replay(name, monkeypatch=None):
-    r = replay.make_replay(name)
+def run_replay(name, monkeypatch=None, r=None, start=None):
+    r = r if r is not None else replay.make_replay(name)
     mode, y = r["mode"], r["y"]
     m = reg.make_matcher(mode, y)
     o = util.oracle_for(mode, y)
@@ -30,7 +30,7 @@ def run_replay(name, monkeypatch=None):
     slots = (0, 1) if mode == "LoamFull_KdTree" else (0,)
     for s in slots:
         assert m.map_size(s) == o.map_size(s), ("init", s)
-    Tprev = np.eye(4)
+    Tprev = np.eye(4) if start is None else np.array(start, dtype=np.float64)
     hist = []
     for k, f in enumerate(r["frames"]):
         guess = Tprev @ f["guess_step"]
@@ -111,18 +111,32 @@ def test_ndt_mapping_replay_device_refusal(monkeypatch):
 
 
 def test_ndt_mapping_replay_device_evictions():
-    """Capacity 2,600, default settings (round 3): the handle enters device mode after the first host update and STAYS there at the
-    capacity -- a batch whose creations reach the capacity evicts the least recently touched voxels on the device (rows sorted by
-    their 64-bit LRU stamp; incremental_ndt.h:202-206) as long as none of them is touched by the batch itself.  Every frame equals
-    the oracle (ids = voxel ids, n_valid, poses, map sizes), no batch is refused."""
-    r, h = run_replay("ndt")
+    """Round 3: LRU evictions INSIDE a device batch (incremental_ndt.h:202-206).  A straight 33 m run with a 20 m sensor range and a
+    capacity of 1,700 voxels: from frame ~17 on every scan creates 30-70 voxels and the same number of least recently touched ones
+    -- far behind the sensor, untouched by the batch -- are evicted on the device (rows sorted by their 64-bit LRU stamp, tombstoned
+    table entries).  The handle never leaves device mode: no refused batch; every frame equals the oracle (voxel ids, n_valid, poses,
+    map sizes)."""
+    start = np.eye(4)
+    start[1, 3] = 18.0  # the corridor between two rows of buildings
+    r = replay.make_replay("ndt_dev", n_frames=40, yaw_long_deg=0.0, start=start, max_range=20.0, y_over=dict(ndt_capacity=1700))
+    r, h = run_replay("ndt_dev", r=r, start=start)
     applied, refused = r["device_updates"]
     evicted, compactions = r["device_evictions"]
-    cap = r["y"]["ndt_capacity"]
-    assert h[-1]["size"] == cap - 1 and sum(1 for x in h if x["size"] == cap - 1) >= 4, "the LRU list must sit at capacity for several scans"
+    assert h[-1]["size"] == 1699 and sum(1 for x in h if x["size"] == 1699) >= 15, "the LRU list must sit at capacity for many scans"
     assert refused == 0 and applied >= len(h) - 1, (applied, refused)
-    assert evicted > 100, evicted
-    print(f"ndt at capacity {cap}: {applied} device batches, {refused} refused, {evicted} voxels evicted on the device, {compactions} compactions")
+    assert evicted > 500, evicted
+    print(f"ndt straight run at capacity 1700: {applied} device batches, {refused} refused, {evicted} voxels evicted on the device, {compactions} compactions")
+
+
+def test_ndt_mapping_replay_device_evictions_with_conflicts():
+    """The adversarial case: capacity 2,600 in a scene the sensor sees end to end, so the least recently touched voxels ARE touched by
+    nearly every batch.  Such a batch is refused untouched and replayed by the exact sequential host code; the handle returns to
+    device mode after eight host updates.  Results equal the oracle throughout (run_replay asserts every frame)."""
+    r, h = run_replay("ndt")
+    applied, refused = r["device_updates"]
+    cap = r["y"]["ndt_capacity"]
+    assert h[-1]["size"] == cap - 1 and sum(1 for x in h if x["size"] == cap - 1) >= 4
+    assert applied >= 1 and refused >= 1, (applied, refused)
 
 
 def test_ndt_mapping_replay_host_path_ab(monkeypatch):

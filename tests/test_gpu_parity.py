@@ -229,6 +229,7 @@ def test_mapping_replay_device_refuses_batch_that_would_evict(monkeypatch):
     would reach the capacity is refused BEFORE any state changes, the device image (points, voxel table, LRU stamps) is read back
     into the host mirror and the exact sequential path -- with evictions -- takes over.  Parity with the oracle throughout."""
     monkeypatch.setenv("FLS_IVOX_DEVICE_MARGIN", "64")  # (head-room below the capacity needed to run on the device; default 4096)
+    monkeypatch.setenv("FLS_IVOX_DEVICE_EVICT", "0")    # round-2 behaviour: evictions only on the host (the next tests run them on the device)
     m, o = _replay(8, monkeypatch=monkeypatch, capacity_over_initial=64 + 250)  # the scenario creates 86, 145, 190, ... 473 voxels
     assert m.map_size(103) >= 1, "some batches must have run on the device"
     assert m.map_size(104) >= 1, "a batch must have been refused and replayed on the host"
@@ -240,6 +241,45 @@ def test_mapping_replay_with_lru_eviction(monkeypatch):
     evicts voxels during the replay; evicted cells must disappear from the device image."""
     m, o = _replay(6, capacity=9000, monkeypatch=monkeypatch)
     assert o.map_voxels() <= 9000
+
+
+def test_mapping_replay_device_evictions_straight_run(monkeypatch):
+    """Round 3: LRU evictions INSIDE a device batch (ivox_map.cpp:133-136).  The map starts as one dense scan and grows along a
+    straight 33 m run with a 20 m sensor range; the capacity (5,000 voxels, test hook) is reached after ~15 scans, from then on
+    every scan creates 100-250 voxels and the same number of least recently touched ones are evicted ON THE DEVICE (alive cells
+    listed and sorted by their 64-bit LRU stamp; a batch that touches one of its own eviction candidates is refused and replayed on
+    the host).  Every Match equals the oracle: ids, flags, n_valid, poses, map points and voxel counts."""
+    from tests import replay
+    cap = 5000
+    monkeypatch.setenv("FLS_IVOX_CAPACITY", str(cap))
+    start = np.eye(4)
+    start[1, 3] = 18.0
+    r = replay.make_replay("ivox", n_frames=40, yaw_long_deg=0.0, start=start, max_range=20.0)
+    scene = synth.make_scene()
+    s0 = synth.cast_scan(scene, start, rng=synth.rng_for(5, 99), max_range=20.0, **dict(synth.VELODYNE_64, n_az=600))
+    init = (s0.astype(np.float64) @ start[:3, :3].T + start[:3, 3]).astype(np.float32)
+    m = reg.make_matcher("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+    o = util.oracle_for("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
+    o.set_ivox_capacity(cap)
+    m.AddCloudToLocalMap([init])
+    o.AddCloudToLocalMap(init)
+    Tp = start.copy()
+    at_cap = 0
+    for k, f in enumerate(r["frames"]):
+        guess = Tp @ f["guess_step"]
+        T = guess.copy()
+        ok = m.Match(reg.PointcloudCluster(planar_cloud_=f["scan"]), T, update_map=True)
+        ok_ref, T_ref = o.Match(f["scan"], guess, update_map=True)
+        util.assert_same_registration(m, o, ok, T, ok_ref, T_ref, sets_only_tail=True, max_tie_rows=int(o.counters().tie_queries))
+        assert m.map_size() == o.map_size() and m.map_size(102) == o.map_voxels(), (k, m.map_size(), o.map_size(), m.map_size(102), o.map_voxels())
+        at_cap += int(o.map_voxels() == cap - 1)
+        Tp = T_ref
+    applied, refused, evicted = m.map_size(103), m.map_size(104), m.map_size(117)
+    print(f"ivox straight run at capacity {cap}: {applied} device batches, {refused} refused, {evicted} voxels evicted on the device, {at_cap} scans at the capacity")
+    assert at_cap >= 15 and evicted > 1000, (at_cap, evicted)
+    assert refused <= 3, refused
+    m.close()
+    o.close()
 
 
 def test_map_export_import_gives_an_identical_handle():
