@@ -38,7 +38,7 @@ constexpr unsigned kUpdNoRank = 0xFFFFFFFFu;
 constexpr int kUpdBlock = 256;
 constexpr int kUpdMaxBlocks = 1024;  // one-workgroup scan of the block totals: n <= 262,144 source points per batch
 
-enum : unsigned { kUpdOk = 0u, kUpdNeedHost = 1u };
+enum : unsigned { kUpdOk = 0u, kUpdNeedHost = 1u, kUpdEvictConflict = 2u, kUpdArrayFull = 4u, kUpdOutside = 8u };  // any bit set: the batch is refused
 
 // persistent device-side bookkeeping of the map image + the per-batch scratch words
 struct IvoxUpdState {
@@ -163,7 +163,7 @@ ivox_upd_seq(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restri
     }
     b.seq_src[r] = (unsigned)i;
     b.seq_cell[r] = cell;
-    if (cell == kUpdInvalidCell) { atomicOr(&st->status, kUpdNeedHost); b.jj[r] = 0u; return; }
+    if (cell == kUpdInvalidCell) { atomicOr(&st->status, kUpdOutside); b.jj[r] = 0u; return; }
     b.jj[r] = atomicAdd(&a.pend[cell], 1u);
     atomicMin(&a.rank_mm[cell], r);
 }
@@ -213,7 +213,7 @@ ivox_upd_scan2(const IvoxUpdBatch b, IvoxUpdState* __restrict__ st) {
         // the count REACHES the capacity after a creation): with n alive voxels and k creations the batch evicts
         // E = max(0, n + k - (capacity - 1)) voxels; they are the E least recently touched ones as long as none of those is touched by
         // this batch (ivox_evict_check) -- the host queues the selection (alive cells sorted by stamp) whenever the batch could get there.
-        if (st->used + (unsigned long long)tot[0] > st->pts_capacity) status |= kUpdNeedHost;
+        if (st->used + (unsigned long long)tot[0] > st->pts_capacity) status |= kUpdArrayFull;
         const unsigned long long total = (unsigned long long)st->n_alive + tot[1];
         unsigned e = 0u;
         if (total >= (unsigned long long)st->lru_capacity) {
@@ -265,22 +265,67 @@ ivox_evict_hikeys(const unsigned long long* __restrict__ stamp, const unsigned* 
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) key[i] = (unsigned)(stamp[order[i]] >> 32);
 }
-// the E oldest voxels must not be touched by this batch (pend counts the batch's arrivals per cell)
-__global__ void __launch_bounds__(256)
-ivox_evict_check(const unsigned* __restrict__ order, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st) {
-    const unsigned j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= st->evict) return;
-    if (j >= st->n_list || a.pend[order[j]] != 0u) atomicOr(&st->status, kUpdNeedHost);
+// rank of every creation of the batch, in creation order: the i-th eviction happens right after creation number
+// (capacity - 1 - n_alive) + i (ivox_map.cpp:133-136)
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_cranks(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState* __restrict__ st, unsigned* __restrict__ crank) {
+    const unsigned A = st->n1 + st->n2;
+    const unsigned r = blockIdx.x * kUpdBlock + threadIdx.x;
+    if (r >= A || !b.fbit[r]) return;
+    const unsigned cell = b.seq_cell[r];
+    if (a.cells[cell].y != 0u) return;  // an existing voxel: no creation
+    crank[b.bt2[blockIdx.x].y + b.px[r].y] = r;
+}
+// Which voxels the batch evicts.  The candidates are the alive cells in LRU order (oldest first).  An UNTOUCHED candidate is the
+// next eviction.  A candidate the batch touches has moved to the list's front by the time the eviction pointer reaches it iff its
+// first touch (rank_mm = first rank, after ivox_upd_seq) precedes that eviction's creation: then the reference skips it -- exactly
+// what is done here; if the eviction comes first the reference evicts the voxel and the later touch re-creates it (one more creation,
+// one more eviction, different ids ...): that batch is refused and replayed by the sequential host code.  One workgroup, chunks of
+// 1024 candidates, a running count of untouched candidates = the eviction index a candidate maps to.
+__global__ void __launch_bounds__(kEvBlock)
+ivox_evict_select(const unsigned* __restrict__ order, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st, const unsigned* __restrict__ crank,
+                  unsigned* __restrict__ evict_list) {
+    __shared__ unsigned wsum[kEvBlock / 64];
+    __shared__ unsigned s_found;
+    const unsigned E = st->evict;
+    if (E == 0u || st->status != kUpdOk) return;
+    const unsigned n_list = st->n_list;
+    const unsigned base_c = st->lru_capacity - 1u > st->n_alive ? st->lru_capacity - 1u - st->n_alive : 0u;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_found = 0u;
+    __syncthreads();
+    for (unsigned j0 = 0; j0 < n_list; j0 += kEvBlock) {
+        const unsigned found = s_found;
+        if (found >= E) break;
+        const unsigned j = j0 + threadIdx.x;
+        const bool valid = j < n_list;
+        const unsigned cell = valid ? order[j] : 0u;
+        const bool un = valid && a.pend[cell] == 0u;
+        const unsigned long long m = __ballot(un);
+        if (lane == 0) wsum[w] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned before = 0u, total = 0u;
+        for (int q = 0; q < kEvBlock / 64; ++q) { const unsigned t = wsum[q]; if (q < w) before += t; total += t; }
+        const unsigned idx = found + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));  // evictions decided before this candidate
+        if (valid && idx < E) {
+            if (un) evict_list[idx] = cell;
+            else if (!(a.rank_mm[cell] < crank[base_c + idx])) atomicOr(&st->status, kUpdEvictConflict);  // evicted first, re-created later: host
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_found = found + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && s_found < E) atomicOr(&st->status, kUpdNeedHost);
 }
 __global__ void ivox_upd_set_evict(IvoxUpdState* __restrict__ st, const unsigned ready, const unsigned n_list) { st->evict_ready = ready; st->n_list = n_list; }
 __global__ void ivox_upd_decide(IvoxUpdState* __restrict__ st) {
     if (threadIdx.x == 0 && blockIdx.x == 0) st->apply = st->status == kUpdOk ? 1u : 0u;
 }
 __global__ void __launch_bounds__(256)
-ivox_evict_apply(const unsigned* __restrict__ order, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st) {
+ivox_evict_apply(const unsigned* __restrict__ evict_list, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st) {
     const unsigned j = blockIdx.x * 256 + threadIdx.x;
     if (!st->apply || j >= st->evict) return;
-    const unsigned cell = order[j];
+    const unsigned cell = evict_list[j];
     const uint2 e = a.cells[cell];
     const unsigned cl = a.cap_log2[cell];
     atomicAdd(&st->evicted_points, (unsigned long long)e.y);

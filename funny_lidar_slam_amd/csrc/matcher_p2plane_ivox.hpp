@@ -33,10 +33,10 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     bool device_map = false;
     bool allow_device_map = true;  // FLS_IVOX_DEVICE_UPDATE=0: always the host path (A/B)
     size_t device_margin = 4096;   // voxels of head-room below the LRU capacity required to (re-)enter device mode (FLS_IVOX_DEVICE_MARGIN: test hook)
-    size_t n_device_updates = 0, n_host_fallbacks = 0, n_device_evictions = 0;
+    size_t n_device_updates = 0, n_host_fallbacks = 0, n_device_evictions = 0, n_refused_conflict = 0, n_refused_full = 0, n_refused_outside = 0;
     bool device_evict = true;      // FLS_IVOX_DEVICE_EVICT=0: a batch that reaches the LRU capacity is refused (round-2 behaviour, with the margin rule)
     DevicePairSort ev_sort;
-    DevBuf<unsigned> d_ev_bt;
+    DevBuf<unsigned> d_ev_bt, d_crank, d_evict_list;
     DevBuf<IvoxUpdState> d_upd_state;
     IvoxUpdMailbox* upd_mb_host = nullptr;
     IvoxUpdMailbox* upd_mb_dev = nullptr;
@@ -231,9 +231,14 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         }
         hipLaunchKernelGGL(ivox_upd_set_evict, dim3(1), dim3(1), 0, stream, d_upd_state.p, may_evict ? 1u : 0u, n_list);
         hipLaunchKernelGGL(ivox_upd_scan2, dim3(1), dim3(kUpdMaxBlocks), 0, stream, b, d_upd_state.p);
-        if (may_evict) hipLaunchKernelGGL(ivox_evict_check, g, t, 0, stream, (const unsigned*)ev_sort.v0, a, d_upd_state.p);
+        if (may_evict) {
+            d_crank.reserve(n);
+            d_evict_list.reserve(n);
+            hipLaunchKernelGGL(ivox_upd_cranks, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p, d_crank.p);
+            hipLaunchKernelGGL(ivox_evict_select, dim3(1), dim3(kEvBlock), 0, stream, (const unsigned*)ev_sort.v0, a, d_upd_state.p, (const unsigned*)d_crank.p, d_evict_list.p);
+        }
         hipLaunchKernelGGL(ivox_upd_decide, dim3(1), dim3(64), 0, stream, d_upd_state.p);
-        if (may_evict) hipLaunchKernelGGL(ivox_evict_apply, g, t, 0, stream, (const unsigned*)ev_sort.v0, a, d_upd_state.p);
+        if (may_evict) hipLaunchKernelGGL(ivox_evict_apply, g, t, 0, stream, (const unsigned*)d_evict_list.p, a, d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_last, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_regions, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_points, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
@@ -252,7 +257,12 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             __builtin_ia32_pause();
 #endif
         }
-        if (upd_mb_host->status != kUpdOk) return false;
+        if (upd_mb_host->status != kUpdOk) {
+            if (upd_mb_host->status & kUpdEvictConflict) ++n_refused_conflict;
+            if (upd_mb_host->status & kUpdArrayFull) ++n_refused_full;
+            if (upd_mb_host->status & kUpdOutside) ++n_refused_outside;
+            return false;
+        }
         dev_n_points = size_t(upd_mb_host->n_points);
         dev_n_alive = size_t(upd_mb_host->n_alive);
         stamp_bound += n;
@@ -613,6 +623,9 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (slot == 103) return n_device_updates;  //                ... by the device-side AddPoints
         if (slot == 104) return n_host_fallbacks;  //                batches the device refused (replayed on the host)
         if (slot == 117) return n_device_evictions;  //              voxels evicted inside device batches
+        if (slot == 119) return n_refused_conflict;  //              refusals by reason: eviction order conflict / point array full / point outside the window
+        if (slot == 120) return n_refused_full;
+        if (slot == 121) return n_refused_outside;
         if (slot == 102) return device_map ? dev_n_alive : ivox.n_alive;     // occupied voxels
         return device_map ? dev_n_points : ivox.n_points;
     }

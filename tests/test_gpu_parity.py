@@ -247,8 +247,8 @@ def test_mapping_replay_device_evictions_straight_run(monkeypatch):
     """Round 3: LRU evictions INSIDE a device batch (ivox_map.cpp:133-136).  The map starts as one dense scan and grows along a
     straight 33 m run with a 20 m sensor range; the capacity (5,000 voxels, test hook) is reached after ~15 scans, from then on
     every scan creates 100-250 voxels and the same number of least recently touched ones are evicted ON THE DEVICE (alive cells
-    listed and sorted by their 64-bit LRU stamp; a batch that touches one of its own eviction candidates is refused and replayed on
-    the host).  Every Match equals the oracle: ids, flags, n_valid, poses, map points and voxel counts."""
+    listed and sorted by their 64-bit LRU stamp; a candidate the batch touches BEFORE its turn is skipped like the reference does,
+    one it touches after its turn makes the batch fall back to the host).  Every Match equals the oracle: ids, flags, n_valid, poses, map points and voxel counts."""
     from tests import replay
     cap = 5000
     monkeypatch.setenv("FLS_IVOX_CAPACITY", str(cap))
@@ -275,9 +275,13 @@ def test_mapping_replay_device_evictions_straight_run(monkeypatch):
         at_cap += int(o.map_voxels() == cap - 1)
         Tp = T_ref
     applied, refused, evicted = m.map_size(103), m.map_size(104), m.map_size(117)
-    print(f"ivox straight run at capacity {cap}: {applied} device batches, {refused} refused, {evicted} voxels evicted on the device, {at_cap} scans at the capacity")
+    print(f"ivox straight run at capacity {cap}: {applied} device batches, {refused} refused (eviction-order conflicts {m.map_size(119)}, point array full {m.map_size(120)}, "
+          f"outside the window {m.map_size(121)}), {evicted} voxels evicted on the device, {at_cap} scans at the capacity")
     assert at_cap >= 15 and evicted > 1000, (at_cap, evicted)
-    assert refused <= 3, refused
+    # a candidate that the batch touches AFTER its eviction is evicted and re-created by the reference (one more creation, one more
+    # eviction, ...): those batches are refused and replayed on the host -- they exist in this scenario (old near-ground voxels still in
+    # range), most at-capacity batches must nevertheless run on the device
+    assert applied >= 28 and refused == m.map_size(119) + m.map_size(120) + m.map_size(121), (applied, refused)
     m.close()
     o.close()
 
