@@ -535,9 +535,11 @@ __device__ __forceinline__ void icp_point_terms(const double (&T)[16], const flo
 // search grid writes one partial row (rows of idle workgroups are zero), gn_solve_lu_kernel sums them in row order.
 __global__ void __launch_bounds__(256)
 icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
-                   const GnState* __restrict__ st, const int first, const Pose16 T0, const CellGridDev cg, const float gate, const double max_corr /* squared */,
-                   int* __restrict__ nn_id, unsigned char* __restrict__ eff, double* __restrict__ partials) {
+                   GnState* __restrict__ st, const int first, const Pose16 T0, const CellGridDev cg, const float gate, const double max_corr /* squared */,
+                   int* __restrict__ nn_id, unsigned char* __restrict__ eff, double* __restrict__ partials,
+                   unsigned* __restrict__ ticket /* nullptr: the tail runs as its own launch */, const int shards, const LuTailArgs tail) {
     const int done = first ? 0 : st->done;
+    const int it = first ? 0 : st->iter;
     if (done) return;  // uniform over the launch
     __shared__ double wsum[4][32];
     GridKnnLane r;
@@ -571,7 +573,14 @@ icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
     for (int k = 0; k < 6; ++k) { const double v = wave_sum_dpp(Bc[k]); if (lane == 63) row[21 + k] = v; }
     const double sr = wave_sum_dpp(res), sc = wave_sum_dpp(contrib ? 1.0 : 0.0);
     if (lane == 63) { row[27] = sr; row[28] = sc; }
-    block_row_from_wave_sums(wsum, partials);
+    if (!ticket) { block_row_from_wave_sums(wsum, partials); return; }
+    // fused Gauss-Newton tail (round 3): the row goes out write-through, the last workgroup to arrive solves and publishes
+    __syncthreads();
+    const double v = threadIdx.x < 29 ? ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x] : 0.0;
+    __shared__ unsigned s_ticket;
+    __shared__ LuTailSmem sm;
+    if (!publish_row_and_arrive(v, threadIdx.x < 29, partials, ticket, shards, s_ticket)) return;
+    lu_tail<256, true>(st, sm, partials, (int)gridDim.x, tail, T, it);
 }
 
 __global__ void __launch_bounds__(256)

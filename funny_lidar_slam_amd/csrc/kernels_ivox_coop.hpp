@@ -422,7 +422,6 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
 // The ticket counters (kTicketWords unsigned words) are reset by their last arrivers, so they are zero at every launch.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFitThreads = 512;
-constexpr int kTicketWords = 32 * 10;  // [0] single counter (shards <= 1) | [32 (1 + s)] shard s | [32 * 9] top counter
 template <bool FIRST>
 __global__ void __launch_bounds__(kFitThreads)
 p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
@@ -496,30 +495,8 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
     __syncthreads();
-    // Sharded fan-in: 225 arrivals on ONE device-scope counter serialise at ~12 ns each (the last arriver waits ~3 us behind the
-    // others -- all workgroups finish their fit phase within 0.4 us of each other); eight counters (shard = blockIdx & 7, the XCD the
-    // workgroup normally runs on -- a speed matter only, every atomic is agent scope) take ~28 arrivals each in parallel, the last
-    // arriver of a shard moves on to the top counter, and the last of those is the reducer.  Counters sit 128 bytes apart and are
-    // reset by their last arriver, so they are zero at every launch.
-    if (threadIdx.x == 0) {
-        unsigned last = 0u;
-        if (shards <= 1) {
-            last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-            if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            const unsigned sh = blockIdx.x & 7u, nsh = (gridDim.x - sh + 7u) >> 3, ntop = gridDim.x < 8u ? gridDim.x : 8u;
-            unsigned* const cs = ticket + 32u * (1u + sh);
-            unsigned* const ct = ticket + 32u * 9u;
-            if (__hip_atomic_fetch_add(cs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1u) {
-                __hip_atomic_store(cs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__hip_atomic_fetch_add(ct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ntop - 1u) {
-                    __hip_atomic_store(ct, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    last = 1u;
-                }
-            }
-        }
-        s_ticket = last;
-    }
+    // sharded fan-in (kernels_p2plane.hpp::fanin_last_arriver): which workgroup arrives last
+    if (threadIdx.x == 0) s_ticket = fanin_last_arriver(ticket, shards);
     __syncthreads();
     if (!s_ticket) return;
     // ---- last workgroup: Gauss-Newton tail (reads the rows with sc1 loads: no acquire fence either) ----

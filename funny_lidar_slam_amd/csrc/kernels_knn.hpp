@@ -367,6 +367,102 @@ ndt_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const flo
     if (COUNT) count_traffic(tc, c_p, c_h, c_c);
 }
 
+// ---------------------------------------------------------------------------------------------
+// ICP / NDT Gauss-Newton tail.  mode 0 = IcpOptimized (state [dt, dtheta], det==0 skip, converged
+// flag), mode 1 = IncrementalNDT (state [dtheta, dt], min_effective early-out).  Both right-multiply.
+// ---------------------------------------------------------------------------------------------
+struct LuTailSmem {
+    double red[32][33];
+    double tot[32];
+    double Hs[36], inv[36], gs[6], xs[6];
+    int tr[6];
+};
+struct LuTailArgs {  // what the tail needs besides the rows (one struct so that the fused kernels stay readable)
+    int mode;            // 0 = IcpOptimized, 1 = IncrementalNDT
+    double rot_thr, pos_thr;
+    int min_effective;
+    Mailbox* mb;
+    unsigned match_id;   // launch word: max_iterations << 24 | exact-solver flag << 23 | match id
+};
+// executed by a whole workgroup of NT threads (all reduce the rows, wave 0 solves); SC1: the rows were published write-through by
+// other workgroups of the SAME launch (fused search + fit + tail kernels)
+template <int NT, bool SC1>
+__device__ __forceinline__ void lu_tail(GnState* __restrict__ st, LuTailSmem& sm, const double* __restrict__ partials, const int nrows, const LuTailArgs a,
+                                        double (&Tl)[16], const int it) {
+    double (&red)[32][33] = sm.red;
+    double (&tot)[32] = sm.tot;
+    double (&Hs)[36] = sm.Hs;
+    double (&inv)[36] = sm.inv;
+    double (&gs)[6] = sm.gs;
+    double (&xs)[6] = sm.xs;
+    int (&tr)[6] = sm.tr;
+    const int mode = a.mode, min_effective = a.min_effective;
+    const double rot_thr = a.rot_thr, pos_thr = a.pos_thr;
+    Mailbox* const mb = a.mb;
+    const unsigned match_id = a.match_id;
+    reduce_partials<NT, SC1>(partials, nrows, tot, red);
+    if (threadIdx.x >= 64) return;  // wave 0 only
+    const int lane = threadIdx.x;
+    if (lane < 36) {
+        const int i = lane % 6, j = lane / 6;
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        const int k = a * 6 - (a * (a - 1)) / 2 + (b - a);
+        Hs[lane] = tot[k];
+        st->H[lane] = tot[k];
+    }
+    if (lane < 6) { gs[lane] = tot[21 + lane]; st->g[lane] = tot[21 + lane]; }
+    __builtin_amdgcn_wave_barrier();
+    const int effective = (int)tot[28];
+    const double sres = tot[27];
+    const bool early_fail = (mode == 1 && effective < min_effective);  // incremental_ndt.h:306-309: T = pose; return false
+    double det = 1.0;
+    if (!early_fail) {
+        // SPD fast path (kernels_p2plane.hpp::ldlt_solve6_lane): positive pivots imply det(H) > 0, so the reference's exact
+        // det == 0 test (icp_optimized.h:129, Q14) cannot fire; anything else goes through the restated LU inverse
+        int fast = 0;
+        if (lane == 0 && !((match_id >> 23) & 1u)) fast = ldlt_solve6_lane(Hs, gs, xs) ? 1 : 0;
+        fast = __shfl(fast, 0, 64);
+        if (!fast) det = lu6_solve_wave(Hs, inv, gs, xs, tr);
+    }
+    if (lane == 0) {
+        st->n_valid = effective;
+        st->sum_res = sres;
+        int stop = 0, conv = 0;
+        double dxo[6] = {0, 0, 0, 0, 0, 0};
+        if (early_fail) {
+            stop = 1;
+        } else if (mode == 0 && det == 0.0) {
+            // icp_optimized.h:129-131: skip the update, keep iterating
+        } else {
+            double dx[6];
+            for (int q = 0; q < 6; ++q) dx[q] = xs[q];
+            const double* dth = (mode == 0) ? dx + 3 : dx;
+            const double* dt = (mode == 0) ? dx : dx + 3;
+            double Rd[9], R[9], Rn[9];
+            if (mode == 0) { Tl[12] += dt[0]; Tl[13] += dt[1]; Tl[14] += dt[2]; }
+            so3_exp_dev(dth, Rd);
+            for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) R[i + j * 3] = Tl[i + j * 4];
+            mat3_mul_dev(R, Rd, Rn);  // right-multiplicative
+            for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) Tl[i + j * 4] = Rn[i + j * 3];
+            if (mode == 1) { Tl[12] += dt[0]; Tl[13] += dt[1]; Tl[14] += dt[2]; }
+            for (int q = 0; q < 6; ++q) { st->last_dx[q] = dx[q]; dxo[q] = dx[q]; }
+            if (norm3d(dth) < rot_thr && norm3d(dt) < pos_thr) { stop = 1; conv = 1; }
+        }
+        for (int q = 0; q < 16; ++q) st->T[q] = Tl[q];
+        st->done = stop;
+        st->converged = conv;
+        if (it < kMaxIter) {
+            for (int q = 0; q < 16; ++q) st->log_T[it][q] = Tl[q];
+            st->log_nv[it] = effective;
+            st->log_res[it] = sres;
+        }
+        st->iter = it + 1;
+        if (mb) {
+            mailbox_publish(mb, Tl, dxo, sres, 0.0, it + 1, stop, conv, effective, 0, match_id);  // launch word: max_iterations << 24 | match id
+        }
+    }
+}
+
 // ndt_lanes_kernel: the same per-point lambda with ONE LANE PER NEIGHBOUR VOXEL (8 lanes per point, lane 7 idle): the seven
 // dependent look-up chains of a point (table probe -> mean / information -> Mahalanobis gate -> J^T Sigma^-1 J) run side by side
 // and the launch has eight times the waves of ndt_kernel (which runs 29k points as 457 single-wave workgroups, under one wave
@@ -376,12 +472,14 @@ ndt_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const flo
 constexpr int kNdtLanesBlock = 512;
 __global__ void __launch_bounds__(kNdtLanesBlock)
 ndt_lanes_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
-                 const GnState* __restrict__ st, const int first, const Pose16 T0, const NdtGridDev ng, const double outlier_thr,
-                 int* __restrict__ hit_vid /* [n][7] */, unsigned char* __restrict__ eff7 /* [n][7] */, double* __restrict__ partials) {
+                 GnState* __restrict__ st, const int first, const Pose16 T0, const NdtGridDev ng, const double outlier_thr,
+                 int* __restrict__ hit_vid /* [n][7] */, unsigned char* __restrict__ eff7 /* [n][7] */, double* __restrict__ partials,
+                 unsigned* __restrict__ ticket /* nullptr: the tail runs as its own launch */, const int shards, const LuTailArgs tail) {
     const int done = first ? 0 : st->done;
     double P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) P[k] = first ? T0.m[k] : st->T[k];
+    const int it = first ? 0 : st->iter;
     if (done) return;
     __shared__ double wsum[kNdtLanesBlock / 64][32];
     const int i = (blockIdx.x * kNdtLanesBlock + threadIdx.x) >> 3, k = threadIdx.x & 7;
@@ -462,18 +560,20 @@ ndt_lanes_kernel(const float* __restrict__ sx, const float* __restrict__ sy, con
     const double sr = wave_sum_dpp(res), sc = wave_sum_dpp(cnt);
     if (lane == 63) { row[27] = sr; row[28] = sc; }
     __syncthreads();
+    double v = 0.0;
     if (threadIdx.x < 29) {
-        double v = 0.0;
 #pragma unroll
         for (int w = 0; w < kNdtLanesBlock / 64; ++w) v += wsum[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
+        if (!ticket) partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
     }
+    if (!ticket) return;
+    // fused Gauss-Newton tail (round 3): the row goes out write-through, the last workgroup to arrive solves and publishes
+    __shared__ unsigned s_ticket;
+    __shared__ LuTailSmem sm;
+    if (!publish_row_and_arrive(v, threadIdx.x < 29, partials, ticket, shards, s_ticket)) return;
+    lu_tail<kNdtLanesBlock, true>(st, sm, partials, (int)gridDim.x, tail, P, it);
 }
 
-// ---------------------------------------------------------------------------------------------
-// ICP / NDT Gauss-Newton tail.  mode 0 = IcpOptimized (state [dt, dtheta], det==0 skip, converged
-// flag), mode 1 = IncrementalNDT (state [dtheta, dt], min_effective early-out).  Both right-multiply.
-// ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
 gn_solve_lu_kernel(GnState* __restrict__ st, const int first, const Pose16 T0, const double* __restrict__ partials, const int nrows,
                    const int mode, const double rot_thr, const double pos_thr, const int min_effective, Mailbox* __restrict__ mb,
@@ -484,71 +584,8 @@ gn_solve_lu_kernel(GnState* __restrict__ st, const int first, const Pose16 T0, c
     for (int q = 0; q < 16; ++q) Tl[q] = first ? T0.m[q] : st->T[q];
     const int it = first ? 0 : st->iter;
     if (done) return;
-    __shared__ double red[32][33];
-    __shared__ double tot[32];
-    __shared__ double Hs[36], inv[36], gs[6], xs[6];
-    __shared__ int tr[6];
-    reduce_partials<kSolveThreads>(partials, nrows, tot, red);
-    if (threadIdx.x >= 64) return;  // wave 0 only
-    const int lane = threadIdx.x;
-    if (lane < 36) {
-        const int i = lane % 6, j = lane / 6;
-        const int a = i < j ? i : j, b = i < j ? j : i;
-        const int k = a * 6 - (a * (a - 1)) / 2 + (b - a);
-        Hs[lane] = tot[k];
-        st->H[lane] = tot[k];
-    }
-    if (lane < 6) { gs[lane] = tot[21 + lane]; st->g[lane] = tot[21 + lane]; }
-    __builtin_amdgcn_wave_barrier();
-    const int effective = (int)tot[28];
-    const double sres = tot[27];
-    const bool early_fail = (mode == 1 && effective < min_effective);  // incremental_ndt.h:306-309: T = pose; return false
-    double det = 1.0;
-    if (!early_fail) {
-        // SPD fast path (kernels_p2plane.hpp::ldlt_solve6_lane): positive pivots imply det(H) > 0, so the reference's exact
-        // det == 0 test (icp_optimized.h:129, Q14) cannot fire; anything else goes through the restated LU inverse
-        int fast = 0;
-        if (lane == 0 && !((match_id >> 23) & 1u)) fast = ldlt_solve6_lane(Hs, gs, xs) ? 1 : 0;
-        fast = __shfl(fast, 0, 64);
-        if (!fast) det = lu6_solve_wave(Hs, inv, gs, xs, tr);
-    }
-    if (lane == 0) {
-        st->n_valid = effective;
-        st->sum_res = sres;
-        int stop = 0, conv = 0;
-        double dxo[6] = {0, 0, 0, 0, 0, 0};
-        if (early_fail) {
-            stop = 1;
-        } else if (mode == 0 && det == 0.0) {
-            // icp_optimized.h:129-131: skip the update, keep iterating
-        } else {
-            double dx[6];
-            for (int q = 0; q < 6; ++q) dx[q] = xs[q];
-            const double* dth = (mode == 0) ? dx + 3 : dx;
-            const double* dt = (mode == 0) ? dx : dx + 3;
-            double Rd[9], R[9], Rn[9];
-            if (mode == 0) { Tl[12] += dt[0]; Tl[13] += dt[1]; Tl[14] += dt[2]; }
-            so3_exp_dev(dth, Rd);
-            for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) R[i + j * 3] = Tl[i + j * 4];
-            mat3_mul_dev(R, Rd, Rn);  // right-multiplicative
-            for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) Tl[i + j * 4] = Rn[i + j * 3];
-            if (mode == 1) { Tl[12] += dt[0]; Tl[13] += dt[1]; Tl[14] += dt[2]; }
-            for (int q = 0; q < 6; ++q) { st->last_dx[q] = dx[q]; dxo[q] = dx[q]; }
-            if (norm3d(dth) < rot_thr && norm3d(dt) < pos_thr) { stop = 1; conv = 1; }
-        }
-        for (int q = 0; q < 16; ++q) st->T[q] = Tl[q];
-        st->done = stop;
-        st->converged = conv;
-        if (it < kMaxIter) {
-            for (int q = 0; q < 16; ++q) st->log_T[it][q] = Tl[q];
-            st->log_nv[it] = effective;
-            st->log_res[it] = sres;
-        }
-        st->iter = it + 1;
-        if (mb) {
-            mailbox_publish(mb, Tl, dxo, sres, 0.0, it + 1, stop, conv, effective, 0, match_id);  // launch word: max_iterations << 24 | match id
-        }
-    }
+    __shared__ LuTailSmem sm;
+    lu_tail<kSolveThreads, false>(st, sm, partials, nrows, LuTailArgs{mode, rot_thr, pos_thr, min_effective, mb, match_id}, Tl, it);
 }
 
 }  // namespace fls

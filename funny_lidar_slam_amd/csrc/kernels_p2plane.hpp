@@ -129,6 +129,40 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
     __syncthreads();
 }
 
+// Sharded fan-in of a launch's workgroups ("am I the last one to arrive?"): 225-450 arrivals on ONE device-scope counter serialise at
+// ~12 ns each and the last arriver waits microseconds behind the others; eight counters (shard = blockIdx & 7, the XCD the workgroup
+// normally runs on -- a speed matter only, every atomic is agent scope) take their arrivals in parallel, the last arriver of a shard
+// moves on to the top counter, the last of those is THE last.  Counters sit 128 bytes apart and are reset by their last arriver, so
+// they are zero at every launch.  Call with one thread after the workgroup's row is published and drained; kTicketWords words.
+constexpr int kTicketWords = 32 * 10;  // [0] single counter (shards <= 1) | [32 (1 + s)] shard s | [32 * 9] top counter
+__device__ __forceinline__ unsigned fanin_last_arriver(unsigned* __restrict__ ticket, const int shards) {
+    if (shards <= 1) {
+        const unsigned last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return last;
+    }
+    const unsigned sh = blockIdx.x & 7u, nsh = (gridDim.x - sh + 7u) >> 3, ntop = gridDim.x < 8u ? gridDim.x : 8u;
+    unsigned* const cs = ticket + 32u * (1u + sh);
+    unsigned* const ct = ticket + 32u * 9u;
+    if (__hip_atomic_fetch_add(cs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nsh - 1u) return 0u;
+    __hip_atomic_store(cs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(ct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ntop - 1u) return 0u;
+    __hip_atomic_store(ct, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 1u;
+}
+// publish one partial row write-through (sc1) + drain + ticket: returns (uniformly over the workgroup) whether this workgroup is the last
+__device__ __forceinline__ bool publish_row_and_arrive(const double v, const bool has_value, double* __restrict__ partials, unsigned* __restrict__ ticket,
+                                                       const int shards, unsigned& s_ticket) {
+    if (has_value)
+        __hip_atomic_store((unsigned long long*)partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, (unsigned long long)__double_as_longlong(v),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = fanin_last_arriver(ticket, shards);
+    __syncthreads();
+    return s_ticket != 0u;
+}
+
 #ifdef FLS_TIMING
 #define FLS_STAMP(k) do { if (threadIdx.x == 0) st->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
 #else

@@ -70,6 +70,8 @@ struct NdtMatcher final : fls_matcher {
     SourceFilter src_filter;
     bool host_timing = false;  // FLS_HOST_TIMING=1: print the host-side split of every map update
     bool lanes_kernel = true;  // FLS_NDT_LANES=0: one lane per point (ndt_kernel) instead of one lane per neighbour voxel
+    bool fused_tail = true;    // FLS_FUSED_TAIL=0: the Gauss-Newton tail as its own launch (gn_solve_lu_kernel) instead of the correspondence kernel's last workgroup
+    DevBuf<unsigned> d_ticket;
     DevBuf<int> d_hit_vid;
     DevBuf<unsigned char> d_eff7;
     double final_T[16]{};
@@ -87,6 +89,9 @@ struct NdtMatcher final : fls_matcher {
         src_filter.init();
         if (const char* e = std::getenv("FLS_HOST_TIMING")) host_timing = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_NDT_LANES")) lanes_kernel = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_FUSED_TAIL")) fused_tail = std::atoi(e) != 0;
+        d_ticket.reserve(kTicketWords);
+        FLS_HIP(hipMemsetAsync(d_ticket.p, 0, kTicketWords * sizeof(unsigned), stream));
         if (const char* e = std::getenv("FLS_NDT_DEVICE_UPDATE")) allow_device_update = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_NDT_DEVICE_MARGIN")) { const long c = std::atol(e); if (c >= 0) device_margin = size_t(c); }
         if (const char* e = std::getenv("FLS_NDT_DEVICE_EVICT")) device_evict = std::atoi(e) != 0;
@@ -624,8 +629,13 @@ struct NdtMatcher final : fls_matcher {
         const unsigned word = run_mailbox_loop(int(p.max_iterations), n, [&](int it, int first) {
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
             if (nblk > 0 && lanes_kernel && !count_traffic) {  // one lane per neighbour voxel (64 points per workgroup: same row count)
-                hipLaunchKernelGGL(ndt_lanes_kernel, dim3(nblk), dim3(kNdtLanesBlock), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), (const GnState*)d_state.p, first,
-                                   T0, ng, p.ndt_res_outlier_threshold, d_hit_vid.p, d_eff7.p, d_partials_b.p);
+                const LuTailArgs tail{1, p.rotation_converge_thres, p.position_converge_thres, p.ndt_min_effective_pts, mb_dev, launch_word()};
+                hipLaunchKernelGGL(ndt_lanes_kernel, dim3(nblk), dim3(kNdtLanesBlock), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, first,
+                                   T0, ng, p.ndt_res_outlier_threshold, d_hit_vid.p, d_eff7.p, d_partials_b.p, fused_tail ? d_ticket.p : (unsigned*)nullptr, 8, tail);
+                if (fused_tail) {  // the last workgroup ran the Gauss-Newton tail: one launch per iteration
+                    if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
+                    return;
+                }
             } else if (nblk > 0) {
                 if (count_traffic)
                     hipLaunchKernelGGL(ndt_kernel<true>, dim3(nblk), dim3(64), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, first, T0, ng,

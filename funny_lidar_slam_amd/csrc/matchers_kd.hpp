@@ -34,6 +34,8 @@ struct IcpMatcher final : fls_matcher {
     size_t local_map_n = 0;  // points of the local map (the host vector is not produced on the device path)
     bool have_map = false;
     bool fused = true;  // FLS_ICP_FUSED=0: separate correspondence and fit launches
+    bool fused_tail = true;  // FLS_FUSED_TAIL=0: gn_solve_lu_kernel as its own launch
+    DevBuf<unsigned> d_ticket;
     const IcpMatcher* owner = nullptr;  // batch lane: reads the owner's map grid
     DevScan scan;
     size_t raw_n = 0;
@@ -55,6 +57,9 @@ struct IcpMatcher final : fls_matcher {
         src_filter.init();
         mapdev.init();
         if (const char* e = std::getenv("FLS_ICP_FUSED")) fused = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_FUSED_TAIL")) fused_tail = std::atoi(e) != 0;
+        d_ticket.reserve(kTicketWords);
+        FLS_HIP(hipMemsetAsync(d_ticket.p, 0, kTicketWords * sizeof(unsigned), stream));
         return FLS_OK;
     }
     fls_status add_cloud_impl(const std::vector<PtI>& new_cloud) {  // :165-189
@@ -115,9 +120,12 @@ struct IcpMatcher final : fls_matcher {
         const unsigned word = run_mailbox_loop(int(p.max_iterations), n, [&](int it, int first) {
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
             if (fused) {  // search + fit in one launch: one partial row per workgroup of the search grid
-                hipLaunchKernelGGL(icp_knn_fit_kernel, knn_grid_dim, dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), (const GnState*)d_state.p, first,
-                                   T0, cg, float(p.point_search_thres), p.point_search_thres, d_nn_id.p, d_eff.p, d_partials_b.p);
+                const LuTailArgs tail{0, p.rotation_converge_thres, p.position_converge_thres, 0, mb_dev, launch_word()};
+                hipLaunchKernelGGL(icp_knn_fit_kernel, knn_grid_dim, dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, first,
+                                   T0, cg, float(p.point_search_thres), p.point_search_thres, d_nn_id.p, d_eff.p, d_partials_b.p,
+                                   fused_tail ? d_ticket.p : (unsigned*)nullptr, 8, tail);
                 if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
+                if (fused_tail) return;  // ... and the Gauss-Newton tail in its last workgroup: one launch per iteration
                 hipLaunchKernelGGL(gn_solve_lu_kernel, dim3(1), dim3(kSolveThreads), 0, stream, d_state.p, first, T0, (const double*)d_partials_b.p,
                                    int(knn_grid_dim.x), 0, p.rotation_converge_thres, p.position_converge_thres, 0, mb_dev, launch_word());
                 return;
