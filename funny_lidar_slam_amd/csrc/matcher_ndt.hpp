@@ -70,7 +70,9 @@ struct NdtMatcher final : fls_matcher {
     SourceFilter src_filter;
     bool host_timing = false;  // FLS_HOST_TIMING=1: print the host-side split of every map update
     bool lanes_kernel = true;  // FLS_NDT_LANES=0: one lane per point (ndt_kernel) instead of one lane per neighbour voxel
-    bool fused_tail = true;    // FLS_FUSED_TAIL=0: the Gauss-Newton tail as its own launch (gn_solve_lu_kernel) instead of the correspondence kernel's last workgroup
+    bool fused_tail = false;   // FLS_FUSED_TAIL=1: the Gauss-Newton tail in the correspondence kernel's last workgroup instead of its own launch (gn_solve_lu_kernel).
+                               // Measured on configs[2] (457 workgroups of 512 threads): 83.9 us per Match fused vs 76-80 us with the separate 6.6 us launch -- the
+                               // write-through rows + fan-in + in-kernel tail cost more than the boundary they remove; IcpOptimized (205 small workgroups) gains 6 %.
     DevBuf<unsigned> d_ticket;
     DevBuf<int> d_hit_vid;
     DevBuf<unsigned char> d_eff7;
