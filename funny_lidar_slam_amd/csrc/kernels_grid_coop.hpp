@@ -279,10 +279,44 @@ grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restri
             merge();
         }
     }
-    // un-gated search (LoamPointToPlaneKdtree): the 27 cells certify the result only if the K-th neighbour lies
-    // within one cell size; otherwise lane 0 of the group redoes the query with the serial ring search
+    // un-gated search (LoamPointToPlaneKdtree): the 27 cells certify the result only if the K-th neighbour lies within one cell
+    // size.  Otherwise the group walks the rings 2 .. kMaxRing TOGETHER (round 3): the shell cells of a ring are dealt round-robin
+    // to the eight lanes (eight probe chains in flight instead of one lane probing up to 729 cells one after the other: the serial
+    // version took up to 590 us per launch), a cell is probed only if its box can still hold something closer than the K-th
+    // distance known so far, and after every ring the merged K-th distance is tested against the ring's radius.  Only a query
+    // that is still uncertain after kMaxRing rings (far outside the map) falls back to lane 0's exact brute-force search.
     const double rad2 = cg.cell * cg.cell * (1.0 - 1e-5);
-    const bool certain = (gate < INFINITY) || (found == K && (double)kth <= rad2);
+    bool certain = (gate < INFINITY) || (found == K && (double)kth <= rad2);
+    if (!certain) {  // uniform within the group
+        for (int rho = 2; rho <= kMaxRing && !certain; ++rho) {
+            const float bnd = found == K ? kth : INFINITY;
+#pragma unroll
+            for (int j = 0; j < K; ++j) { t[j] = ~0ull; sl[j] = 0u; }
+            ncand = 0;
+            if (sub < K && mine_key != ~0ull) { t[0] = mine_key; sl[0] = mine_slot; ncand = 1; }  // the merged top-K, one entry per lane
+            const int w = 2 * rho + 1, cube = w * w * w;
+            for (int idx = sub; idx < cube; idx += G) {
+                const int dx = idx % w - rho, dy = (idx / w) % w - rho, dz = idx / (w * w) - rho;
+                const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
+                const int m = ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az);
+                if (m != rho || !in_range || box_dmin2(dx, dy, dz) > (double)bnd) continue;
+                unsigned bb, cc;
+                lookup(true, dx, dy, dz, bb, cc);
+                const unsigned last = bb + cc - 1;
+                for (unsigned sp = bb; sp < bb + cc; sp += 4) {
+                    const unsigned s1 = sp + 1 < last ? sp + 1 : last, s2 = sp + 2 < last ? sp + 2 : last, s3 = sp + 3 < last ? sp + 3 : last;
+                    const float4 p0 = cg.g.pts[sp], p1 = cg.g.pts[s1], p2 = cg.g.pts[s2], p3 = cg.g.pts[s3];
+                    consider(p0, sp, true);
+                    consider(p1, s1, sp + 1 <= last);
+                    consider(p2, s2, sp + 2 <= last);
+                    consider(p3, s3, sp + 3 <= last);
+                }
+            }
+            merge();
+            const double rr = (double)rho * cg.cell;
+            certain = found == K && (double)kth <= rr * rr * (1.0 - 1e-5);
+        }
+    }
     if (!certain) {  // uniform within the group
         if (sub == 0 && active) {
             KnnResult<K> r;

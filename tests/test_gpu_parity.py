@@ -123,9 +123,11 @@ def test_config4_loam_full(scale):
     assert m.stats.n_valid_corner > 0
 
 
-def test_p2plane_kdtree_localization():
-    """LoamPointToPlaneKdtree (localization only in the reference): un-gated exact 5-NN + fitness."""
-    cfg = synth.make_config(1, scale=0.1)
+@pytest.mark.parametrize("scale", [0.1, 1.0])
+def test_p2plane_kdtree_localization(scale):
+    """LoamPointToPlaneKdtree (localization only in the reference): un-gated exact 5-NN + fitness; scale 1.0 = the full 115,200-point
+    scan against the 1e6-point map (round 3: the ring search beyond the 27 cells is walked by the whole 8-lane group)."""
+    cfg = synth.make_config(1, scale=scale)
     m, o, T, T_ref = run_pair("PointToPlane_KdTree", reg.YAML_NCLT_LOC_KDTREE, [cfg["map"]], cfg["scan"], loc=True)
     assert m.GetFitnessScore(2.0) == pytest.approx(o.GetFitnessScore(2.0), rel=1e-6)
 
