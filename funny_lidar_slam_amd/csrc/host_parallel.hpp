@@ -13,6 +13,9 @@
 // permutation against std::sort itself (random keys with heavy ties, all sizes); the heap-sort fallback of introsort
 // (recursion deeper than 2 log2 n: adversarial inputs only) is not restated -- the caller gets `false` and runs std::sort.
 #pragma once
+#if defined(__linux__)
+#include <sched.h>
+#endif
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -49,6 +52,7 @@ public:
             Phase& ph = phases_.back();  // stays alive (and at this address) until the region ends: a helper may still hold it
             ph.body = [&body](size_t c) { body(c); };
             ph.n = n_chunks;
+            ph.failed = &failed_;
             cur_.store(&ph, std::memory_order_release);
             help(ph);
             while (ph.done.load(std::memory_order_acquire) != n_chunks) spin_pause();
@@ -60,12 +64,13 @@ public:
             std::function<void(size_t)> body;
             size_t n = 0;
             std::atomic<size_t> next{0}, done{0};
+            std::atomic<bool>* failed = nullptr;
         };
         static void help(Phase& ph) {
             for (;;) {
                 const size_t c = ph.next.fetch_add(1, std::memory_order_acq_rel);
                 if (c >= ph.n) return;  // (a helper that arrives after the phase is over only bumps its private counter)
-                ph.body(c);
+                try { ph.body(c); } catch (...) { if (ph.failed) ph.failed->store(true, std::memory_order_release); }  // never std::terminate a worker
                 ph.done.fetch_add(1, std::memory_order_acq_rel);
             }
         }
@@ -81,6 +86,7 @@ public:
         static Phase* end_marker() { return reinterpret_cast<Phase*>(uintptr_t(1)); }
         std::deque<Phase> phases_;
         std::atomic<Phase*> cur_{nullptr};
+        std::atomic<bool> failed_{false};
     };
 
     // fn(region) on the calling thread; false when another region is running (the caller then takes its sequential path --
@@ -98,15 +104,23 @@ public:
             gen_hint_.store(gen_, std::memory_order_release);
         }
         cv_.notify_all();
+        // the region is closed by a guard: if fn throws on the caller (bad_alloc from a resize inside a filter) the workers must not be
+        // left looking at the destroyed stack Region
+        struct Closer {
+            HostPool* pool;
+            Region* reg;
+            ~Closer() {
+                reg->cur_.store(Region::end_marker(), std::memory_order_release);
+                {
+                    std::lock_guard<std::mutex> lk(pool->mx_);
+                    pool->region_ = nullptr;  // a worker that wakes from now on finds no region
+                }
+                while (pool->inside_.load(std::memory_order_acquire) != 0) spin_pause();
+                pool->last_end_ns_.store(now_ns(), std::memory_order_relaxed);
+            }
+        } closer{this, &reg};
         fn(reg);
-        reg.cur_.store(Region::end_marker(), std::memory_order_release);
-        {
-            std::lock_guard<std::mutex> lk(mx_);
-            region_ = nullptr;  // a worker that wakes from now on finds no region
-        }
-        while (inside_.load(std::memory_order_acquire) != 0) spin_pause();
-        last_end_ns_.store(now_ns(), std::memory_order_relaxed);
-        return true;
+        return !reg.failed_.load(std::memory_order_acquire);  // a phase body threw on a helper: the caller redoes the work sequentially
     }
     // the workers are still spinning after a recent region (no wake-up cost): smaller jobs pay off then
     bool hot() const { return n_ > 1 && now_ns() - last_end_ns_.load(std::memory_order_relaxed) < 1000000ll; }
@@ -130,7 +144,14 @@ private:
     HostPool() {
         int n = 8;
         if (const char* e = std::getenv("FLS_HOST_THREADS")) n = std::atoi(e);
-        const int hw = int(std::thread::hardware_concurrency());
+        int hw = int(std::thread::hardware_concurrency());
+#if defined(__linux__)
+        {   // the CPUs this process may actually run on (cgroup cpusets / taskset), not the machine's
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0) hw = hw > 0 ? std::min(hw, a) : a; }
+        }
+#endif
         if (hw > 0) n = std::min(n, std::max(1, hw / 2));
         n_ = std::max(1, std::min(n, 32));
         for (int t = 1; t < n_; ++t) th_.emplace_back([this] { worker(); });

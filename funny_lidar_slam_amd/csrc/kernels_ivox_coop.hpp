@@ -159,7 +159,8 @@ __global__ void __launch_bounds__(256)
 ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
                 const GnState* __restrict__ st, const Pose16 T0, const DevGrid grid, const DenseWindow win,
                 const float inv_res, float4* __restrict__ nn_pts /* [n][5] */, unsigned char* __restrict__ nn_cnt,
-                unsigned char* __restrict__ flag, TrafficCounters* __restrict__ tc, const int chunk) {
+                unsigned char* __restrict__ flag, TrafficCounters* __restrict__ tc, const int chunk,
+                unsigned* __restrict__ nn_ids /* [n][8]: map slots of the neighbours (ids form); nullptr: rows form */) {
     static_assert(G == 4 || G == 8, "group size");
     constexpr int QPB = 256 / G;       // queries per workgroup
     constexpr int R = (19 + G - 1) / G;  // probe rounds per lane
@@ -383,6 +384,7 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
     if (dkey_valid(m0)) {  // uniform within the group: at least one candidate (else nothing is written, ivox_map.cpp:21-23)
         int cnt = 0;
         double mine = kNone;  // G == 8: the j-th smallest key lands in lane sub == j
+        unsigned sid[5] = {~0u, ~0u, ~0u, ~0u, ~0u};
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const double m = j == 0 ? m0 : group_min_dkey<G>(t5[0]);
@@ -392,13 +394,28 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
                 t5[0] = t5[1]; t5[1] = t5[2]; t5[2] = t5[3]; t5[3] = t5[4]; t5[4] = kNone;
             }
             if (G >= 8) { if (sub == j) mine = m; }
-            else if (sub == 0 && active) {  // G == 4: lane 0 writes all five
+            else if (nn_ids) sid[j] = mv ? dkey_slot(m) : ~0u;
+            else if (sub == 0 && active) {  // G == 4, rows form: lane 0 writes all five
                 store_nn_row(&nn_pts[(size_t)q * 5 + j], mv ? grid.pts[dkey_slot(m)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1)));
             }
         }
-        if (G >= 8 && sub < 5 && active)
-            nn_pts[(size_t)q * 5 + sub] = dkey_valid(mine) ? grid.pts[dkey_slot(mine)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        if (sub == 0 && active) nn_cnt[q] = (unsigned char)cnt;
+        // Neighbour lists in IDS form (round 3): 20 bytes of map slots per point instead of 80 bytes of gathered rows -- the rows were the
+        // path's only real HBM traffic (9.2 MB written here and re-read by the fit kernel every iteration); the fit kernel gathers
+        // the five points from the (cache-resident) map image instead.  Bit 7 of the count byte says which form a point's list has
+        // (0x80 = rows): a point without candidates keeps its previous list in whatever form it was (Q15); the lists are turned into
+        // rows before anything moves map slots (matcher_p2plane_ivox.hpp::ensure_nn_rows).
+        if (nn_ids) {
+            if (G >= 8) { if (sub < 5 && active) nn_ids[(size_t)q * 8 + sub] = dkey_valid(mine) ? dkey_slot(mine) : ~0u; }
+            else if (sub == 0 && active) {
+                *reinterpret_cast<uint4*>(nn_ids + (size_t)q * 8) = make_uint4(sid[0], sid[1], sid[2], sid[3]);
+                nn_ids[(size_t)q * 8 + 4] = sid[4];
+            }
+            if (sub == 0 && active) nn_cnt[q] = (unsigned char)cnt;
+        } else {
+            if (G >= 8 && sub < 5 && active)
+                nn_pts[(size_t)q * 5 + sub] = dkey_valid(mine) ? grid.pts[dkey_slot(mine)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            if (sub == 0 && active) nn_cnt[q] = (unsigned char)(cnt | 0x80);
+        }
     }
     if (COUNT) {
         const double p = wave_sum_u((double)c_probes), hsum = wave_sum_u((double)c_hits), c = wave_sum_u((double)c_cand);
@@ -428,7 +445,8 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
                          GnState* __restrict__ st, const Pose16 T0, const float4* __restrict__ nn_pts,
                          const unsigned char* __restrict__ nn_cnt, double* __restrict__ Jst /* [7][n] */, unsigned char* __restrict__ flag,
                          double* __restrict__ partials, unsigned* __restrict__ ticket, Mailbox* __restrict__ mb, const unsigned match_id,
-                         const double plane_thres, const double rot_thr, const double pos_thr, const int shards) {
+                         const double plane_thres, const double rot_thr, const double pos_thr, const int shards,
+                         const unsigned* __restrict__ nn_ids /* may be null */, const float4* __restrict__ map_pts, const unsigned n_slots) {
     const int i = blockIdx.x * kFitThreads + threadIdx.x;
     const int done = FIRST ? 0 : st->done;
     double T44[16];
@@ -439,10 +457,23 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
     // every per-point input is loaded up front on a clamped index (one memory round trip; the neighbour points
     // are fetched whether or not all five exist, the stale flag whether or not it is needed)
     const int ii = i < n ? i : 0;
-    const int cnt = nn_cnt[ii];
+    const int cb = nn_cnt[ii];
+    const int cnt = cb & 7;
     float4 nn[5];
+    if (nn_ids) {  // uniform: lists in ids form unless a point's count byte says rows (bit 7)
+        const uint4 i4 = *reinterpret_cast<const uint4*>(nn_ids + (size_t)ii * 8);
+        const unsigned i5 = nn_ids[(size_t)ii * 8 + 4];
+        const unsigned sl[5] = {i4.x, i4.y, i4.z, i4.w, i5};
+        const bool rows_form = (cb & 0x80) != 0;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) nn[j] = nn_pts[(size_t)ii * 5 + j];
+        for (int j = 0; j < 5; ++j) {
+            const float4* src = rows_form ? nn_pts + (size_t)ii * 5 + j : map_pts + (sl[j] < n_slots ? sl[j] : 0u);
+            nn[j] = *src;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) nn[j] = nn_pts[(size_t)ii * 5 + j];
+    }
     const float px = sx[ii], py = sy[ii], pz = sz[ii];
     const unsigned char stale = FIRST ? (unsigned char)0 : flag[ii];  // the first kNN launch of a Match cleared the flags
     if (done) return;
@@ -532,10 +563,29 @@ ivox_apply_updates_kernel(const PtUpdDev* __restrict__ pu, const int npu, const 
     }
 }
 
+// neighbour lists: ids form -> rows form (before map slots move, and for the host-side readers)
+__global__ void __launch_bounds__(256)
+ivox_nn_materialize_kernel(const unsigned* __restrict__ nn_ids, unsigned char* __restrict__ nn_cnt, const int n, const float4* __restrict__ map_pts,
+                           const unsigned n_slots, float4* __restrict__ nn_pts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char cb = nn_cnt[i];
+    if (cb & 0x80) return;
+    if (cb & 7) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const unsigned sl = nn_ids[(size_t)i * 8 + j];
+            nn_pts[(size_t)i * 5 + j] = sl < n_slots ? map_pts[sl] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        }
+    }
+    nn_cnt[i] = (unsigned char)(cb | 0x80);
+}
+
 __global__ void __launch_bounds__(256)
 ivox_add_decide_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
                        const Pose16 Tw, const float4* __restrict__ nn_pts, const unsigned char* __restrict__ nn_cnt, const int nn_n,
-                       const double fs /* filter_size_map_min */, unsigned char* __restrict__ code, float4* __restrict__ pw_out) {
+                       const double fs /* filter_size_map_min */, unsigned char* __restrict__ code, float4* __restrict__ pw_out,
+                       const unsigned* __restrict__ nn_ids /* may be null */, const float4* __restrict__ map_pts, const unsigned n_slots) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double x = sx[i], y = sy[i], z = sz[i];
@@ -543,12 +593,19 @@ ivox_add_decide_kernel(const float* __restrict__ sx, const float* __restrict__ s
     const float wy = (float)(((Tw.m[1] * x + Tw.m[5] * y) + Tw.m[9] * z) + Tw.m[13]);
     const float wz = (float)(((Tw.m[2] * x + Tw.m[6] * y) + Tw.m[10] * z) + Tw.m[14]);
     pw_out[i] = make_float4(wx, wy, wz, 0.f);
-    const int cnt = i < nn_n ? nn_cnt[i] : 0;
+    const int cb = i < nn_n ? nn_cnt[i] : 0;
+    const int cnt = cb & 7;
+    const bool ids_form = nn_ids != nullptr && !(cb & 0x80);
+    auto neighbour = [&](const int k) -> float4 {
+        if (!ids_form) return nn_pts[(size_t)i * 5 + k];
+        const unsigned sl = nn_ids[(size_t)i * 8 + k];
+        return map_pts[sl < n_slots ? sl : 0u];
+    };
     unsigned char c = 1;  // no neighbours: add (:126)
     if (cnt > 0) {
         const double half = 0.5 * fs;
         const double c0 = (floor((double)wx / fs) + 0.5) * fs, c1 = (floor((double)wy / fs) + 0.5) * fs, c2 = (floor((double)wz / fs) + 0.5) * fs;
-        const float4 n0 = nn_pts[(size_t)i * 5];
+        const float4 n0 = neighbour(0);
         const double d0 = (double)n0.x - c0, d1 = (double)n0.y - c1, d2 = (double)n0.z - c2;
         if (fabs(d0) > half && fabs(d1) > half && fabs(d2) > half) {
             c = 2;  // :103-108
@@ -558,7 +615,7 @@ ivox_add_decide_kernel(const float* __restrict__ sx, const float* __restrict__ s
             bool need_add = true;
             if (cnt >= 5) {
                 for (int k = 0; k < 5 && need_add; ++k) {
-                    const float4 q = nn_pts[(size_t)i * 5 + k];
+                    const float4 q = neighbour(k);
                     const double f0 = (double)q.x - c0, f1 = (double)q.y - c1, f2 = (double)q.z - c2;
                     if ((f0 * f0 + f1 * f1) + f2 * f2 < dist + 1.0e-6) need_add = false;
                 }

@@ -58,6 +58,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     bool balanced = true;  // equal candidate ranges per lane through an LDS voxel table (FLS_IVOX_BALANCED=0: whole voxels per lane)
     int variant = 4;       // lanes cooperating on one query in ivox_knn_kernel: 4 or 8 (FLS_IVOX_VARIANT)
     int ticket_shards = 8; // fan-in of the fit kernel's workgroups: 8 per-XCD counters + a top counter (FLS_TICKET_SHARDS=1: one counter)
+    bool plain_launch = false;  // FLS_PLAIN_LAUNCH=1 (A/B): hipLaunchKernelGGL instead of hipExtLaunchKernelGGL with null events
     bool prof_fit = false; // FLS_PROF_FIT=1 (diagnosis): the profiling events bracket the fit+solve kernel instead of the kNN kernel
     bool is_first = true;  // the reference's function-static flag (:62), per handle here
     const double filter_size_map_min = 0.5;  // :351
@@ -65,7 +66,10 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     DevScan scan;
     // per-point state that outlives an iteration (Q1) or a Match (nearest_points_, :257)
     DevBuf<float4> d_nn;          // [n][5]
-    DevBuf<unsigned char> d_nn_cnt;
+    DevBuf<unsigned char> d_nn_cnt;   // neighbour count (bits 0-2) | 0x80 when the point's list is in rows form
+    DevBuf<unsigned> d_nn_ids;        // [n][8] map slots of the neighbours (ids form: what the kNN kernel writes by default)
+    bool nn_ids_mode = true;          // FLS_IVOX_NN_IDS=0: the kNN kernel writes gathered rows (round-2 behaviour)
+    bool nn_rows_current = true;      // every list is in rows form
     size_t nn_n = 0;              // logical size of nearest_points_
     DevBuf<double> d_J;           // [7][n]
     DevBuf<unsigned char> d_flag;
@@ -89,6 +93,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (const char* e = std::getenv("FLS_IVOX_VARIANT")) { const int v = std::atoi(e); if (v == 4 || v == 8) variant = v; }
         if (const char* e = std::getenv("FLS_IVOX_DENSE")) use_dense = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_PROF_FIT")) prof_fit = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_PLAIN_LAUNCH")) plain_launch = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_IVOX_NN_IDS")) nn_ids_mode = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_BALANCED")) balanced = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_HOST_TIMING")) host_timing = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_DEVICE_UPDATE")) allow_device_map = std::atoi(e) != 0;
@@ -281,7 +287,17 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         return r;
     }
 
+    // ids form -> rows form for every point (the ids are slots of the image as it is NOW: call before anything moves slots)
+    void ensure_nn_rows() {
+        if (nn_rows_current || nn_n == 0) { nn_rows_current = true; return; }
+        const GridImage& im = borrowed ? *borrowed : image;
+        hipLaunchKernelGGL(ivox_nn_materialize_kernel, dim3(unsigned((nn_n + 255) / 256)), dim3(256), 0, stream, (const unsigned*)d_nn_ids.p, d_nn_cnt.p, int(nn_n),
+                           (const float4*)im.d_pts.p, unsigned(im.d_pts.cap), d_nn.p);  // (slot bound = the allocation: in device mode the host's `used` is stale)
+        FLS_HIP(hipGetLastError());
+        nn_rows_current = true;
+    }
     void download_nn() {
+        ensure_nn_rows();
         const size_t n = nn_n;
         h_nn.resize(n * 5);
         h_cnt.resize(n);
@@ -289,6 +305,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         FLS_HIP(hipMemcpyAsync(h_nn.data(), d_nn.p, n * 5 * sizeof(float4), hipMemcpyDeviceToHost, stream));
         FLS_HIP(hipMemcpyAsync(h_cnt.data(), d_nn_cnt.p, n, hipMemcpyDeviceToHost, stream));
         FLS_HIP(hipStreamSynchronize(stream));
+        for (unsigned char& c : h_cnt) c &= 7;  // (bit 7 = rows form)
     }
 
     fls_status add_cloud(const float* c0, size_t n0, const float* c1, size_t n1, int stride) override {
@@ -300,7 +317,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     fls_status add_cloud_impl(const std::vector<PtI>& planar_cloud, const bool from_resident_scan = false) {
         if (p.is_localization_mode) { device_map = false; is_first = true; ivox.clear(); image_built = false; }
         fls_status rc = FLS_OK;
-        if (!(from_resident_scan && !is_first)) sync_host_from_device();  // every other branch works on the host mirror
+        if (!(from_resident_scan && !is_first)) { ensure_nn_rows(); sync_host_from_device(); }  // every other branch works on the host mirror
         if (is_first) {
             rc = ivox.add_points(planar_cloud.data(), planar_cloud.size());
             if (rc != FLS_OK) return rc;
@@ -320,8 +337,9 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
                 std::memcpy(Tw.m, T_, sizeof(Tw.m));
                 hipLaunchKernelGGL(ivox_add_decide_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p,
                                    int(n), Tw, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, int(nn_n), filter_size_map_min,
-                                   d_code.p, d_pw.p);
+                                   d_code.p, d_pw.p, (const unsigned*)(nn_ids_mode ? d_nn_ids.p : nullptr), (const float4*)image.d_pts.p, unsigned(image.d_pts.cap));
                 FLS_HIP(hipGetLastError());
+                ensure_nn_rows();  // the update below moves map slots: the lists become rows first
                 if (device_map) {
                     if (device_add_points(n)) {
                         if (host_timing)
@@ -420,12 +438,20 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     template <int G>
     void launch_knn(const size_t n, const int first, const Pose16& T0, const DevGrid& g, const DenseWindow& win, hipEvent_t e0 = nullptr,
                     hipEvent_t e1 = nullptr) {
+        unsigned* const ids_arg = nn_ids_mode ? d_nn_ids.p : nullptr;
         const size_t nblk = (n * G + 255) / 256, gran = size_t(8) * size_t(xcd_chunk);
         const dim3 grid(unsigned((nblk + gran - 1) / gran * gran));  // multiple of 8 * chunk: the XCD re-map is a bijection
 #define FLS_KNN_L(C, D, F, B)                                                                                                        \
-    hipExtLaunchKernelGGL((ivox_knn_kernel<G, C, D, F, B>), grid, dim3(256), 0, stream, e0, e1, 0, (const float*)scan.x.p,           \
-                          (const float*)scan.y.p, (const float*)scan.z.p, int(n), (const GnState*)d_state.p, T0, g, win,            \
-                          ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p, xcd_chunk)
+    do {                                                                                                                             \
+        if (e0 || !plain_launch)                                                                                                     \
+            hipExtLaunchKernelGGL((ivox_knn_kernel<G, C, D, F, B>), grid, dim3(256), 0, stream, e0, e1, 0, (const float*)scan.x.p,   \
+                                  (const float*)scan.y.p, (const float*)scan.z.p, int(n), (const GnState*)d_state.p, T0, g, win,    \
+                                  ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p, xcd_chunk, ids_arg);                   \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((ivox_knn_kernel<G, C, D, F, B>), grid, dim3(256), 0, stream, (const float*)scan.x.p,                 \
+                               (const float*)scan.y.p, (const float*)scan.z.p, int(n), (const GnState*)d_state.p, T0, g, win,       \
+                               ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p, xcd_chunk, ids_arg);                      \
+    } while (0)
 #define FLS_KNN(C, D)                                                                                                                \
     do {                                                                                                                             \
         if (balanced && G == 4) { if (first) FLS_KNN_L(C, D, true, true); else FLS_KNN_L(C, D, false, true); }                        \
@@ -455,6 +481,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         // nearest_points_.resize(n) semantics (:257): grown tail is empty, shrink forgets
         d_nn.reserve(n * 5, /*keep=*/true, stream);
         d_nn_cnt.reserve(n, /*keep=*/true, stream);
+        if (nn_ids_mode) d_nn_ids.reserve(n * 8, /*keep=*/true, stream);
         if (n > nn_n) FLS_HIP(hipMemsetAsync(d_nn_cnt.p + nn_n, 0, n - nn_n, stream));
         nn_n = n;
         d_J.reserve(7 * n);
@@ -472,12 +499,22 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             if (prof_fit) { f0 = e0; f1 = e1; e0 = e1 = nullptr; }
             if (variant == 4) launch_knn<4>(n, first, T0, g, win, e0, e1); else launch_knn<8>(n, first, T0, g, win, e0, e1);
 #define FLS_FIT(F)                                                                                                                   \
-    hipExtLaunchKernelGGL(p2plane_fit_solve_kernel<F>, dim3(nwg), dim3(kFitThreads), 0, stream, f0, f1, 0, scan.x.p, scan.y.p, scan.z.p, int(n),  \
+    do {                                                                                                                             \
+        if (f0 || !plain_launch)                                                                                                     \
+            hipExtLaunchKernelGGL(p2plane_fit_solve_kernel<F>, dim3(nwg), dim3(kFitThreads), 0, stream, f0, f1, 0, scan.x.p, scan.y.p, scan.z.p, int(n),  \
                        d_state.p, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,     \
-                       d_ticket.p, mb_dev, launch_word(), p.point_to_planar_thres, p.rotation_converge_thres, p.position_converge_thres, ticket_shards)
+                       d_ticket.p, mb_dev, launch_word(), p.point_to_planar_thres, p.rotation_converge_thres, p.position_converge_thres, ticket_shards,  \
+                       (const unsigned*)(nn_ids_mode ? d_nn_ids.p : nullptr), (const float4*)g.pts, unsigned(im.d_pts.cap));  \
+        else                                                                                                                         \
+            hipLaunchKernelGGL(p2plane_fit_solve_kernel<F>, dim3(nwg), dim3(kFitThreads), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),  \
+                       d_state.p, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,     \
+                       d_ticket.p, mb_dev, launch_word(), p.point_to_planar_thres, p.rotation_converge_thres, p.position_converge_thres, ticket_shards,  \
+                       (const unsigned*)(nn_ids_mode ? d_nn_ids.p : nullptr), (const float4*)g.pts, unsigned(im.d_pts.cap));  \
+    } while (0)
             if (first) FLS_FIT(true); else FLS_FIT(false);
 #undef FLS_FIT
         });
+        if (nn_ids_mode) nn_rows_current = false;  // the lists of every point with candidates are slots of the current image now
         const Mailbox& mb = *mb_host;
         const int used = int(word & 0xffu);
         std::memcpy(T, mb.T, sizeof(double) * 16);
@@ -572,7 +609,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         ivox.rebuild_from_image(vox, bp, size_t(hd.n_points), int(hd.next_id));
         ivox.resolution = hd.resolution; ivox.inv_resolution = 1.0f / hd.resolution; ivox.capacity = capacity;
         is_first = hd.is_first != 0;
-        nn_n = 0; have_final = false;
+        nn_n = 0; have_final = false; nn_rows_current = true;
         image_built = false;  // the slot layout is rebuilt from the mirror (window order), like the first build of the exporter
         image_dirty = true;
         refresh_image();
@@ -593,7 +630,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     }
     void tune_lane(fls_matcher& l) override {
         auto& q = static_cast<P2PlaneIvoxMatcher&>(l);
-        q.use_dense = use_dense; q.variant = variant; q.balanced = balanced; q.xcd_chunk = xcd_chunk; q.prof_fit = prof_fit; q.ticket_shards = ticket_shards;
+        q.use_dense = use_dense; q.variant = variant; q.balanced = balanced; q.xcd_chunk = xcd_chunk; q.prof_fit = prof_fit; q.ticket_shards = ticket_shards; q.plain_launch = plain_launch; q.nn_ids_mode = nn_ids_mode;
     }
 
     fls_status fitness(float max_range, float* score) override {
