@@ -60,7 +60,15 @@ loop_reduce_kernel(const double* __restrict__ rows, const int nrows, const int n
     const int c = threadIdx.x;
     if (c < nv) {
         double s = 0.0;
-        for (int r = 0; r < nrows; ++r) s += rows[(size_t)r * kLoopMaxV + c];  // fixed order
+        int r = 0;
+        for (; r + 8 <= nrows; r += 8) {  // eight loads in flight, adds in row order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = rows[(size_t)(r + u) * kLoopMaxV + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < nrows; ++r) s += rows[(size_t)r * kLoopMaxV + c];  // fixed order
         __hip_atomic_store((unsigned long long*)&mail->v[c], (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -180,29 +188,132 @@ ndt_p2d_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const
 }
 
 // ---- GICP --------------------------------------------------------------------------------------------------------------------
-// 20-NN covariance of every point of a cloud held in its own cell grid (ids = cloud indices)
-__global__ void __launch_bounds__(64)
+// 20-NN covariance of every point of a cloud held in its own cell grid (ids = cloud indices).  ONE WAVE PER QUERY (round 3; the
+// first version ran a sorted 20-entry insertion in one lane per query: 7-21 ms per cloud, 55 % of the whole loop-closure Match):
+// the candidates of the 27 cells around the query (then, if the 20th distance is not certain yet, of the 125 cells) go to LDS as
+// {float-bits(d2) : map index} keys, every lane ranks its candidates by counting the smaller keys (ties: lower index, the
+// oracle's order), the twenty smallest land in rank order; nine lanes then run the nine moment sums over them IN THAT ORDER
+// (sequential sums, bit-identical to a scalar loop), lane 0 does the 3x3 SVD.  Exact: a result is accepted only if the 20th
+// distance is within the searched block's guaranteed radius; anything else (sparse fringe) takes lane 0's exact ring search.
+constexpr int kCovK = 20, kCovMaxCand = 1024, kCovWaves = 4;
+__global__ void __launch_bounds__(64 * kCovWaves)
 gicp_cov_kernel(const float* __restrict__ cx, const float* __restrict__ cy, const float* __restrict__ cz, const int n, const CellGridDev cg,
                 const double gicp_epsilon, double* __restrict__ cov_out /* [n][9] column-major */) {
-    constexpr int K = 20;
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    KnnResult<K> r;
-    unsigned long long a = 0, b = 0, c = 0;
-    knn_grid<K>(cg, cx[i], cy[i], cz[i], INFINITY, r, a, b, c);
-    double mean[3] = {0.0, 0.0, 0.0}, cov[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int j = 0; j < K; ++j) {
-        if (j >= r.found) break;
-        const float4 p = cg.g.pts[r.slot[j]];
-        mean[0] += p.x; mean[1] += p.y; mean[2] += p.z;
-        cov[0] += p.x * p.x;  // float products, double sums (gicp.hpp computeCovariances)
-        cov[1] += p.y * p.x; cov[4] += p.y * p.y;
-        cov[2] += p.z * p.x; cov[5] += p.z * p.y; cov[8] += p.z * p.z;
+    __shared__ unsigned long long s_key[kCovWaves][kCovMaxCand];
+    __shared__ unsigned s_slot[kCovWaves][kCovMaxCand];
+    __shared__ unsigned s_top[kCovWaves][kCovK];
+    __shared__ double s_acc[kCovWaves][12];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kCovWaves + w;
+    if (i >= n) return;  // (whole wave)
+    const float qx = cx[i], qy = cy[i], qz = cz[i];
+    const int c0 = (int)floor((double)qx * cg.inv_cell), c1 = (int)floor((double)qy * cg.inv_cell), c2 = (int)floor((double)qz * cg.inv_cell);
+    bool done = false;
+    // growing blocks of cells around the query (clipped to the grid's window: no point lies outside it): rho = 1 (27 cells), 2, 3, 4, 6, 9, 13 ...
+    // A sparse fringe point reaches its 20 neighbours after a few steps; a block with more than kCovMaxCand points whose 20th
+    // distance is still uncertain (never seen on sub-map clouds) leaves the loop for lane 0's exact serial search.
+    for (int rho = 1; !done && cg.win.cells; rho = rho < 4 ? rho + 1 : rho + rho / 2) {
+        const int lx = max(c0 - rho, cg.win.ox), ly = max(c1 - rho, cg.win.oy), lz = max(c2 - rho, cg.win.oz);
+        const int hx = min(c0 + rho, cg.win.ox + cg.win.nx - 1), hy = min(c1 + rho, cg.win.oy + cg.win.ny - 1), hz = min(c2 + rho, cg.win.oz + cg.win.nz - 1);
+        const int ex = hx - lx + 1, ey = hy - ly + 1, ez = hz - lz + 1;
+        const bool whole = ex == cg.win.nx && ey == cg.win.ny && ez == cg.win.nz;
+        const int cube = (ex > 0 && ey > 0 && ez > 0) ? ex * ey * ez : 0;
+        unsigned total = 0;  // (uniform)
+        for (int base = 0; base < cube; base += 64) {
+            const int idx = base + lane;
+            unsigned b = 0, c = 0;
+            if (idx < cube) {
+                const int wx = lx + idx % ex - cg.win.ox, wy = ly + (idx / ex) % ey - cg.win.oy, wz = lz + idx / (ex * ey) - cg.win.oz;
+                const uint2 e = cg.win.cells[(unsigned)((wz * cg.win.ny + wy) * cg.win.nx + wx)];
+                b = e.x; c = e.y;
+            }
+            // exclusive prefix of the counts over the wave
+            unsigned inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+            const unsigned off = total + inc - c;
+            for (unsigned k = 0; k < c; ++k) {
+                if (off + k < (unsigned)kCovMaxCand) {
+                    const float4 p = cg.g.pts[b + k];
+                    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;  // flann::L2_Simple<float>
+                    s_key[w][off + k] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p.w);
+                    s_slot[w][off + k] = b + k;
+                }
+            }
+            total += (unsigned)__shfl(inc, 63, 64);
+            if (total > (unsigned)kCovMaxCand) break;
+        }
+        if (total > (unsigned)kCovMaxCand) break;  // serial fallback
+        if (total < (unsigned)kCovK) { if (whole) break; continue; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // rank by counting: keys are distinct (the map index is the low word)
+        for (unsigned a = lane; a < total; a += 64) {
+            const unsigned long long ka = s_key[w][a];
+            unsigned rank = 0;
+            for (unsigned bq = 0; bq < total; ++bq) rank += s_key[w][bq] < ka ? 1u : 0u;
+            if (rank < (unsigned)kCovK) s_top[w][rank] = a;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float d20 = __uint_as_float((unsigned)(s_key[w][s_top[w][kCovK - 1]] >> 32));
+        const double rad = (double)rho * cg.cell;
+        done = whole || (double)d20 <= rad * rad * (1.0 - 1e-5);  // everything outside the block is farther than rho cells
+        if (whole) break;
     }
-    for (int q = 0; q < 3; ++q) mean[q] /= (double)K;
+    double cov[9];
+    if (done) {
+        // nine sequential moment sums over the 20 neighbours in rank order (lanes 0-2: mean, 3-8: the lower triangle)
+        if (lane < 9) {
+            double acc = 0.0;
+            for (int j = 0; j < kCovK; ++j) {
+                const float4 p = cg.g.pts[s_slot[w][s_top[w][j]]];
+                float v;
+                switch (lane) {
+                    case 0: v = p.x; break;
+                    case 1: v = p.y; break;
+                    case 2: v = p.z; break;
+                    case 3: v = p.x * p.x; break;  // float products, double sums (gicp.hpp computeCovariances)
+                    case 4: v = p.y * p.x; break;
+                    case 5: v = p.z * p.x; break;
+                    case 6: v = p.y * p.y; break;
+                    case 7: v = p.z * p.y; break;
+                    default: v = p.z * p.z; break;
+                }
+                acc += v;
+            }
+            s_acc[w][lane] = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane != 0) return;
+        for (int q = 0; q < 9; ++q) cov[q] = 0.0;
+        cov[0] = s_acc[w][3]; cov[1] = s_acc[w][4]; cov[2] = s_acc[w][5]; cov[4] = s_acc[w][6]; cov[5] = s_acc[w][7]; cov[8] = s_acc[w][8];
+    } else {
+        if (lane != 0) return;
+        KnnResult<kCovK> r;
+        unsigned long long a = 0, b = 0, c = 0;
+        knn_grid<kCovK>(cg, qx, qy, qz, INFINITY, r, a, b, c);
+        s_acc[w][0] = s_acc[w][1] = s_acc[w][2] = 0.0;
+        for (int q = 0; q < 9; ++q) cov[q] = 0.0;
+        for (int j = 0; j < kCovK; ++j) {
+            if (j >= r.found) break;
+            const float4 p = cg.g.pts[r.slot[j]];
+            s_acc[w][0] += p.x; s_acc[w][1] += p.y; s_acc[w][2] += p.z;
+            cov[0] += p.x * p.x;
+            cov[1] += p.y * p.x; cov[4] += p.y * p.y;
+            cov[2] += p.z * p.x; cov[5] += p.z * p.y; cov[8] += p.z * p.z;
+        }
+    }
+    double mean[3] = {s_acc[w][0], s_acc[w][1], s_acc[w][2]};
+    for (int q = 0; q < 3; ++q) mean[q] /= (double)kCovK;
     for (int rr = 0; rr < 3; ++rr)
         for (int l = 0; l <= rr; ++l) {
-            double v = cov[rr + 3 * l] / (double)K;
+            double v = cov[rr + 3 * l] / (double)kCovK;
             v -= mean[rr] * mean[l];
             cov[rr + 3 * l] = v;
             cov[l + 3 * rr] = v;

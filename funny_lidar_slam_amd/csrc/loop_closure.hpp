@@ -722,7 +722,7 @@ struct LoopMatcher {
         DevCloud tgt_dev, src_own;
         tgt_dev.upload(tgt, stream);
         src_own.upload(src, stream);
-        const float cell = 1.0f;
+        const float cell = 1.5f;  // 20 neighbours of a 0.4-0.5 m down-sampled cloud lie within ~1.2 m on a surface: the 27 cells certify most queries
         CellGridImage src_grid;
         if (!builder.run(g.tgt_grid, tgt_dev.x(), tgt_dev.y(), tgt_dev.z(), tgt.size(), cell, 1, true, stream)) {
             const fls_status rc = g.tgt_grid.build(tgt, cell, stream, 1, true);
@@ -733,9 +733,9 @@ struct LoopMatcher {
             if (rc != FLS_OK) return rc;
         }
         g.cov_src.reserve(src.size() * 9); g.cov_tgt.reserve(tgt.size() * 9); g.mahal.reserve(src.size() * 9); g.corr.reserve(src.size());
-        hipLaunchKernelGGL(gicp_cov_kernel, dim3(unsigned((tgt.size() + 63) / 64)), dim3(64), 0, stream, tgt_dev.x(), tgt_dev.y(), tgt_dev.z(), int(tgt.size()),
+        hipLaunchKernelGGL(gicp_cov_kernel, dim3(unsigned((tgt.size() + kCovWaves - 1) / kCovWaves)), dim3(64 * kCovWaves), 0, stream, tgt_dev.x(), tgt_dev.y(), tgt_dev.z(), int(tgt.size()),
                            cell_dev(g.tgt_grid), 0.001, g.cov_tgt.p);
-        hipLaunchKernelGGL(gicp_cov_kernel, dim3(unsigned((src.size() + 63) / 64)), dim3(64), 0, stream, src_own.x(), src_own.y(), src_own.z(), int(src.size()),
+        hipLaunchKernelGGL(gicp_cov_kernel, dim3(unsigned((src.size() + kCovWaves - 1) / kCovWaves)), dim3(64 * kCovWaves), 0, stream, src_own.x(), src_own.y(), src_own.z(), int(src.size()),
                            cell_dev(src_grid), 0.001, g.cov_src.p);
         FLS_HIP(hipGetLastError());
         // `output` = the source moved by the guess
