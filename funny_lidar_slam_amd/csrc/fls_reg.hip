@@ -279,8 +279,11 @@ fls_status fls_loop_match(int device_id, const float* source, size_t n_source, c
         hipDeviceProp_t prop;
         FLS_HIP(hipGetDeviceProperties(&prop, device_id));
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FLS_ERR_DEVICE;
+        const bool timing = std::getenv("FLS_HOST_TIMING") && std::atoi(std::getenv("FLS_HOST_TIMING")) != 0;
+        const auto t0 = std::chrono::steady_clock::now();
         LoopMatcher m;
         m.init(device_id);
+        if (timing) std::fprintf(stderr, "[fls loop] ms: matcher set-up %.2f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         const fls_status rc = m.run(cloud_from(source, n_source, stride), cloud_from(target, n_target, stride), T, fitness);
         if (stats) *stats = m.st;
         return rc;

@@ -23,6 +23,7 @@
 // synchronisation per evaluation).  The VoxelGridCloud calls use the exact host filter by default, the device filter with
 // FLS_DEVICE_VOXELGRID=1.
 #pragma once
+#include <chrono>
 #include "device_voxelgrid.hpp"
 #include "kernels_loop.hpp"
 #include "fitness_host.hpp"
@@ -689,6 +690,12 @@ struct LoopMatcher {
         std::memset(&st, 0, sizeof(st));
         *fitness = std::numeric_limits<float>::max();
         DeviceGridBuilder builder;
+        // FLS_HOST_TIMING=1: where the wall time of one Match goes (stderr)
+        const bool timing = std::getenv("FLS_HOST_TIMING") && std::atoi(std::getenv("FLS_HOST_TIMING")) != 0;
+        double t_filter = 0, t_leaves = 0, t_ndt = 0, t_gicp_setup = 0, t_gicp = 0, t_fit = 0;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t0 = now();
+        auto lap = [&](double& acc) { const double t = now(); acc += t - t0; t0 = t; };
         // ---- four NDT stages ----------------------------------------------------------------------------------------------
         static const float resolution[4] = {10.0f, 5.0f, 3.0f, 2.0f};
         DevCloud src_dev;
@@ -696,10 +703,12 @@ struct LoopMatcher {
         for (int s = 0; s < 4; ++s) {
             const float r = resolution[s];
             const std::vector<PtI> src = filter(source, r * 0.2f), tgt = filter(target, r * 0.2f);
+            lap(t_filter);
             NdtRun run;
             run.resolution = r;
             const bool have = build_target(tgt, r, leaves);
             src_dev.upload(src, stream);
+            lap(t_leaves);
             run.src = &src_dev;
             run.tl = have ? &leaves : nullptr;
             int iters = 0;
@@ -708,10 +717,12 @@ struct LoopMatcher {
             for (int i = 0; i < 16; ++i) T[i] = double(fin.m[i]);
             st.ndt_iterations[s] = iters; st.ndt_evaluations[s] = run.evaluations; st.ndt_source_points[s] = int(src.size());
             st.ndt_target_leaves[s] = have ? int(leaves.rows) : 0; st.ndt_score[s] = score;
+            lap(t_ndt);
         }
         for (int i = 0; i < 16; ++i) st.T_after_ndt[i] = T[i];
         // ---- GICP ---------------------------------------------------------------------------------------------------------
         const std::vector<PtI> src = filter(source, 0.5f), tgt = filter(target, 0.4f);
+        lap(t_filter);
         st.gicp_source_points = int(src.size());
         st.gicp_target_points = int(tgt.size());
         if (src.size() < 20 || tgt.size() < 20) return FLS_OK;  // computeCovariances refuses (k_correspondences_ > cloud size): no alignment
@@ -744,6 +755,8 @@ struct LoopMatcher {
             for (size_t i = 0; i < src.size(); ++i) { float o[3]; loop_xform(guess, src[i].x, src[i].y, src[i].z, o); moved[i] = PtI{o[0], o[1], o[2], src[i].i}; }
             g.moved.upload(moved, stream);
         }
+        if (timing) FLS_HIP(hipStreamSynchronize(stream));
+        lap(t_gicp_setup);
         LoopMat4f transformation = ident(), previous = ident();
         const double corr_dist = 2.0, dist_threshold = corr_dist * corr_dist, rotation_epsilon = 2e-3, transformation_epsilon = 5e-4;
         const CellGridDev cg_tgt = cell_dev(g.tgt_grid);
@@ -781,6 +794,7 @@ struct LoopMatcher {
                                     double(transformation.m[12]), double(transformation.m[13]), double(transformation.m[14]));
             if (nr >= 30 || delta < 1) { converged = true; previous = transformation; }
         }
+        lap(t_gicp);
         const LoopMat4f fin = mul(previous, guess);
         for (int i = 0; i < 16; ++i) T[i] = double(fin.m[i]);
         st.gicp_iterations = nr; st.gicp_inner_iterations = g.inner_total; st.gicp_evaluations = g.evaluations; st.gicp_correspondences = g.n_corr;
@@ -793,6 +807,10 @@ struct LoopMatcher {
             if (v[1] > 0) *fitness = float(v[0] / v[1]);
         }
         FLS_HIP(hipStreamSynchronize(stream));
+        lap(t_fit);
+        if (timing)
+            std::fprintf(stderr, "[fls loop] ms: 10 filters %.2f, leaf Gaussians + uploads %.2f, NDT align (%d evaluations) %.2f, GICP grids + covariances %.2f, GICP loop (%d evaluations) %.2f, fitness %.2f\n",
+                         t_filter, t_leaves, st.ndt_evaluations[0] + st.ndt_evaluations[1] + st.ndt_evaluations[2] + st.ndt_evaluations[3], t_ndt, t_gicp_setup, st.gicp_evaluations, t_gicp, t_fit);
         return FLS_OK;
     }
 };
