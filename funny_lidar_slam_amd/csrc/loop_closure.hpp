@@ -28,6 +28,10 @@
 #include "kernels_loop.hpp"
 #include "fitness_host.hpp"
 #include <map>
+#include <thread>
+#include <mutex>
+#include <exception>
+#include <condition_variable>
 
 namespace fls {
 
@@ -53,6 +57,10 @@ struct LoopMatcher {
         FLS_HIP(hipHostMalloc((void**)&mail_host, sizeof(LoopMail), hipHostMallocMapped));
         std::memset(mail_host, 0, sizeof(LoopMail));
         FLS_HIP(hipHostGetDevicePointer((void**)&mail_dev, mail_host, 0));
+        read_env();
+    }
+    void read_env() {  // per Match: one matcher per device is kept alive across calls (fls_reg.hip)
+        device_filter = false; debug = false;
         if (const char* e = std::getenv("FLS_DEVICE_VOXELGRID")) device_filter = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_LOOP_DEBUG")) debug = std::atoi(e) != 0;
     }
@@ -134,10 +142,10 @@ struct LoopMatcher {
         }
     };
 
+    DevScan raw;  // (device filter's staging + kernels' scratch: kept across calls)
+    DeviceVoxelGrid vg;
     std::vector<PtI> filter(const std::vector<PtI>& c, float leaf) {  // VoxelGridCloud (pointcloud_utility.h:216-271)
         if (device_filter && !c.empty()) {
-            DevScan raw;
-            DeviceVoxelGrid vg;
             raw.upload_raw(&c[0].x, c.size(), 4, stream, true);
             if (vg.run(raw.x.p, raw.y.p, raw.z.p, raw.xyz.p + 3 * c.size(), c.size(), leaf, stream)) {
                 std::vector<float> tmp;
@@ -162,6 +170,8 @@ struct LoopMatcher {
         DevBuf<float> d_centroid;
     };
     struct LeafAcc { int n = 0; double sum[3] = {0, 0, 0}, xx[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; float csum[3] = {0, 0, 0}; };
+    std::vector<int> acc_of;
+    std::vector<LeafAcc> accs;
 
     // symmetric 3x3 eigen-decomposition, ascending (SelfAdjointEigenSolver stand-in: Jacobi via hm::svd3)
     static void sym_eig3(const double* A, double* ev, double* evec) {
@@ -196,21 +206,29 @@ struct LoopMatcher {
         if (dx * dy * dz > (long long)INT_MAX) return false;
         for (int a = 0; a < 3; ++a) { tl.min_b[a] = int(std::floor(mn[a] * inv)); tl.div_b[a] = int(std::floor(mx[a] * inv)) - tl.min_b[a] + 1; }
         const int m1 = tl.div_b[0], m2 = tl.div_b[0] * tl.div_b[1];
-        std::map<int, LeafAcc> leaves;  // ascending leaf index, like PCL's std::map
+        // PCL keeps the leaves in a std::map (ascending leaf index) and adds a leaf's points in cloud order; the same sums and the same
+        // emission order come from a dense cell -> accumulator table (the grid volume is bounded above) walked in ascending cell index.
+        // (A std::map here cost ~100 ns per point: 4-5 ms per Match.)
+        const size_t n_cells = size_t(tl.div_b[0]) * tl.div_b[1] * tl.div_b[2];
+        acc_of.assign(n_cells, -1);
+        accs.clear();
         for (const PtI& p : in) {
             if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
             const int i0 = int(std::floor(p.x * inv) - float(tl.min_b[0])), i1 = int(std::floor(p.y * inv) - float(tl.min_b[1])), i2 = int(std::floor(p.z * inv) - float(tl.min_b[2]));
-            LeafAcc& l = leaves[i0 + i1 * m1 + i2 * m2];
+            int& slot = acc_of[size_t(i0 + i1 * m1 + i2 * m2)];
+            if (slot < 0) { slot = int(accs.size()); accs.emplace_back(); }
+            LeafAcc& l = accs[size_t(slot)];
             const double q[3] = {double(p.x), double(p.y), double(p.z)};
             for (int a = 0; a < 3; ++a) l.sum[a] += q[a];
             for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) l.xx[r + 3 * c] += q[r] * q[c];
             l.csum[0] += p.x; l.csum[1] += p.y; l.csum[2] += p.z;
             ++l.n;
         }
-        tl.leaf_row.assign(size_t(tl.div_b[0]) * tl.div_b[1] * tl.div_b[2], -1);
+        tl.leaf_row.assign(n_cells, -1);
         tl.mean.clear(); tl.icov.clear(); tl.centroid.clear();
-        for (const auto& kv : leaves) {
-            const LeafAcc& l = kv.second;
+        for (size_t cell_i = 0; cell_i < n_cells; ++cell_i) {
+            if (acc_of[cell_i] < 0) continue;
+            const LeafAcc& l = accs[size_t(acc_of[cell_i])];
             const int n = l.n;
             if (n < 6) continue;
             double mean[3], cov[9], icov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -232,7 +250,7 @@ struct LoopMatcher {
                 }
                 hm::inv3(cov, icov);
             }
-            tl.leaf_row[size_t(kv.first)] = int(tl.rows);
+            tl.leaf_row[cell_i] = int(tl.rows);
             for (int a = 0; a < 3; ++a) { tl.mean.push_back(mean[a]); tl.centroid.push_back(l.csum[a] / float(n)); }
             for (int a = 0; a < 9; ++a) tl.icov.push_back(icov[a]);
             ++tl.rows;
@@ -686,10 +704,68 @@ struct LoopMatcher {
         return true;
     }
 
+    // the ten filtered clouds of one Match, produced in the order the stages consume them
+    struct FilterAhead {
+        static constexpr int kN = 10;
+        std::vector<PtI> out[kN];
+        std::mutex mx;
+        std::condition_variable cv;
+        int ready = 0;
+        bool stop = false;
+        std::exception_ptr error;
+        std::thread th;
+        void start(const std::vector<PtI>& source, const std::vector<PtI>& target) {
+            th = std::thread([this, &source, &target] {
+                static const float resolution[4] = {10.0f, 5.0f, 3.0f, 2.0f};
+                for (int k = 0; k < kN; ++k) {
+                    {
+                        std::lock_guard<std::mutex> lk(mx);
+                        if (stop) return;
+                    }
+                    try {
+                        const float l = k < 8 ? resolution[k / 2] * 0.2f : (k == 8 ? 0.5f : 0.4f);  // NDT stages: resolution * 0.2f; GICP: 0.5 / 0.4
+                        out[k] = voxel_grid((k & 1) ? target : source, l);
+                    } catch (...) {
+                        std::lock_guard<std::mutex> lk(mx);
+                        error = std::current_exception();
+                        ready = kN;
+                        cv.notify_all();
+                        return;
+                    }
+                    {
+                        std::lock_guard<std::mutex> lk(mx);
+                        ready = k + 1;
+                    }
+                    cv.notify_all();
+                }
+            });
+        }
+        std::vector<PtI> take(int k) {
+            std::unique_lock<std::mutex> lk(mx);
+            cv.wait(lk, [&] { return ready > k; });
+            if (error) std::rethrow_exception(error);
+            return std::move(out[k]);
+        }
+        ~FilterAhead() {
+            if (th.joinable()) {
+                { std::lock_guard<std::mutex> lk(mx); stop = true; }
+                th.join();
+            }
+        }
+    };
+
+    // buffers that live as long as the matcher (one per device, fls_reg.hip): no allocation on the second Match
+    DeviceGridBuilder builder;
+    DevCloud src_dev, tgt_dev, src_own;
+    TargetLeaves leaves;
+    GicpRun g;
+    CellGridImage src_grid;
+
     fls_status run(const std::vector<PtI>& source, const std::vector<PtI>& target, double* T, float* fitness) {
         std::memset(&st, 0, sizeof(st));
         *fitness = std::numeric_limits<float>::max();
-        DeviceGridBuilder builder;
+        read_env();
+        FLS_HIP(hipSetDevice(device));
         // FLS_HOST_TIMING=1: where the wall time of one Match goes (stderr)
         const bool timing = std::getenv("FLS_HOST_TIMING") && std::atoi(std::getenv("FLS_HOST_TIMING")) != 0;
         double t_filter = 0, t_leaves = 0, t_ndt = 0, t_gicp_setup = 0, t_gicp = 0, t_fit = 0;
@@ -698,11 +774,17 @@ struct LoopMatcher {
         auto lap = [&](double& acc) { const double t = now(); acc += t - t0; t0 = t; };
         // ---- four NDT stages ----------------------------------------------------------------------------------------------
         static const float resolution[4] = {10.0f, 5.0f, 3.0f, 2.0f};
-        DevCloud src_dev;
-        TargetLeaves leaves;
+        // The ten VoxelGridCloud calls depend on the inputs only: with the exact host filter they run on a side thread (which
+        // borrows the worker pool), one stage ahead of the optimiser that spins on the device's result block on this thread.
+        FilterAhead ahead;
+        if (!device_filter) ahead.start(source, target);
+        auto filtered = [&](int stage, bool is_target, float leaf) -> std::vector<PtI> {
+            if (!device_filter) return ahead.take(2 * stage + (is_target ? 1 : 0));
+            return filter(is_target ? target : source, leaf);
+        };
         for (int s = 0; s < 4; ++s) {
             const float r = resolution[s];
-            const std::vector<PtI> src = filter(source, r * 0.2f), tgt = filter(target, r * 0.2f);
+            const std::vector<PtI> src = filtered(s, false, r * 0.2f), tgt = filtered(s, true, r * 0.2f);
             lap(t_filter);
             NdtRun run;
             run.resolution = r;
@@ -721,20 +803,18 @@ struct LoopMatcher {
         }
         for (int i = 0; i < 16; ++i) st.T_after_ndt[i] = T[i];
         // ---- GICP ---------------------------------------------------------------------------------------------------------
-        const std::vector<PtI> src = filter(source, 0.5f), tgt = filter(target, 0.4f);
+        const std::vector<PtI> src = filtered(4, false, 0.5f), tgt = filtered(4, true, 0.4f);
         lap(t_filter);
         st.gicp_source_points = int(src.size());
         st.gicp_target_points = int(tgt.size());
         if (src.size() < 20 || tgt.size() < 20) return FLS_OK;  // computeCovariances refuses (k_correspondences_ > cloud size): no alignment
-        GicpRun g;
         g.n_src = src.size(); g.n_tgt = tgt.size();
+        g.evaluations = g.inner_total = g.n_corr = 0;
         const LoopMat4f guess = from_d(T);
         // target grid (ids = cloud indices) + 20-NN covariances of both clouds, each in its own grid
-        DevCloud tgt_dev, src_own;
         tgt_dev.upload(tgt, stream);
         src_own.upload(src, stream);
         const float cell = 1.5f;  // 20 neighbours of a 0.4-0.5 m down-sampled cloud lie within ~1.2 m on a surface: the 27 cells certify most queries
-        CellGridImage src_grid;
         if (!builder.run(g.tgt_grid, tgt_dev.x(), tgt_dev.y(), tgt_dev.z(), tgt.size(), cell, 1, true, stream)) {
             const fls_status rc = g.tgt_grid.build(tgt, cell, stream, 1, true);
             if (rc != FLS_OK) return rc;
