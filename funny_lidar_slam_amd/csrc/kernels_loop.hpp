@@ -12,7 +12,9 @@
 //                          on d2, Mahalanobis matrix (C2 + R C1 R^T)^-1
 //   gicp_fdf_kernel        OptimizationFunctorWithIndices f / df: sum of res^T M res, translation gradient, sum of p (M res)^T
 //   loop_fitness_kernel    getFitnessScore: squared distance to the nearest target point
-//   loop_reduce_kernel     fixed-order column sums of the partial rows -> host-mapped result block + sequence word
+//   loop_block_reduce      (tail of the three summing kernels) the last workgroup to arrive adds the partial rows in index order and
+//                          publishes them to the host-mapped result block + sequence word; loop_reduce_kernel = the same as a launch of
+//                          its own (FLS_LOOP_FUSED_REDUCE=0, A/B)
 // Every sum has a fixed tree (DPP wave sum -> LDS -> rows in index order): results are bit-reproducible run to run.
 #pragma once
 #include "kernels_knn.hpp"
@@ -37,9 +39,21 @@ struct LoopMail {
     unsigned pad;
 };
 
-// block sums of NV per-lane values -> row[NV] (wave DPP sums, then the waves in order)
+// where a producing kernel leaves its result: the partial rows, the fan-in ticket (kTicketWords words, zero between launches) and the
+// host-mapped result block with the sequence number this evaluation publishes
+struct LoopOut {
+    double* rows;
+    unsigned* ticket;
+    LoopMail* mail;
+    unsigned seq;
+};
+
+// block sums of NV per-lane values -> row[NV] (wave DPP sums, then the waves in order); the LAST workgroup to arrive (sharded ticket,
+// kernels_p2plane.hpp) adds the rows in index order and publishes them -- one launch per evaluation instead of kernel + reduce kernel
+// (round 3; rows travel write-through / are read with agent-scope loads, like the partial rows of the registration kernels)
 template <int NV>
-__device__ __forceinline__ void loop_block_reduce(const double (&acc)[NV], double* __restrict__ row, double (*lds)[kLoopMaxV]) {
+__device__ __forceinline__ void loop_block_reduce(const double (&acc)[NV], const LoopOut out, double (*lds)[kLoopMaxV]) {
+    __shared__ unsigned s_last;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -51,8 +65,33 @@ __device__ __forceinline__ void loop_block_reduce(const double (&acc)[NV], doubl
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < kLoopBlock / 64; ++q) s += lds[q][threadIdx.x];
-        row[threadIdx.x] = s;
+        __hip_atomic_store((unsigned long long*)out.rows + (size_t)blockIdx.x * kLoopMaxV + threadIdx.x, (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (!out.ticket) return;  // FLS_LOOP_FUSED_REDUCE=0: loop_reduce_kernel follows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = fanin_last_arriver(out.ticket, 8);
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    const int c = threadIdx.x, nrows = (int)gridDim.x;
+    if (c < NV) {
+        const unsigned long long* col = (const unsigned long long*)out.rows + c;
+        double s = 0.0;
+        int r = 0;
+        for (; r + 8 <= nrows; r += 8) {  // eight loads in flight, adds in row order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __longlong_as_double((long long)__hip_atomic_load(col + (size_t)(r + u) * kLoopMaxV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < nrows; ++r) s += __longlong_as_double((long long)__hip_atomic_load(col + (size_t)r * kLoopMaxV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __hip_atomic_store((unsigned long long*)&out.mail->v[c], (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (c == 0) __hip_atomic_store(&out.mail->seq, out.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void __launch_bounds__(64)
@@ -95,7 +134,7 @@ struct NdtP2dPose {
 template <bool HESS>
 __global__ void __launch_bounds__(kLoopBlock)
 ndt_p2d_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n, const NdtP2dTarget tg,
-               const NdtP2dPose ps, double* __restrict__ rows) {
+               const NdtP2dPose ps, const LoopOut out) {
     constexpr int NV = HESS ? 44 : 8;  // score, grad[6], (hess[36],) count of contributing (point, leaf) pairs
     __shared__ double lds[kLoopBlock / 64][kLoopMaxV];
     double acc[NV];
@@ -184,7 +223,7 @@ ndt_p2d_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const
                     acc[NV - 1] += 1.0;
                 }
     }
-    loop_block_reduce<NV>(acc, rows + (size_t)blockIdx.x * kLoopMaxV, lds);
+    loop_block_reduce<NV>(acc, out, lds);
 }
 
 // ---- GICP --------------------------------------------------------------------------------------------------------------------
@@ -361,7 +400,7 @@ gicp_corr_kernel(const float* __restrict__ mx, const float* __restrict__ my, con
 template <bool GRAD>
 __global__ void __launch_bounds__(kLoopBlock)
 gicp_fdf_kernel(const float* __restrict__ mx, const float* __restrict__ my, const float* __restrict__ mz, const int n, const LoopMat4f T,
-                const float4* __restrict__ tgt_by_id, const int* __restrict__ corr, const double* __restrict__ mahal, double* __restrict__ rows) {
+                const float4* __restrict__ tgt_by_id, const int* __restrict__ corr, const double* __restrict__ mahal, const LoopOut out) {
     constexpr int NV = GRAD ? 14 : 2;  // f, (g_t[3], Racc[9],) count
     __shared__ double lds[kLoopBlock / 64][kLoopMaxV];
     double acc[NV];
@@ -391,12 +430,12 @@ gicp_fdf_kernel(const float* __restrict__ mx, const float* __restrict__ my, cons
         }
         acc[NV - 1] = 1.0;
     }
-    loop_block_reduce<NV>(acc, rows + (size_t)blockIdx.x * kLoopMaxV, lds);
+    loop_block_reduce<NV>(acc, out, lds);
 }
 
 __global__ void __launch_bounds__(kLoopBlock)
 loop_fitness_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n, const LoopMat4f T,
-                    const CellGridDev cg_tgt, double* __restrict__ rows) {
+                    const CellGridDev cg_tgt, const LoopOut out) {
     __shared__ double lds[kLoopBlock / 64][kLoopMaxV];
     double acc[2] = {0.0, 0.0};
     const int i = blockIdx.x * kLoopBlock + threadIdx.x;
@@ -408,7 +447,7 @@ loop_fitness_kernel(const float* __restrict__ sx, const float* __restrict__ sy, 
         knn_grid<1>(cg_tgt, q[0], q[1], q[2], INFINITY, r, a, b, c);
         if (r.found) { acc[0] = (double)r.d[0]; acc[1] = 1.0; }
     }
-    loop_block_reduce<2>(acc, rows + (size_t)blockIdx.x * kLoopMaxV, lds);
+    loop_block_reduce<2>(acc, out, lds);
 }
 
 }  // namespace fls

@@ -42,6 +42,8 @@ struct LoopMatcher {
     LoopMail* mail_dev = nullptr;
     unsigned seq = 0;
     DevBuf<double> d_rows;
+    DevBuf<unsigned> d_ticket;
+    bool fused_reduce = true;  // FLS_LOOP_FUSED_REDUCE=0: partial rows summed by a launch of their own
     bool device_filter = false;
     bool debug = false;  // FLS_LOOP_DEBUG=1: one line per GICP outer iteration on stderr
     fls_loop_stats st{};
@@ -60,7 +62,8 @@ struct LoopMatcher {
         read_env();
     }
     void read_env() {  // per Match: one matcher per device is kept alive across calls (fls_reg.hip)
-        device_filter = false; debug = false;
+        device_filter = false; debug = false; fused_reduce = true;
+        if (const char* e = std::getenv("FLS_LOOP_FUSED_REDUCE")) fused_reduce = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_DEVICE_VOXELGRID")) device_filter = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_LOOP_DEBUG")) debug = std::atoi(e) != 0;
     }
@@ -104,10 +107,14 @@ struct LoopMatcher {
     template <class F>
     const double* reduce(int nrows, int nv, F&& fill) {
         d_rows.reserve(size_t(std::max(nrows, 1)) * kLoopMaxV);
-        fill(d_rows.p);
+        if (!d_ticket.p) {
+            d_ticket.reserve(kTicketWords);
+            FLS_HIP(hipMemsetAsync(d_ticket.p, 0, kTicketWords * sizeof(unsigned), stream));
+        }
         seq = (seq + 1u) & 0x7fffffffu;
         if (seq == 0u) seq = 1u;
-        hipLaunchKernelGGL(loop_reduce_kernel, dim3(1), dim3(64), 0, stream, (const double*)d_rows.p, nrows, nv, mail_dev, seq);
+        fill(LoopOut{d_rows.p, fused_reduce ? d_ticket.p : nullptr, mail_dev, seq});
+        if (!fused_reduce) hipLaunchKernelGGL(loop_reduce_kernel, dim3(1), dim3(64), 0, stream, (const double*)d_rows.p, nrows, nv, mail_dev, seq);
         FLS_HIP(hipGetLastError());
         for (unsigned long long spin = 1;; ++spin) {
             if (__atomic_load_n(&mail_host->seq, __ATOMIC_ACQUIRE) == seq) break;
@@ -120,6 +127,8 @@ struct LoopMatcher {
             __builtin_ia32_pause();
 #endif
         }
+        // (the stream went idle: the block must be there -- anything else is a lost fan-in, never a result to use)
+        if (__atomic_load_n(&mail_host->seq, __ATOMIC_ACQUIRE) != seq) throw HipError(hipErrorUnknown, "fls_loop_match: the device left no result block for an evaluation");
         return mail_host->v;
     }
 
@@ -305,7 +314,7 @@ struct LoopMatcher {
                         tl.inv, r.resolution * r.resolution};
         const int n = int(r.src->n), nb = (n + kLoopBlock - 1) / kLoopBlock;
         ++r.evaluations;
-        const double* v = reduce(nb, hessian ? 44 : 8, [&](double* rows) {
+        const double* v = reduce(nb, hessian ? 44 : 8, [&](const LoopOut rows) {
             if (hessian) hipLaunchKernelGGL(ndt_p2d_kernel<true>, dim3(unsigned(nb)), dim3(kLoopBlock), 0, stream, r.src->x(), r.src->y(), r.src->z(), n, tg, r.pose, rows);
             else hipLaunchKernelGGL(ndt_p2d_kernel<false>, dim3(unsigned(nb)), dim3(kLoopBlock), 0, stream, r.src->x(), r.src->y(), r.src->z(), n, tg, r.pose, rows);
         });
@@ -522,7 +531,7 @@ struct LoopMatcher {
         apply_state(T, x);
         const int n = int(g.n_src), nb = (n + kLoopBlock - 1) / kLoopBlock;
         const bool with_g = grad != nullptr;
-        const double* v = reduce(nb, with_g ? 14 : 2, [&](double* rows) {
+        const double* v = reduce(nb, with_g ? 14 : 2, [&](const LoopOut rows) {
             if (with_g) hipLaunchKernelGGL(gicp_fdf_kernel<true>, dim3(unsigned(nb)), dim3(kLoopBlock), 0, stream, g.moved.x(), g.moved.y(), g.moved.z(), n, T,
                                            (const float4*)g.tgt_grid.d_by_id.p, (const int*)g.corr.p, (const double*)g.mahal.p, rows);
             else hipLaunchKernelGGL(gicp_fdf_kernel<false>, dim3(unsigned(nb)), dim3(kLoopBlock), 0, stream, g.moved.x(), g.moved.y(), g.moved.z(), n, T,
@@ -766,6 +775,7 @@ struct LoopMatcher {
         *fitness = std::numeric_limits<float>::max();
         read_env();
         FLS_HIP(hipSetDevice(device));
+        if (d_ticket.p) FLS_HIP(hipMemsetAsync(d_ticket.p, 0, kTicketWords * sizeof(unsigned), stream));  // (a Match that failed half-way must not poison the next)
         // FLS_HOST_TIMING=1: where the wall time of one Match goes (stderr)
         const bool timing = std::getenv("FLS_HOST_TIMING") && std::atoi(std::getenv("FLS_HOST_TIMING")) != 0;
         double t_filter = 0, t_leaves = 0, t_ndt = 0, t_gicp_setup = 0, t_gicp = 0, t_fit = 0;
@@ -881,7 +891,7 @@ struct LoopMatcher {
         // ---- getFitnessScore ------------------------------------------------------------------------------------------------
         {
             const int n = int(src.size()), nb = (n + kLoopBlock - 1) / kLoopBlock;
-            const double* v = reduce(nb, 2, [&](double* rows) {
+            const double* v = reduce(nb, 2, [&](const LoopOut rows) {
                 hipLaunchKernelGGL(loop_fitness_kernel, dim3(unsigned(nb)), dim3(kLoopBlock), 0, stream, src_own.x(), src_own.y(), src_own.z(), n, fin, cg_tgt, rows);
             });
             if (v[1] > 0) *fitness = float(v[0] / v[1]);
