@@ -282,17 +282,22 @@ fls_status fls_loop_match(int device_id, const float* source, size_t n_source, c
         const bool timing = std::getenv("FLS_HOST_TIMING") && std::atoi(std::getenv("FLS_HOST_TIMING")) != 0;
         const auto t0 = std::chrono::steady_clock::now();
         // one matcher per device, kept for the life of the process (stream, result block, device buffers: ~3 ms to set up, the
-        // reference's loop-closure thread calls Match once per candidate); calls on one device are serialised.  Never destroyed:
+        // reference's loop-closure thread calls Match once per candidate); calls on one device are serialised (run_mx).  Never destroyed:
         // static destruction would run after the HIP runtime's own teardown.
         static std::mutex mx;
         static std::map<int, LoopMatcher*>* cache = new std::map<int, LoopMatcher*>();
-        std::lock_guard<std::mutex> lk(mx);
-        LoopMatcher*& m = (*cache)[device_id];
-        if (!m) {
-            std::unique_ptr<LoopMatcher> fresh(new LoopMatcher());
-            fresh->init(device_id);
-            m = fresh.release();
+        LoopMatcher* m = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mx);
+            LoopMatcher*& slot = (*cache)[device_id];
+            if (!slot) {
+                std::unique_ptr<LoopMatcher> fresh(new LoopMatcher());
+                fresh->init(device_id);
+                slot = fresh.release();
+            }
+            m = slot;
         }
+        std::lock_guard<std::mutex> run_lk(m->run_mx);  // (devices run side by side, calls on one device one after the other)
         if (timing) std::fprintf(stderr, "[fls loop] ms: matcher set-up %.2f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         const fls_status rc = m->run(cloud_from(source, n_source, stride), cloud_from(target, n_target, stride), T, fitness);
         if (stats) *stats = m->st;

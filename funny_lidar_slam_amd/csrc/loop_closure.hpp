@@ -36,6 +36,7 @@
 namespace fls {
 
 struct LoopMatcher {
+    std::mutex run_mx;  // held by fls_loop_match for the duration of a Match
     int device = 0;
     hipStream_t stream = nullptr;
     LoopMail* mail_host = nullptr;

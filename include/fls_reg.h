@@ -176,7 +176,9 @@ fls_status fls_voxel_grid_cloud(int device_id, fls_voxelgrid_mode mode, const fl
  * distance) over VoxelGridCloud(source, 0.5) / VoxelGridCloud(target, 0.4), return value gicp.getFitnessScore().
  * source / target: n x stride floats (as fls_match); T_colmajor: the initial guess in, the aligned pose out (target <- source);
  * *fitness: mean squared nearest-neighbour distance (FLT_MAX when GICP could not run: fewer than 20 filtered points).
- * Per-point work runs on the device, the six-parameter optimisers on the host (csrc/loop_closure.hpp).  Stateless: no handle. */
+ * Per-point work runs on the device, the six-parameter optimisers on the host (csrc/loop_closure.hpp).  No handle and no state a
+ * caller can observe: the library keeps one set of device buffers per device for the life of the process (the second call on a
+ * device allocates nothing); calls on one device run one after the other, calls on different devices side by side.       */
 typedef struct fls_loop_stats {
     int32_t ndt_iterations[4];     /* per resolution stage: Newton iterations                       */
     int32_t ndt_evaluations[4];    /*                       score / derivative evaluations          */
