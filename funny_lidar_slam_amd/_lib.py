@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = [
     "fls_scan_upload", "fls_match_resident", "fls_match_batch", "fls_map_export", "fls_map_import", "fls_get_iteration_log", "fls_get_correspondences", "fls_map_size",
     "fls_set_profiling", "fls_get_kernel_time", "fls_get_traffic_counters", "fls_get_debug_stamps", "fls_debug_fullpiv_qr6", "fls_debug_voxel_grid", "fls_voxel_grid_cloud", "fls_loop_match", "fls_status_string", "fls_abi_version",
     "fls_device_count",
+    "fls_replicas_create", "fls_replicas_refresh", "fls_replicas_match_batch", "fls_replicas_import_ms", "fls_replicas_destroy",
     # include/fls_features.h
     "fls_features_create", "fls_features_destroy", "fls_features_project", "fls_features_extract", "fls_features_get", "fls_features_get_time",
 ]
@@ -146,6 +147,17 @@ def lib():
         L.fls_match_batch.restype = C.c_int
         L.fls_match_batch.argtypes = [hp, C.c_size_t, C.POINTER(fp), C.POINTER(C.c_size_t), C.POINTER(fp), C.POINTER(C.c_size_t), C.c_int,
                                       dp, C.POINTER(Stats), ip, C.c_int]
+        L.fls_replicas_create.restype = C.c_int
+        L.fls_replicas_create.argtypes = [hp, ip, C.c_int, C.POINTER(C.c_void_p)]
+        L.fls_replicas_refresh.restype = C.c_int
+        L.fls_replicas_refresh.argtypes = [C.c_void_p]
+        L.fls_replicas_match_batch.restype = C.c_int
+        L.fls_replicas_match_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(fp), C.POINTER(C.c_size_t), C.POINTER(fp), C.POINTER(C.c_size_t), C.c_int,
+                                               dp, C.POINTER(Stats), ip, C.c_int]
+        L.fls_replicas_import_ms.restype = C.c_int
+        L.fls_replicas_import_ms.argtypes = [C.c_void_p, dp, C.c_int]
+        L.fls_replicas_destroy.restype = None
+        L.fls_replicas_destroy.argtypes = [C.c_void_p]
         L.fls_get_iteration_log.restype = C.c_int
         L.fls_get_iteration_log.argtypes = [hp, dp, ip, dp, C.c_int]
         L.fls_get_correspondences.restype = C.c_int

@@ -7,6 +7,7 @@
 #include "matcher_ndt.hpp"
 #include "features_host.hpp"
 #include "loop_closure.hpp"
+#include "replicas.hpp"
 #include <new>
 
 using namespace fls;
@@ -158,6 +159,62 @@ fls_status fls_map_import(fls_handle h, const void* blob, size_t n) {
     if (!h || !blob) return FLS_ERR_INVALID;
     return guarded([&]() -> fls_status { FLS_HIP(hipSetDevice(h->device)); return h->map_import(blob, n); });
 }
+
+fls_status fls_replicas_create(fls_handle owner, const int* device_ids, int n_devices, fls_replicas_handle* out) {
+    if (!out) return FLS_ERR_INVALID;
+    *out = nullptr;
+    if (!owner || !device_ids || n_devices <= 0 || n_devices > 64) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FLS_ERR_DEVICE;
+        for (int i = 0; i < n_devices; ++i)
+            if (device_ids[i] < 0 || device_ids[i] >= n) return FLS_ERR_DEVICE;
+        std::unique_ptr<fls_replicas> r(new fls_replicas());
+        r->owner = owner;
+        bool owner_used = false;
+        for (int i = 0; i < n_devices; ++i) {
+            r->devices.push_back(device_ids[i]);
+            r->import_ms.push_back(0.0);
+            if (device_ids[i] == owner->device && !owner_used) {
+                owner_used = true;
+                r->handles.push_back(owner);
+                r->owned.push_back(0);
+                continue;
+            }
+            fls_handle h = nullptr;
+            const fls_status rc = fls_create(owner->kind, &owner->p, device_ids[i], &h);
+            if (rc < 0) return rc;  // (the set's destructor releases what was created so far)
+            r->handles.push_back(h);
+            r->owned.push_back(1);
+        }
+        const fls_status rc = r->refresh();
+        if (rc < 0) return rc;
+        *out = r.release();
+        return FLS_OK;
+    });
+}
+
+fls_status fls_replicas_refresh(fls_replicas_handle r) {
+    if (!r) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status { return r->refresh(); });
+}
+
+fls_status fls_replicas_match_batch(fls_replicas_handle r, size_t n_jobs, const float* const* src0, const size_t* n0, const float* const* src1,
+                                    const size_t* n1, int stride, double* T, fls_stats* stats, int32_t* status, int lanes) {
+    if (!r || stride < 3 || (n_jobs && (!src0 || !n0 || !T))) return FLS_ERR_INVALID;
+    if ((src1 == nullptr) != (n1 == nullptr)) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status { return r->match_batch(n_jobs, src0, n0, src1, n1, stride, T, stats, status, lanes); });
+}
+
+int fls_replicas_import_ms(fls_replicas_handle r, double* ms, int cap) {
+    if (!r) return 0;
+    const int n = int(r->import_ms.size());
+    for (int i = 0; i < std::min(n, cap); ++i)
+        if (ms) ms[i] = r->import_ms[size_t(i)];
+    return n;
+}
+
+void fls_replicas_destroy(fls_replicas_handle r) { delete r; }
 
 fls_status fls_get_fitness_score(fls_handle h, float max_range, float* score) {
     if (!h || !score) return FLS_ERR_INVALID;

@@ -1,0 +1,74 @@
+// replicas.hpp -- one process, several GPUs: the native host side of BASELINE configs[4] / SURVEY.md 8e ("one process + N host
+// threads ... C++ host calling HIP through a thin C-ABI").  A replica set holds one handle per listed device, each carrying a copy of
+// the owner handle's map (exported once as the self-describing host image of fls_map_export and imported per device on that device's
+// own host thread: 24 MB for the 1e6-point map, against ~340 MB for the device image it is rebuilt into -- so the image travels over
+// PCIe from host memory, not device to device).  fls_replicas_match_batch block-partitions the jobs over the devices (the same
+// partition as batch.py), runs fls_match_batch per device on its own host thread and writes every result straight into the caller's
+// arrays: no collective, no gather step -- the ranks share an address space.  Built on the public entry points only.
+// torch.distributed (one process per GPU, bench.py --gpus N) remains the multi-process form of the same sharding.
+#pragma once
+#include "../../include/fls_reg.h"
+#include <exception>
+#include <thread>
+#include <vector>
+
+struct fls_replicas {
+    fls_handle owner = nullptr;
+    std::vector<int> devices;
+    std::vector<fls_handle> handles;  // handles[i] serves devices[i]; the owner itself serves the first entry that names its device
+    std::vector<char> owned;          // created (and destroyed) by the set
+    std::vector<double> import_ms;    // last replication, per entry (0 for the owner's own entry)
+
+    ~fls_replicas() {
+        for (size_t i = 0; i < handles.size(); ++i)
+            if (owned[i] && handles[i]) fls_destroy(handles[i]);
+    }
+
+    // (re-)replicate the owner's current map
+    fls_status refresh() {
+        const size_t need = fls_map_export(owner, nullptr, 0);
+        if (need == 0) return FLS_ERR_STATE;  // kind without an exportable image, or no map yet
+        std::vector<unsigned char> blob(need);
+        if (fls_map_export(owner, blob.data(), blob.size()) != need) return FLS_ERR_STATE;
+        std::vector<fls_status> rc(handles.size(), FLS_OK);
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < handles.size(); ++i) {
+            if (!owned[i]) continue;
+            th.emplace_back([&, i] {
+                const auto t0 = std::chrono::steady_clock::now();
+                rc[i] = fls_map_import(handles[i], blob.data(), blob.size());
+                import_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            });
+        }
+        for (auto& t : th) t.join();
+        for (fls_status r : rc)
+            if (r < 0) return r;
+        return FLS_OK;
+    }
+
+    static void block(size_t n_jobs, size_t world, size_t rank, size_t& begin, size_t& end) {  // batch.py::partition
+        const size_t base = n_jobs / world, extra = n_jobs % world;
+        begin = rank * base + std::min(rank, extra);
+        end = begin + base + (rank < extra ? 1 : 0);
+    }
+
+    fls_status match_batch(size_t n_jobs, const float* const* src0, const size_t* n0, const float* const* src1, const size_t* n1, int stride, double* T,
+                           fls_stats* stats, int32_t* status, int lanes) {
+        const size_t world = handles.size();
+        std::vector<fls_status> rc(world, FLS_OK);
+        std::vector<std::thread> th;
+        for (size_t r = 0; r < world; ++r) {
+            size_t b, e;
+            block(n_jobs, world, r, b, e);
+            if (b == e) continue;
+            th.emplace_back([&, r, b, e] {
+                rc[r] = fls_match_batch(handles[r], e - b, src0 + b, n0 + b, src1 ? src1 + b : nullptr, n1 ? n1 + b : nullptr, stride, T + 16 * b, stats ? stats + b : nullptr,
+                                        status ? status + b : nullptr, lanes);
+            });
+        }
+        for (auto& t : th) t.join();
+        for (fls_status r : rc)
+            if (r < 0) return r;
+        return FLS_OK;
+    }
+};

@@ -99,9 +99,7 @@ class RegistrationInterface:
         T[...] = Tf.reshape(4, 4).T
         return rc == _lib.FLS_OK
 
-    def MatchBatch(self, clusters, T_inits, lanes: int = 4):
-        """fls_match_batch: independent registrations of `clusters[j]` from `T_inits[j]` against the current map (no map
-        update, no state carried between jobs).  Returns (ok[j], T[j] (n,4,4), stats[j]) -- BASELINE configs[4]."""
+    def _batch_args(self, clusters, T_inits):
         n = len(clusters)
         fp = C.POINTER(C.c_float)
         keep, p0s, n0s, p1s, n1s = [], (fp * n)(), (C.c_size_t * n)(), (fp * n)(), (C.c_size_t * n)()
@@ -119,14 +117,21 @@ class RegistrationInterface:
                 two = True
                 p1s[j], n1s[j] = p1, n1
         Tf = np.ascontiguousarray(np.asarray(T_inits, dtype=np.float64).reshape(n, 4, 4).transpose(0, 2, 1)).reshape(-1)  # column-major
-        stats = (Stats * n)()
-        status = (C.c_int32 * n)()
-        rc = _lib.lib().fls_match_batch(self._h, n, p0s, n0s, p1s if two else None, n1s if two else None, stride or 3,
-                                        Tf.ctypes.data_as(C.POINTER(C.c_double)), stats, status, int(lanes))
+        return n, keep, p0s, n0s, (p1s if two else None), (n1s if two else None), stride or 3, Tf, (Stats * n)(), (C.c_int32 * n)()
+
+    def MatchBatch(self, clusters, T_inits, lanes: int = 4):
+        """fls_match_batch: independent registrations of `clusters[j]` from `T_inits[j]` against the current map (no map
+        update, no state carried between jobs).  Returns (ok[j], T[j] (n,4,4), stats[j]) -- BASELINE configs[4]."""
+        n, keep, p0s, n0s, p1s, n1s, stride, Tf, stats, status = self._batch_args(clusters, T_inits)
+        rc = _lib.lib().fls_match_batch(self._h, n, p0s, n0s, p1s, n1s, stride, Tf.ctypes.data_as(C.POINTER(C.c_double)), stats, status, int(lanes))
         if rc < 0:
             raise FlsError(rc, "fls_match_batch")
         T = Tf.reshape(n, 4, 4).transpose(0, 2, 1).copy()
         return [status[j] == _lib.FLS_OK for j in range(n)], T, list(stats)
+
+    def Replicas(self, device_ids):
+        """fls_replicas_create: one handle per entry of device_ids, each with a copy of this handle's map (one process, N GPUs)."""
+        return ReplicaSet(self, device_ids)
 
     def GetFitnessScore(self, max_range: float) -> float:
         out = C.c_float()
@@ -420,3 +425,43 @@ YAML_NCLT_LOAM_FULL = dict(optimization_iter_num=30, local_corner_map_size=50, l
 YAML_NCLT_LOC_KDTREE = dict(optimization_iter_num=8, point_to_planar_thres=0.1, position_converge_thres=0.005,
                             rotation_converge_thres=0.005, local_map_size=0, local_map_cloud_filter_size=0.5,
                             keyframe_delta_distance=0.0, keyframe_delta_rotation=0.0)  # config/localization/config_nclt.yaml:40-50
+
+
+class ReplicaSet:
+    """Native one-process multi-GPU form of BASELINE configs[4] (include/fls_reg.h: fls_replicas_*): the owner's map image
+    replicated per device, jobs block-partitioned over the devices, one host thread per device inside the library."""
+
+    def __init__(self, owner, device_ids):
+        self._owner = owner  # keeps the owner handle alive
+        ids = (C.c_int32 * len(device_ids))(*[int(d) for d in device_ids])
+        h = C.c_void_p()
+        rc = _lib.lib().fls_replicas_create(owner._h, ids, len(device_ids), C.byref(h))
+        if rc != _lib.FLS_OK:
+            raise FlsError(rc, "fls_replicas_create")
+        self._r = h
+        self.n = len(device_ids)
+
+    def close(self):
+        if getattr(self, "_r", None):
+            _lib.lib().fls_replicas_destroy(self._r)
+            self._r = None
+
+    __del__ = close
+
+    def Refresh(self):
+        rc = _lib.lib().fls_replicas_refresh(self._r)
+        if rc != _lib.FLS_OK:
+            raise FlsError(rc, "fls_replicas_refresh")
+
+    def import_ms(self):
+        buf = (C.c_double * self.n)()
+        _lib.lib().fls_replicas_import_ms(self._r, buf, self.n)
+        return list(buf)
+
+    def MatchBatch(self, clusters, T_inits, lanes: int = 4):
+        n, keep, p0s, n0s, p1s, n1s, stride, Tf, stats, status = self._owner._batch_args(clusters, T_inits)
+        rc = _lib.lib().fls_replicas_match_batch(self._r, n, p0s, n0s, p1s, n1s, stride, Tf.ctypes.data_as(C.POINTER(C.c_double)), stats, status, int(lanes))
+        if rc < 0:
+            raise FlsError(rc, "fls_replicas_match_batch")
+        T = Tf.reshape(n, 4, 4).transpose(0, 2, 1).copy()
+        return [status[j] == _lib.FLS_OK for j in range(n)], T, list(stats)

@@ -153,6 +153,24 @@ fls_status fls_match_batch(fls_handle h, size_t n_jobs, const float* const* src0
 size_t fls_map_export(fls_handle h, void* blob, size_t cap_bytes);
 fls_status fls_map_import(fls_handle h, const void* blob, size_t n_bytes);
 
+/* ---- one process, several GPUs ("one process + N host threads"; BASELINE configs[4]) ---------------------------
+ * A replica set = one handle per entry of device_ids, each holding a copy of the owner's map image (fls_map_export once,
+ * fls_map_import per device on that device's own host thread); the owner itself serves the first entry that names its own
+ * device, so {owner's device} alone is valid and {d, d} gives two handles on one GPU (what the tests use on a one-GPU box).
+ * fls_replicas_match_batch = fls_match_batch with the jobs block-partitioned over the entries (job j of the caller's arrays
+ * lands on entry floor-partition(j); results are written straight into the caller's arrays: one address space, no gather),
+ * one host thread per entry, `lanes` stream lanes per entry.  Every job still equals a fresh reference matcher holding the
+ * owner's map, so the table is independent of the device list.  fls_replicas_refresh re-replicates after the owner's map
+ * changed.  The owner must outlive the set and must not run a Match of its own while a batch is in flight.
+ * FLS_P2PLANE_IVOX only (the kind with an exportable image); fls_replicas_import_ms: per entry, the last replication.      */
+typedef struct fls_replicas* fls_replicas_handle;
+fls_status fls_replicas_create(fls_handle owner, const int* device_ids, int n_devices, fls_replicas_handle* out);
+fls_status fls_replicas_refresh(fls_replicas_handle r);
+fls_status fls_replicas_match_batch(fls_replicas_handle r, size_t n_jobs, const float* const* src0, const size_t* n0, const float* const* src1,
+                                    const size_t* n1, int stride_floats, double* T_colmajor, fls_stats* stats, int32_t* status, int lanes);
+int fls_replicas_import_ms(fls_replicas_handle r, double* ms, int cap);
+void fls_replicas_destroy(fls_replicas_handle r);
+
 /* ---- VoxelGridCloud  (include/common/pointcloud_utility.h:216-271 = pcl::VoxelGrid<PointXYZI>::filter) -------------------------
  * The stand-alone filter the pipeline applies OUTSIDE the matchers: the planar / corner voxel filters of the preprocessing
  * thread that feed Match (src/slam/preprocessing.cpp:224-237) and the sub-map / multi-resolution filters of loop closure
