@@ -657,6 +657,18 @@ icp_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const
     block_row_from_wave_sums(wsum, partials);
 }
 
+// what the last workgroup of a fused fit + Gauss-Newton launch needs (LoamFull's dual launch; FLS_FUSED_TAIL)
+struct LoamFusedTail {
+    const double* partials_a;  // corner rows
+    const double* partials_b;  // planar rows
+    int nrows_a, nrows_b;
+    double rot_thr, pos_thr;
+    unsigned* ticket;
+    int shards;
+    Mailbox* mb;
+    unsigned match_id;
+};
+
 // ---------------------------------------------------------------------------------------------
 // point-to-plane / point-to-line on the 5 exact neighbours left by grid_knn_kernel<5>
 // LINE = false: plane (Appendix C.1), LINE = true: corner feature (Appendix C.2)
@@ -667,12 +679,15 @@ feature_fit_body(const int bid, const float* __restrict__ sx, const float* __res
                  const GnState* __restrict__ st, const int first, const Pose16& T0, const float4* __restrict__ nn_pts /* [n][5] */,
                  const unsigned char* __restrict__ nn_cnt, const float* __restrict__ kth_d2, const float gate, const double thres,
                  int* __restrict__ nn_id /* [n][5] */, unsigned char* __restrict__ cnt_out, double* __restrict__ Jst /* [7][n] */,
-                 unsigned char* __restrict__ flag, double* __restrict__ partials) {
+                 unsigned char* __restrict__ flag, double* __restrict__ partials, const LoamFusedTail* __restrict__ ft = nullptr) {
     const int i = bid * 256 + threadIdx.x;
     const int done = first ? 0 : st->done;
     double T44[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) T44[k] = first ? T0.m[k] : st->T[k];
+    // (fused tail: the state words the last workgroup needs, loaded before any waiting)
+    const double last_rot = (ft && !first) ? st->last_rot : 0.0, last_pos = (ft && !first) ? st->last_pos : 0.0;
+    const int it = (ft && !first) ? st->iter : 0;
     if (done) return;
     __shared__ double wsum[4][32];
     bool contrib = false;
@@ -709,7 +724,23 @@ feature_fit_body(const int bid, const float* __restrict__ sx, const float* __res
         }
     }
     reduce_rank1_and_store(contrib, J, res, &wsum[threadIdx.x >> 6][0]);
-    block_row_from_wave_sums(wsum, partials, bid);
+    if (!ft) { block_row_from_wave_sums(wsum, partials, bid); return; }
+    // fused Gauss-Newton tail (round 3, LOAM dual launch): the row goes out write-through, the last workgroup of the WHOLE launch (both
+    // feature classes) sums the corner rows, then the planar rows (SumCoefficient's order) and runs the LOAM-family tail
+    __syncthreads();
+    const double v = threadIdx.x < 29 ? ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x] : 0.0;
+    __shared__ unsigned s_ticket;
+    __shared__ LoamTailSmem sm;
+    if (threadIdx.x < 29)
+        __hip_atomic_store((unsigned long long*)partials + (size_t)bid * kPartialStride + threadIdx.x, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = fanin_last_arriver(ft->ticket, ft->shards);
+    __syncthreads();
+    if (!s_ticket) return;
+    GnState* const stw = const_cast<GnState*>(st);
+    loam_tail<256, true>(stw, sm, ft->partials_a, ft->nrows_a, ft->partials_b, ft->nrows_b, ft->rot_thr, ft->pos_thr, T44, last_rot, last_pos, it, ft->mb, ft->match_id);
 }
 
 template <bool LINE>
@@ -738,13 +769,15 @@ struct FeatureFitArgs {
     double* partials;
 };
 __global__ void __launch_bounds__(256)
-feature_fit_dual_kernel(const GnState* __restrict__ st, const int first, const Pose16 T0, const FeatureFitArgs line, const FeatureFitArgs plane, const int nb_line) {
+feature_fit_dual_kernel(const GnState* __restrict__ st, const int first, const Pose16 T0, const FeatureFitArgs line, const FeatureFitArgs plane, const int nb_line,
+                        const LoamFusedTail tail /* ticket == nullptr: gn_solve_loam_kernel follows */) {
+    const LoamFusedTail* const ft = tail.ticket ? &tail : nullptr;
     if ((int)blockIdx.x < nb_line)
         feature_fit_body<true>((int)blockIdx.x, line.sx, line.sy, line.sz, line.n, st, first, T0, line.nn_pts, line.nn_cnt, line.kth_d2, line.gate, line.thres,
-                               line.nn_id, line.cnt_out, line.Jst, line.flag, line.partials);
+                               line.nn_id, line.cnt_out, line.Jst, line.flag, line.partials, ft);
     else
         feature_fit_body<false>((int)blockIdx.x - nb_line, plane.sx, plane.sy, plane.sz, plane.n, st, first, T0, plane.nn_pts, plane.nn_cnt, plane.kth_d2,
-                                plane.gate, plane.thres, plane.nn_id, plane.cnt_out, plane.Jst, plane.flag, plane.partials);
+                                plane.gate, plane.thres, plane.nn_id, plane.cnt_out, plane.Jst, plane.flag, plane.partials, ft);
 }
 
 }  // namespace fls

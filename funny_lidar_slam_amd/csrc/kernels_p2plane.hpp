@@ -201,7 +201,7 @@ __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem
                                           const double rot_thr, const double pos_thr, double (&Tl)[16], const double last_rot,
                                           const double last_pos, const int it, Mailbox* __restrict__ mb = nullptr,
                                           const unsigned match_id = 0u) {
-    if (nrows_a > 0) reduce_partials<NT>(partials_a, nrows_a, sm.tot_a, sm.red);
+    if (nrows_a > 0) reduce_partials<NT, SC1>(partials_a, nrows_a, sm.tot_a, sm.red);
     else { if (threadIdx.x < 32) sm.tot_a[threadIdx.x] = 0.0; __syncthreads(); }
     FLS_STAMP(2);
     reduce_partials<NT, SC1>(partials_b, nrows_b, sm.tot_b, sm.red);

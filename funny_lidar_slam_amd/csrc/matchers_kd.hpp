@@ -256,10 +256,13 @@ struct LoamFullMatcher final : fls_matcher {
     hm::KeyframeGate gate;
     bool grid27 = false;     // FLS_GRID27=1: gate-sized cells + the one-stage 27-cell kernel (measured slower: A/B switch)
     bool dual_launch = true;  // FLS_LOAM_DUAL=0: one correspondence + one fit launch per feature class
+    bool loam_fused_tail = true;  // FLS_FUSED_TAIL=0: gn_solve_loam_kernel as a launch of its own after the dual fit launch
+    DevBuf<unsigned> d_loam_ticket;
 
     fls_status init() {
         if (const char* e = std::getenv("FLS_GRID27")) grid27 = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_LOAM_DUAL")) dual_launch = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_FUSED_TAIL")) loam_fused_tail = std::atoi(e) != 0;
         if (unset_d(p.point_to_planar_thres) || unset_d(p.point_search_thres) || unset_d(p.line_ratio_thres) ||
             unset_d(p.position_converge_thres) || unset_d(p.rotation_converge_thres) || unset_d(p.rot_thre_add_cloud) ||
             unset_d(p.dist_thre_add_cloud))
@@ -267,6 +270,8 @@ struct LoamFullMatcher final : fls_matcher {
         if (p.local_planar_size == 0 || p.local_corner_size == 0) return FLS_ERR_INVALID;  // CHECK_GT :55-56
         if (!(p.point_search_thres > 0.0) || !(p.corner_voxel_filter_size > 0.f) || !(p.planar_voxel_filter_size > 0.f)) return FLS_ERR_INVALID;
         init_common();
+        d_loam_ticket.reserve(kTicketWords);
+        FLS_HIP(hipMemsetAsync(d_loam_ticket.p, 0, kTicketWords * sizeof(unsigned), stream));
         mapdev_planar.init();
         mapdev_corner.init();
         return FLS_OK;
@@ -330,8 +335,15 @@ struct LoamFullMatcher final : fls_matcher {
                 const int kc = int((((nc * 8 + 255) / 256) + 63) / 64 * 64), kp = int((((np * 8 + 255) / 256) + 63) / 64 * 64);
                 hipLaunchKernelGGL((grid_knn_dual_kernel<5, false>), dim3(unsigned(kc + kp)), dim3(256), 0, stream, (const GnState*)d_state.p, first, T0,
                                    corner.knn_args(cgc, gate_f), planar.knn_args(cgp, gate_f), kc);
+                const bool fuse = loam_fused_tail;
+                const LoamFusedTail tail{(const double*)d_partials_a.p, (const double*)d_partials_b.p, nbc, nbp, p.rotation_converge_thres, p.position_converge_thres,
+                                         fuse ? d_loam_ticket.p : nullptr, 8, mb_dev, launch_word()};
                 hipLaunchKernelGGL(feature_fit_dual_kernel, dim3(unsigned(nbc + nbp)), dim3(256), 0, stream, (const GnState*)d_state.p, first, T0,
-                                   corner.fit_args(gate_f, p.line_ratio_thres, d_partials_a.p), planar.fit_args(gate_f, p.point_to_planar_thres, d_partials_b.p), nbc);
+                                   corner.fit_args(gate_f, p.line_ratio_thres, d_partials_a.p), planar.fit_args(gate_f, p.point_to_planar_thres, d_partials_b.p), nbc, tail);
+                if (fuse) {
+                    if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
+                    return;
+                }
             } else {
                 corner.launch<true>(stream, d_state.p, first, T0, cgc, gate_f, p.line_ratio_thres, d_partials_a.p);
                 planar.launch<false>(stream, d_state.p, first, T0, cgp, gate_f, p.point_to_planar_thres, d_partials_b.p);

@@ -14,7 +14,7 @@ o = util.oracle_for("LoamFull_KdTree", y); o.AddCloudToLocalMap(cfg["map"], cfg[
 ok_ref, T_ref = o.Match(cfg["scan"], np.eye(4), src1=cfg["corner_scan"], update_map=False)
 cl = util.cluster_for("LoamFull_KdTree", cfg["scan"], cfg["corner_scan"])
 for arm in (sys.argv[1:] or ["FLS_LOAM_DUAL=1", "FLS_LOAM_DUAL=0"]):
-    for k in ("FLS_LOAM_DUAL", "FLS_GRID27"):
+    for k in ("FLS_LOAM_DUAL", "FLS_GRID27", "FLS_FUSED_TAIL"):
         os.environ.pop(k, None)
     os.environ.update(dict(kv.split("=", 1) for kv in arm.split()))
     m = reg.make_matcher("LoamFull_KdTree", y); m.AddCloudToLocalMap([cfg["map"], cfg["corner_map"]])
