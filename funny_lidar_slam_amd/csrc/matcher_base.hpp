@@ -97,6 +97,10 @@ struct fls_matcher {
         L = std::min(L, lanes.size());
         std::vector<fls_status> lane_rc(L, FLS_OK);
         std::vector<std::thread> th;
+        struct JoinAll {  // a joinable std::thread must never be destroyed: also when starting a later lane throws
+            std::vector<std::thread>& t;
+            ~JoinAll() { for (auto& x : t) if (x.joinable()) x.join(); }
+        } join_all{th};
         for (size_t l = 0; l < L; ++l) {
             fls_matcher* q = lanes[l].get();
             tune_lane(*q);
@@ -121,7 +125,7 @@ struct fls_matcher {
                 }
             });
         }
-        for (auto& t : th) t.join();
+        for (auto& t : th) t.join();  // (join_all is the exception path)
         for (const fls_status rc : lane_rc) if (rc < 0) return rc;
         return FLS_OK;
     }

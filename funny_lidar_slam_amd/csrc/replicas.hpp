@@ -8,11 +8,20 @@
 // torch.distributed (one process per GPU, bench.py --gpus N) remains the multi-process form of the same sharding.
 #pragma once
 #include "../../include/fls_reg.h"
+#include <algorithm>
+#include <chrono>
 #include <exception>
 #include <thread>
 #include <vector>
 
 struct fls_replicas {
+    // joins whatever was started, also when starting the next thread throws (std::system_error): a joinable std::thread must never be destroyed
+    struct Threads {
+        std::vector<std::thread> th;
+        template <class F> void start(F&& f) { th.emplace_back(std::forward<F>(f)); }
+        void join() { for (auto& t : th) if (t.joinable()) t.join(); }
+        ~Threads() { join(); }
+    };
     fls_handle owner = nullptr;
     std::vector<int> devices;
     std::vector<fls_handle> handles;  // handles[i] serves devices[i]; the owner itself serves the first entry that names its device
@@ -31,16 +40,16 @@ struct fls_replicas {
         std::vector<unsigned char> blob(need);
         if (fls_map_export(owner, blob.data(), blob.size()) != need) return FLS_ERR_STATE;
         std::vector<fls_status> rc(handles.size(), FLS_OK);
-        std::vector<std::thread> th;
+        Threads th;
         for (size_t i = 0; i < handles.size(); ++i) {
             if (!owned[i]) continue;
-            th.emplace_back([&, i] {
+            th.start([&, i] {
                 const auto t0 = std::chrono::steady_clock::now();
                 rc[i] = fls_map_import(handles[i], blob.data(), blob.size());
                 import_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             });
         }
-        for (auto& t : th) t.join();
+        th.join();
         for (fls_status r : rc)
             if (r < 0) return r;
         return FLS_OK;
@@ -56,17 +65,17 @@ struct fls_replicas {
                            fls_stats* stats, int32_t* status, int lanes) {
         const size_t world = handles.size();
         std::vector<fls_status> rc(world, FLS_OK);
-        std::vector<std::thread> th;
+        Threads th;
         for (size_t r = 0; r < world; ++r) {
             size_t b, e;
             block(n_jobs, world, r, b, e);
             if (b == e) continue;
-            th.emplace_back([&, r, b, e] {
+            th.start([&, r, b, e] {
                 rc[r] = fls_match_batch(handles[r], e - b, src0 + b, n0 + b, src1 ? src1 + b : nullptr, n1 ? n1 + b : nullptr, stride, T + 16 * b, stats ? stats + b : nullptr,
                                         status ? status + b : nullptr, lanes);
             });
         }
-        for (auto& t : th) t.join();
+        th.join();
         for (fls_status r : rc)
             if (r < 0) return r;
         return FLS_OK;
