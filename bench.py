@@ -570,14 +570,18 @@ def main():
     # against 110 us at W = 100 / K = 200, kNN launch 18.6 vs 17.6 us).  A SLAM front-end registers scans continuously, so the
     # steady state is the number that means something: PRE_WARM_MATCHES untimed Matches (~30 ms) precede the W warm-up steps.
     # They count as calls of the handle in the call-k bookkeeping below.
-    for _ in range(PRE_WARM_MATCHES):
+    for _ in range(PRE_WARM_MATCHES - 2):
         step()
+    m.set_profiling(True)   # two of the untimed Matches run bracketed: the library creates its event ring on the first profiled Match,
+    step(); step()          # which must not be a timed one (two, not one: the parity of the call index is kept, Q15)
+    m.set_profiling(False)
+    m.kernel_time()
     for _ in range(args.warmup):
         step()
     # start / stop hipEvents are attached to every correspondence-kernel launch of every EVENT_EVERY-th step of the
     # timed region (hipExtLaunchKernelGGL: the kernel's own execution time); they are settled after the region.  A bracketed step
     # costs ~36 us more than a plain one (measured, tools/loop_overhead.py: 125 us / step without events, 134 with every 4th, 128 with
-    # every 16th), so the sampling is kept sparse: every 32nd step = 1 step / 3 launches at K = 20, 2 steps / 6 launches at K = 50
+    # every 16th), so the sampling is kept sparse: steps 16, 48, ... = 1 step / 3 launches at K = 20, 2 steps / 6 launches at K = 50
     # (launch durations repeat to +-1 us).
     EVENT_EVERY = 32
     m.kernel_time()  # reset the accumulators
@@ -585,8 +589,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    # (mid-period steps, not step 0: the first Match after the barrier + synchronize starts on an idle GPU and its launches read 2-3 us
+    # longer than the steady state the other 19 steps run in -- 17.4-18.6 us against 15.6-16.0 us over 60 launches, tools/gpu_ab.py)
+    bracketed = {k for k in range(args.steps) if k % EVENT_EVERY == EVENT_EVERY // 2} or {args.steps // 2}
     for k in range(args.steps):
-        if k % EVENT_EVERY == 0:
+        if k in bracketed:
             m.set_profiling(True)
             ok, T = step()
             m.set_profiling(False)
