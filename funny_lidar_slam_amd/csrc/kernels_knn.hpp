@@ -470,6 +470,9 @@ __device__ __forceinline__ void lu_tail(GnState* __restrict__ st, LuTailSmem& sm
 // Per point the seven contributions are now added by the wave reduction tree instead of sequentially (last-bit differences in H, g;
 // counts and flags are integers).
 constexpr int kNdtLanesBlock = 512;
+// FUSED = the Gauss-Newton tail in the last workgroup (FLS_FUSED_TAIL=1; measured slower for NDT, off by default).  A template
+// parameter, not a run-time branch: carrying the tail's code and LDS in the default kernel cost it 1.5 us per launch (13.3 vs 14.9 us).
+template <bool FUSED>
 __global__ void __launch_bounds__(kNdtLanesBlock)
 ndt_lanes_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
                  GnState* __restrict__ st, const int first, const Pose16 T0, const NdtGridDev ng, const double outlier_thr,
@@ -479,7 +482,7 @@ ndt_lanes_kernel(const float* __restrict__ sx, const float* __restrict__ sy, con
     double P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) P[k] = first ? T0.m[k] : st->T[k];
-    const int it = first ? 0 : st->iter;
+    const int it = (FUSED && !first) ? st->iter : 0;
     if (done) return;
     __shared__ double wsum[kNdtLanesBlock / 64][32];
     const int i = (blockIdx.x * kNdtLanesBlock + threadIdx.x) >> 3, k = threadIdx.x & 7;
@@ -564,14 +567,15 @@ ndt_lanes_kernel(const float* __restrict__ sx, const float* __restrict__ sy, con
     if (threadIdx.x < 29) {
 #pragma unroll
         for (int w = 0; w < kNdtLanesBlock / 64; ++w) v += wsum[w][threadIdx.x];
-        if (!ticket) partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
+        if (!FUSED) partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
     }
-    if (!ticket) return;
-    // fused Gauss-Newton tail (round 3): the row goes out write-through, the last workgroup to arrive solves and publishes
-    __shared__ unsigned s_ticket;
-    __shared__ LuTailSmem sm;
-    if (!publish_row_and_arrive(v, threadIdx.x < 29, partials, ticket, shards, s_ticket)) return;
-    lu_tail<kNdtLanesBlock, true>(st, sm, partials, (int)gridDim.x, tail, P, it);
+    if constexpr (FUSED) {
+        // fused Gauss-Newton tail (round 3): the row goes out write-through, the last workgroup to arrive solves and publishes
+        __shared__ unsigned s_ticket;
+        __shared__ LuTailSmem sm;
+        if (!publish_row_and_arrive(v, threadIdx.x < 29, partials, ticket, shards, s_ticket)) return;
+        lu_tail<kNdtLanesBlock, true>(st, sm, partials, (int)gridDim.x, tail, P, it);
+    }
 }
 
 __global__ void __launch_bounds__(1024)

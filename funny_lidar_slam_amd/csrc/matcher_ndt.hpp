@@ -632,8 +632,12 @@ struct NdtMatcher final : fls_matcher {
             if (profiling) FLS_HIP(hipEventRecord(ev[2 * it], stream));
             if (nblk > 0 && lanes_kernel && !count_traffic) {  // one lane per neighbour voxel (64 points per workgroup: same row count)
                 const LuTailArgs tail{1, p.rotation_converge_thres, p.position_converge_thres, p.ndt_min_effective_pts, mb_dev, launch_word()};
-                hipLaunchKernelGGL(ndt_lanes_kernel, dim3(nblk), dim3(kNdtLanesBlock), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, first,
-                                   T0, ng, p.ndt_res_outlier_threshold, d_hit_vid.p, d_eff7.p, d_partials_b.p, fused_tail ? d_ticket.p : (unsigned*)nullptr, 8, tail);
+                if (fused_tail)
+                    hipLaunchKernelGGL(ndt_lanes_kernel<true>, dim3(nblk), dim3(kNdtLanesBlock), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, first,
+                                       T0, ng, p.ndt_res_outlier_threshold, d_hit_vid.p, d_eff7.p, d_partials_b.p, d_ticket.p, 8, tail);
+                else
+                    hipLaunchKernelGGL(ndt_lanes_kernel<false>, dim3(nblk), dim3(kNdtLanesBlock), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n), d_state.p, first,
+                                       T0, ng, p.ndt_res_outlier_threshold, d_hit_vid.p, d_eff7.p, d_partials_b.p, (unsigned*)nullptr, 8, tail);
                 if (fused_tail) {  // the last workgroup ran the Gauss-Newton tail: one launch per iteration
                     if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
                     return;
