@@ -768,10 +768,11 @@ struct FeatureFitArgs {
     unsigned char* flag;
     double* partials;
 };
+template <bool FUSED>
 __global__ void __launch_bounds__(256)
 feature_fit_dual_kernel(const GnState* __restrict__ st, const int first, const Pose16 T0, const FeatureFitArgs line, const FeatureFitArgs plane, const int nb_line,
-                        const LoamFusedTail tail /* ticket == nullptr: gn_solve_loam_kernel follows */) {
-    const LoamFusedTail* const ft = tail.ticket ? &tail : nullptr;
+                        const LoamFusedTail tail /* FUSED = false: gn_solve_loam_kernel follows */) {
+    const LoamFusedTail* const ft = FUSED ? &tail : nullptr;
     if ((int)blockIdx.x < nb_line)
         feature_fit_body<true>((int)blockIdx.x, line.sx, line.sy, line.sz, line.n, st, first, T0, line.nn_pts, line.nn_cnt, line.kth_d2, line.gate, line.thres,
                                line.nn_id, line.cnt_out, line.Jst, line.flag, line.partials, ft);

@@ -338,8 +338,12 @@ struct LoamFullMatcher final : fls_matcher {
                 const bool fuse = loam_fused_tail;
                 const LoamFusedTail tail{(const double*)d_partials_a.p, (const double*)d_partials_b.p, nbc, nbp, p.rotation_converge_thres, p.position_converge_thres,
                                          fuse ? d_loam_ticket.p : nullptr, 8, mb_dev, launch_word()};
-                hipLaunchKernelGGL(feature_fit_dual_kernel, dim3(unsigned(nbc + nbp)), dim3(256), 0, stream, (const GnState*)d_state.p, first, T0,
-                                   corner.fit_args(gate_f, p.line_ratio_thres, d_partials_a.p), planar.fit_args(gate_f, p.point_to_planar_thres, d_partials_b.p), nbc, tail);
+                if (fuse)
+                    hipLaunchKernelGGL(feature_fit_dual_kernel<true>, dim3(unsigned(nbc + nbp)), dim3(256), 0, stream, (const GnState*)d_state.p, first, T0,
+                                       corner.fit_args(gate_f, p.line_ratio_thres, d_partials_a.p), planar.fit_args(gate_f, p.point_to_planar_thres, d_partials_b.p), nbc, tail);
+                else
+                    hipLaunchKernelGGL(feature_fit_dual_kernel<false>, dim3(unsigned(nbc + nbp)), dim3(256), 0, stream, (const GnState*)d_state.p, first, T0,
+                                       corner.fit_args(gate_f, p.line_ratio_thres, d_partials_a.p), planar.fit_args(gate_f, p.point_to_planar_thres, d_partials_b.p), nbc, tail);
                 if (fuse) {
                     if (profiling) FLS_HIP(hipEventRecord(ev[2 * it + 1], stream));
                     return;
