@@ -64,7 +64,9 @@ struct GridKnnLane {
     int found, q;
     float kth;
 };
-template <int K, bool FLOAT_XFORM, bool EMIT = true>
+// UNGATED: the caller searches without a gate (LoamPointToPlaneKdtree): only that instantiation carries the ring walk and the serial
+// fallback below (as a run-time test on `gate` they sat in every instantiation's register budget)
+template <int K, bool FLOAT_XFORM, bool EMIT = true, bool UNGATED = false>
 __device__ __forceinline__ void
 grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
               const GnState* __restrict__ st, const int first, const Pose16& T0, const CellGridDev& cg, const float gate,
@@ -286,7 +288,8 @@ grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restri
     // distance known so far, and after every ring the merged K-th distance is tested against the ring's radius.  Only a query
     // that is still uncertain after kMaxRing rings (far outside the map) falls back to lane 0's exact brute-force search.
     const double rad2 = cg.cell * cg.cell * (1.0 - 1e-5);
-    bool certain = (gate < INFINITY) || (found == K && (double)kth <= rad2);
+    bool certain = !UNGATED || (found == K && (double)kth <= rad2);
+    if constexpr (UNGATED) {
     if (!certain) {  // uniform within the group
         for (int rho = 2; rho <= kMaxRing && !certain; ++rho) {
             const float bnd = found == K ? kth : INFINITY;
@@ -330,6 +333,7 @@ grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restri
         }
         return;
     }
+    }  // UNGATED
     if (!EMIT) {
         lane_out->key = mine_key; lane_out->slot = mine_slot; lane_out->found = found; lane_out->kth = kth; lane_out->q = active ? q : -1;
         return;
@@ -339,13 +343,13 @@ grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restri
     if (sub == 0 && active) { nn_cnt[q] = (unsigned char)found; kth_d2[q] = kth; }
 }
 
-template <int K, bool FLOAT_XFORM>
+template <int K, bool FLOAT_XFORM, bool UNGATED = false>
 __global__ void __launch_bounds__(256)
 grid_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
                 const GnState* __restrict__ st, const int first, const Pose16 T0, const CellGridDev cg, const float gate,
                 float4* __restrict__ nn_pts /* [n][K] */, unsigned char* __restrict__ nn_cnt, float* __restrict__ kth_d2,
                 unsigned char* __restrict__ flag_to_clear /* may be null */) {
-    grid_knn_body<K, FLOAT_XFORM>((int)blockIdx.x, sx, sy, sz, n, st, first, T0, cg, gate, nn_pts, nn_cnt, kth_d2, flag_to_clear);
+    grid_knn_body<K, FLOAT_XFORM, true, UNGATED>((int)blockIdx.x, sx, sy, sz, n, st, first, T0, cg, gate, nn_pts, nn_cnt, kth_d2, flag_to_clear);
 }
 
 // two independent queries in one launch: blocks [0, nb_a) serve A, the rest B (both block counts are multiples of 64, so the
@@ -361,8 +365,9 @@ struct GridKnnArgs {
     float* kth_d2;
     unsigned char* flag_to_clear;
 };
+// six waves per SIMD (80 VGPRs, no scratch; the natural allocation is 84 = five waves): LoamFull Match 255 -> 249 us.  (Eight waves spill: round 1.)
 template <int K, bool FLOAT_XFORM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))
 grid_knn_dual_kernel(const GnState* __restrict__ st, const int first, const Pose16 T0, const GridKnnArgs a, const GridKnnArgs b, const int nb_a) {
     if ((int)blockIdx.x < nb_a)
         grid_knn_body<K, FLOAT_XFORM>((int)blockIdx.x, a.sx, a.sy, a.sz, a.n, st, first, T0, a.cg, a.gate, a.nn_pts, a.nn_cnt, a.kth_d2, a.flag_to_clear);

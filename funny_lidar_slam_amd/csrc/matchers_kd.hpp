@@ -234,8 +234,12 @@ struct FeatureDev {
                                kth.p, flag.p);
         } else {
             const dim3 knn_grid_dim(unsigned((((n * 8 + 255) / 256) + 63) / 64 * 64));  // multiple of 64: the XCD chunk re-map is a bijection
-            hipLaunchKernelGGL((grid_knn_kernel<5, false>), knn_grid_dim, dim3(256), 0, s, scan.x.p, scan.y.p, scan.z.p, int(n), st, first, T0, cg, gate,
-                               nn_pts.p, nn_cnt.p, kth.p, flag.p);
+            if (std::isinf(gate))  // un-gated search (LoamPointToPlaneKdtree): the instantiation with the ring walk
+                hipLaunchKernelGGL((grid_knn_kernel<5, false, true>), knn_grid_dim, dim3(256), 0, s, scan.x.p, scan.y.p, scan.z.p, int(n), st, first, T0, cg, gate,
+                                   nn_pts.p, nn_cnt.p, kth.p, flag.p);
+            else
+                hipLaunchKernelGGL((grid_knn_kernel<5, false>), knn_grid_dim, dim3(256), 0, s, scan.x.p, scan.y.p, scan.z.p, int(n), st, first, T0, cg, gate,
+                                   nn_pts.p, nn_cnt.p, kth.p, flag.p);
         }
         hipLaunchKernelGGL((feature_fit_kernel<LINE>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, scan.x.p, scan.y.p, scan.z.p, int(n), st,
                            first, T0, (const float4*)nn_pts.p, (const unsigned char*)nn_cnt.p, (const float*)kth.p, gate, thres, nn_id.p,
