@@ -439,15 +439,15 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
 // The ticket counters (kTicketWords unsigned words) are reset by their last arrivers, so they are zero at every launch.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFitThreads = 512;
-template <bool FIRST>
-__global__ void __launch_bounds__(kFitThreads)
+template <bool FIRST, int NT = kFitThreads>
+__global__ void __launch_bounds__(NT)
 p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
                          GnState* __restrict__ st, const Pose16 T0, const float4* __restrict__ nn_pts,
                          const unsigned char* __restrict__ nn_cnt, double* __restrict__ Jst /* [7][n] */, unsigned char* __restrict__ flag,
                          double* __restrict__ partials, unsigned* __restrict__ ticket, Mailbox* __restrict__ mb, const unsigned match_id,
                          const double plane_thres, const double rot_thr, const double pos_thr, const int shards,
                          const unsigned* __restrict__ nn_ids /* may be null */, const float4* __restrict__ map_pts, const unsigned n_slots) {
-    const int i = blockIdx.x * kFitThreads + threadIdx.x;
+    const int i = blockIdx.x * NT + threadIdx.x;
     const int done = FIRST ? 0 : st->done;
     double T44[16];
 #pragma unroll
@@ -478,7 +478,7 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
     const unsigned char stale = FIRST ? (unsigned char)0 : flag[ii];  // the first kNN launch of a Match cleared the flags
     if (done) return;
     __shared__ LoamTailSmem sm;
-    __shared__ double wsum[kFitThreads / 64][32];
+    __shared__ double wsum[NT / 64][32];
     __shared__ unsigned s_ticket;
 #ifdef FLS_TIMING
     const long long t_begin = (long long)__builtin_readcyclecounter();
@@ -519,7 +519,7 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
     if (threadIdx.x < 29) {
         double v = 0.0;
 #pragma unroll
-        for (int w = 0; w < kFitThreads / 64; ++w) v += wsum[w][threadIdx.x];
+        for (int w = 0; w < NT / 64; ++w) v += wsum[w][threadIdx.x];
         // write-through (sc1) publish: visible to every XCD once this wave's stores have drained -- no L2 write-back
         __hip_atomic_store((unsigned long long*)partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x,
                            (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -535,7 +535,7 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
     if (threadIdx.x == 0) { st->dbg[0] = t_begin; st->dbg[13] = t_fit; st->dbg[14] = t_red; }
 #endif
     FLS_STAMP(1);
-    loam_tail<kFitThreads, true>(st, sm, nullptr, 0, partials, (int)gridDim.x, rot_thr, pos_thr, T44, last_rot, last_pos, it, mb, match_id);
+    loam_tail<NT, true>(st, sm, nullptr, 0, partials, (int)gridDim.x, rot_thr, pos_thr, T44, last_rot, last_pos, it, mb, match_id);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -581,22 +581,48 @@ ivox_nn_materialize_kernel(const unsigned* __restrict__ nn_ids, unsigned char* _
     nn_cnt[i] = (unsigned char)(cb | 0x80);
 }
 
+// MATERIALIZE (round 3): the launch also turns the ids-form lists into rows (what ivox_nn_materialize_kernel does) -- the map update that
+// follows moves slots, and this kernel gathers the same five points anyway: one launch and one gather less per mapping-mode scan.
+// The grid then covers max(n, nn_n) points (lists beyond the points that are decided on still become rows).
+template <bool MATERIALIZE>
 __global__ void __launch_bounds__(256)
 ivox_add_decide_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
-                       const Pose16 Tw, const float4* __restrict__ nn_pts, const unsigned char* __restrict__ nn_cnt, const int nn_n,
+                       const Pose16 Tw, float4* __restrict__ nn_pts, unsigned char* __restrict__ nn_cnt, const int nn_n,
                        const double fs /* filter_size_map_min */, unsigned char* __restrict__ code, float4* __restrict__ pw_out,
                        const unsigned* __restrict__ nn_ids /* may be null */, const float4* __restrict__ map_pts, const unsigned n_slots) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n && (!MATERIALIZE || i >= nn_n)) return;
+    const int cb = i < nn_n ? nn_cnt[i] : 0;
+    const int cnt = cb & 7;
+    const bool ids_form = nn_ids != nullptr && !(cb & 0x80);
+    float4 nb[5];
+    if (MATERIALIZE) {
+        // all five rows now (whatever the decision below needs), written back in rows form
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if (ids_form) {
+                const unsigned sl = nn_ids[(size_t)i * 8 + k];
+                nb[k] = (cnt && sl < n_slots) ? map_pts[sl] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            } else {
+                nb[k] = (i < nn_n && cnt) ? nn_pts[(size_t)i * 5 + k] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            }
+        }
+        if (i < nn_n && ids_form) {
+            if (cnt) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) nn_pts[(size_t)i * 5 + k] = nb[k];
+            }
+            nn_cnt[i] = (unsigned char)(cb | 0x80);
+        }
+        if (i >= n) return;
+    }
     const double x = sx[i], y = sy[i], z = sz[i];
     const float wx = (float)(((Tw.m[0] * x + Tw.m[4] * y) + Tw.m[8] * z) + Tw.m[12]);
     const float wy = (float)(((Tw.m[1] * x + Tw.m[5] * y) + Tw.m[9] * z) + Tw.m[13]);
     const float wz = (float)(((Tw.m[2] * x + Tw.m[6] * y) + Tw.m[10] * z) + Tw.m[14]);
     pw_out[i] = make_float4(wx, wy, wz, 0.f);
-    const int cb = i < nn_n ? nn_cnt[i] : 0;
-    const int cnt = cb & 7;
-    const bool ids_form = nn_ids != nullptr && !(cb & 0x80);
     auto neighbour = [&](const int k) -> float4 {
+        if (MATERIALIZE) return nb[k];
         if (!ids_form) return nn_pts[(size_t)i * 5 + k];
         const unsigned sl = nn_ids[(size_t)i * 8 + k];
         return map_pts[sl < n_slots ? sl : 0u];
@@ -614,7 +640,9 @@ ivox_add_decide_kernel(const float* __restrict__ sx, const float* __restrict__ s
             const double dist = (e0 * e0 + e1 * e1) + e2 * e2;
             bool need_add = true;
             if (cnt >= 5) {
-                for (int k = 0; k < 5 && need_add; ++k) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    if (!need_add) break;
                     const float4 q = neighbour(k);
                     const double f0 = (double)q.x - c0, f1 = (double)q.y - c1, f2 = (double)q.z - c2;
                     if ((f0 * f0 + f1 * f1) + f2 * f2 < dist + 1.0e-6) need_add = false;

@@ -198,7 +198,8 @@ ivox_upd_plan(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState* _
 }
 
 __global__ void __launch_bounds__(kUpdMaxBlocks)
-ivox_upd_scan2(const IvoxUpdBatch b, IvoxUpdState* __restrict__ st) {
+ivox_upd_scan2(const IvoxUpdBatch b, IvoxUpdState* __restrict__ st, const unsigned evict_ready /* the host queued the eviction selection */,
+               const unsigned n_list /* entries of the stamp-sorted list of alive cells */) {
     __shared__ unsigned wsum[kUpdMaxBlocks / 64][4];
     const unsigned A = st->n1 + st->n2;
     const int nblocks = (int)((A + kUpdBlock - 1) / kUpdBlock);
@@ -218,12 +219,15 @@ ivox_upd_scan2(const IvoxUpdBatch b, IvoxUpdState* __restrict__ st) {
         unsigned e = 0u;
         if (total >= (unsigned long long)st->lru_capacity) {
             e = (unsigned)(total - (unsigned long long)st->lru_capacity + 1ull);
-            if (!st->evict_ready || e > st->n_list) status |= kUpdNeedHost;
+            if (!evict_ready || e > n_list) status |= kUpdNeedHost;
         }
+        st->evict_ready = evict_ready;  // (round 3: a one-thread launch of their own used to set these two words)
+        st->n_list = n_list;
         st->evict = e;
         st->evicted_points = 0ull;
         st->evicted_slots = 0ull;
         st->status = status;
+        if (!evict_ready) st->apply = status == kUpdOk ? 1u : 0u;  // no eviction selection follows: this is the verdict (ivox_upd_decide otherwise)
     }
 }
 
@@ -317,7 +321,6 @@ ivox_evict_select(const unsigned* __restrict__ order, const IvoxUpdArrays a, Ivo
     }
     if (threadIdx.x == 0 && s_found < E) atomicOr(&st->status, kUpdNeedHost);
 }
-__global__ void ivox_upd_set_evict(IvoxUpdState* __restrict__ st, const unsigned ready, const unsigned n_list) { st->evict_ready = ready; st->n_list = n_list; }
 __global__ void ivox_upd_decide(IvoxUpdState* __restrict__ st) {
     if (threadIdx.x == 0 && blockIdx.x == 0) st->apply = st->status == kUpdOk ? 1u : 0u;
 }

@@ -58,6 +58,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     bool balanced = true;  // equal candidate ranges per lane through an LDS voxel table (FLS_IVOX_BALANCED=0: whole voxels per lane)
     int variant = 4;       // lanes cooperating on one query in ivox_knn_kernel: 4 or 8 (FLS_IVOX_VARIANT)
     int ticket_shards = 8; // fan-in of the fit kernel's workgroups: 8 per-XCD counters + a top counter (FLS_TICKET_SHARDS=1: one counter)
+    int fit_threads_env = 0;    // FLS_FIT_THREADS = 512 | 256 (A/B): workgroup size of the fit kernel; 0 = by scan size
     bool plain_launch = false;  // FLS_PLAIN_LAUNCH=1 (A/B): hipLaunchKernelGGL instead of hipExtLaunchKernelGGL with null events
     bool prof_fit = false; // FLS_PROF_FIT=1 (diagnosis): the profiling events bracket the fit+solve kernel instead of the kNN kernel
     bool is_first = true;  // the reference's function-static flag (:62), per handle here
@@ -94,6 +95,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (const char* e = std::getenv("FLS_IVOX_DENSE")) use_dense = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_PROF_FIT")) prof_fit = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_PLAIN_LAUNCH")) plain_launch = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_FIT_THREADS")) { const int v = std::atoi(e); fit_threads_env = (v == 256 || v == 512) ? v : 0; }
         if (const char* e = std::getenv("FLS_IVOX_NN_IDS")) nn_ids_mode = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_BALANCED")) balanced = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_HOST_TIMING")) host_timing = std::atoi(e) != 0;
@@ -235,15 +237,14 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
                                (const unsigned*)ev_sort.v0, n_list, ev_sort.k0);
             ev_sort.run(DevicePairSort::passes_for((unsigned long long)((stamp_bound + n) >> 32) + 1ull), stream);
         }
-        hipLaunchKernelGGL(ivox_upd_set_evict, dim3(1), dim3(1), 0, stream, d_upd_state.p, may_evict ? 1u : 0u, n_list);
-        hipLaunchKernelGGL(ivox_upd_scan2, dim3(1), dim3(kUpdMaxBlocks), 0, stream, b, d_upd_state.p);
+        hipLaunchKernelGGL(ivox_upd_scan2, dim3(1), dim3(kUpdMaxBlocks), 0, stream, b, d_upd_state.p, may_evict ? 1u : 0u, n_list);  // (also decides when no eviction selection follows)
         if (may_evict) {
             d_crank.reserve(n);
             d_evict_list.reserve(n);
             hipLaunchKernelGGL(ivox_upd_cranks, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p, d_crank.p);
             hipLaunchKernelGGL(ivox_evict_select, dim3(1), dim3(kEvBlock), 0, stream, (const unsigned*)ev_sort.v0, a, d_upd_state.p, (const unsigned*)d_crank.p, d_evict_list.p);
         }
-        hipLaunchKernelGGL(ivox_upd_decide, dim3(1), dim3(64), 0, stream, d_upd_state.p);
+        if (may_evict) hipLaunchKernelGGL(ivox_upd_decide, dim3(1), dim3(64), 0, stream, d_upd_state.p);  // (the selection may still refuse the batch)
         if (may_evict) hipLaunchKernelGGL(ivox_evict_apply, g, t, 0, stream, (const unsigned*)d_evict_list.p, a, d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_last, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_regions, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
@@ -335,11 +336,20 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
                 h_pw.resize(n);
                 Pose16 Tw;
                 std::memcpy(Tw.m, T_, sizeof(Tw.m));
-                hipLaunchKernelGGL(ivox_add_decide_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p,
-                                   int(n), Tw, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, int(nn_n), filter_size_map_min,
-                                   d_code.p, d_pw.p, (const unsigned*)(nn_ids_mode ? d_nn_ids.p : nullptr), (const float4*)image.d_pts.p, unsigned(image.d_pts.cap));
+                // (the update below moves map slots: lists still in ids form become rows in the same launch)
+                if (nn_ids_mode && !nn_rows_current && nn_n > 0) {
+                    const size_t m = std::max(n, nn_n);
+                    hipLaunchKernelGGL(ivox_add_decide_kernel<true>, dim3(unsigned((m + 255) / 256)), dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p,
+                                       int(n), Tw, d_nn.p, d_nn_cnt.p, int(nn_n), filter_size_map_min,
+                                       d_code.p, d_pw.p, (const unsigned*)d_nn_ids.p, (const float4*)image.d_pts.p, unsigned(image.d_pts.cap));
+                    nn_rows_current = true;
+                } else {
+                    hipLaunchKernelGGL(ivox_add_decide_kernel<false>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p,
+                                       int(n), Tw, d_nn.p, d_nn_cnt.p, int(nn_n), filter_size_map_min,
+                                       d_code.p, d_pw.p, (const unsigned*)(nn_ids_mode ? d_nn_ids.p : nullptr), (const float4*)image.d_pts.p, unsigned(image.d_pts.cap));
+                }
                 FLS_HIP(hipGetLastError());
-                ensure_nn_rows();  // the update below moves map slots: the lists become rows first
+                ensure_nn_rows();
                 if (device_map) {
                     if (device_add_points(n)) {
                         if (host_timing)
@@ -486,7 +496,11 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         nn_n = n;
         d_J.reserve(7 * n);
         d_flag.reserve(n);  // cleared by the first iteration's kNN kernel (std::fill(flags, false) once per Match, :156, Q1)
-        const int nwg = int((n + kFitThreads - 1) / kFitThreads);
+        // workgroup size of the fit kernel: 512 threads (two waves per SIMD of a CU) when the scan fills the machine anyway; 256 (one wave per
+        // SIMD) up to 65,536 points, where 256 workgroups spread the same waves over every CU -- the 9.8k-point planar cloud the pipeline feeds
+        // ran its 2,500-instruction fit phase two waves deep on 20 CUs with 236 CUs idle
+        const int fit_threads = (fit_threads_env > 0) ? fit_threads_env : (n <= 65536 ? 256 : kFitThreads);
+        const int nwg = int((n + size_t(fit_threads) - 1) / size_t(fit_threads));
         d_partials_b.reserve(size_t(nwg) * kPartialStride);
         const int iters = int(p.max_iterations);
         const DevGrid g = im.dev();
@@ -498,20 +512,22 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             hipEvent_t f0 = nullptr, f1 = nullptr;
             if (prof_fit) { f0 = e0; f1 = e1; e0 = e1 = nullptr; }
             if (variant == 4) launch_knn<4>(n, first, T0, g, win, e0, e1); else launch_knn<8>(n, first, T0, g, win, e0, e1);
-#define FLS_FIT(F)                                                                                                                   \
+#define FLS_FIT_NT(F, NT)                                                                                                            \
     do {                                                                                                                             \
         if (f0 || !plain_launch)                                                                                                     \
-            hipExtLaunchKernelGGL(p2plane_fit_solve_kernel<F>, dim3(nwg), dim3(kFitThreads), 0, stream, f0, f1, 0, scan.x.p, scan.y.p, scan.z.p, int(n),  \
+            hipExtLaunchKernelGGL((p2plane_fit_solve_kernel<F, NT>), dim3(nwg), dim3(NT), 0, stream, f0, f1, 0, scan.x.p, scan.y.p, scan.z.p, int(n),  \
                        d_state.p, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,     \
                        d_ticket.p, mb_dev, launch_word(), p.point_to_planar_thres, p.rotation_converge_thres, p.position_converge_thres, ticket_shards,  \
                        (const unsigned*)(nn_ids_mode ? d_nn_ids.p : nullptr), (const float4*)g.pts, unsigned(im.d_pts.cap));  \
         else                                                                                                                         \
-            hipLaunchKernelGGL(p2plane_fit_solve_kernel<F>, dim3(nwg), dim3(kFitThreads), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),  \
+            hipLaunchKernelGGL((p2plane_fit_solve_kernel<F, NT>), dim3(nwg), dim3(NT), 0, stream, scan.x.p, scan.y.p, scan.z.p, int(n),  \
                        d_state.p, T0, (const float4*)d_nn.p, (const unsigned char*)d_nn_cnt.p, d_J.p, d_flag.p, d_partials_b.p,     \
                        d_ticket.p, mb_dev, launch_word(), p.point_to_planar_thres, p.rotation_converge_thres, p.position_converge_thres, ticket_shards,  \
                        (const unsigned*)(nn_ids_mode ? d_nn_ids.p : nullptr), (const float4*)g.pts, unsigned(im.d_pts.cap));  \
     } while (0)
+#define FLS_FIT(F) do { if (fit_threads == 256) FLS_FIT_NT(F, 256); else FLS_FIT_NT(F, kFitThreads); } while (0)
             if (first) FLS_FIT(true); else FLS_FIT(false);
+#undef FLS_FIT_NT
 #undef FLS_FIT
         });
         if (nn_ids_mode) nn_rows_current = false;  // the lists of every point with candidates are slots of the current image now
