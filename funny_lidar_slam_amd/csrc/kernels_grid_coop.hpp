@@ -728,7 +728,12 @@ feature_fit_body(const int bid, const float* __restrict__ sx, const float* __res
             contrib = true;
         }
     }
+#if FLS_FIT_MFMA
+    __shared__ __attribute__((aligned(64))) double mfma_tile[4][512];  // (kernels_p2plane.hpp::reduce_rank1_mfma_and_store)
+    reduce_rank1_mfma_and_store(contrib, J, res, &wsum[threadIdx.x >> 6][0], &mfma_tile[threadIdx.x >> 6][0]);
+#else
     reduce_rank1_and_store(contrib, J, res, &wsum[threadIdx.x >> 6][0]);
+#endif
     if (!ft) { block_row_from_wave_sums(wsum, partials, bid); return; }
     // fused Gauss-Newton tail (round 3, LOAM dual launch): the row goes out write-through, the last workgroup of the WHOLE launch (both
     // feature classes) sums the corner rows, then the planar rows (SumCoefficient's order) and runs the LOAM-family tail

@@ -511,7 +511,12 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
     const long long t_fit = (long long)__builtin_readcyclecounter();
 #endif
     // wave sums -> LDS -> one row per workgroup (fixed order: wave 0 + wave 1 + ...)
+#if FLS_FIT_MFMA
+    __shared__ __attribute__((aligned(64))) double mfma_tile[NT / 64][512];
+    reduce_rank1_mfma_and_store(contrib, J, res, &wsum[threadIdx.x >> 6][0], &mfma_tile[threadIdx.x >> 6][0]);
+#else
     reduce_rank1_and_store(contrib, J, res, &wsum[threadIdx.x >> 6][0]);
+#endif
 #ifdef FLS_TIMING
     const long long t_red = (long long)__builtin_readcyclecounter();
 #endif

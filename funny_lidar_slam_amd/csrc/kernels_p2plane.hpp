@@ -87,6 +87,62 @@ __device__ __forceinline__ void reduce_rank1_and_store(const bool contrib, const
     if (lane == 63) { partial_row[27] = sr; partial_row[28] = sc; }
 }
 
+// The same 29 sums through the FP64 matrix cores (round 3).  With v_p = (J0 .. J5, r, 1) per contributing point (zeros otherwise) the
+// wave's contribution is the 8 x 8 matrix sum_p v_p v_p^T: H = its leading 6 x 6 block, g_a = -(a, 6), sum r = (6, 7), count = (7, 7).
+// v_mfma_f64_16x16x4_f64 multiplies a 16 x 4 by a 4 x 16 operand per issue: columns 0..7 carry four points, columns 8..15 four more,
+// so the two diagonal 8 x 8 blocks of the 16 x 16 accumulator are two partial sums (the off-diagonal blocks are cross terms nobody
+// reads) and eight issues cover the wave's 64 points.  The points reach the operand layout (lane l supplies component l & 7 of point
+// 8 s + 4 ((l >> 3) & 1) + (l >> 4) in step s) through one 4 KB LDS tile per wave: four 16-byte writes and eight 8-byte reads per lane,
+// both contiguous.  Against the DPP tree (29 sums x 6 steps x {2 moves + 1 add} = 522 VALU instructions per wave, a fifth of the fit
+// phase) this is ~40 instructions plus eight MFMA issues that overlap the other wave's VALU work.  Deterministic (fixed issue order);
+// the products are fused into the accumulation (no intermediate rounding), so H and g differ from the DPP tree's in the last bits
+// like any other summation order -- integers (the count) are exact.
+#ifndef FLS_FIT_MFMA
+#define FLS_FIT_MFMA 1  // 0: the DPP tree (A/B builds)
+#endif
+typedef double fls_double4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void reduce_rank1_mfma_and_store(const bool contrib, const double (&J)[6], const double r, double* __restrict__ partial_row,
+                                                            double* __restrict__ tile /* LDS, 512 doubles of this wave, 64-byte aligned */) {
+    const int lane = threadIdx.x & 63;
+    const double z = 0.0;
+    double v[8];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) v[a] = contrib ? J[a] : z;
+    v[6] = contrib ? r : z;
+    v[7] = contrib ? 1.0 : z;
+    double2* const dst = reinterpret_cast<double2*>(tile + ((lane >> 3) * 64 + (lane & 3) * 16 + ((lane >> 2) & 1) * 8));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = make_double2(v[2 * q], v[2 * q + 1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    fls_double4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const double x = tile[s * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+    }
+    // accumulator: element reg of lane l = D[(l >> 4) + 4 reg][l & 15]; top-left block in lanes with (l & 15) < 8 (regs 0, 1), bottom-right
+    // block eight lanes further (regs 2, 3)
+    const double h0 = acc[0] + __shfl_down(acc[2], 8, 64);  // row (l >> 4)
+    const double h1 = acc[1] + __shfl_down(acc[3], 8, 64);  // row (l >> 4) + 4
+    const int j = lane & 15, i0 = lane >> 4;
+    if (j < 8) {
+        // row i0 (0..3)
+        if (j < 6 && i0 <= j) partial_row[i0 * 6 - (i0 * (i0 - 1)) / 2 + (j - i0)] = h0;
+        if (j == 6) partial_row[21 + i0] = -h0;
+        const int i1 = i0 + 4;  // 4..7
+        if (i1 < 6) {
+            if (j < 6 && i1 <= j) partial_row[i1 * 6 - (i1 * (i1 - 1)) / 2 + (j - i1)] = h1;
+            if (j == 6) partial_row[21 + i1] = -h1;
+        } else if (i1 == 6) {
+            if (j == 7) partial_row[27] = h1;
+        } else if (j == 7) {
+            partial_row[28] = h1;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // fixed-order reduction of partial rows: rows [0,nrows) of `partials`, 32 columns, by a workgroup of
 // NT threads = NT/32 row-groups x 32 columns; every thread keeps 16 independent loads in flight per trip
