@@ -5,6 +5,7 @@
 // No HIP runtime call is made: only host members are touched.
 #include "../../funny_lidar_slam_amd/csrc/host_maps.hpp"
 #include "../../funny_lidar_slam_amd/csrc/host_math.hpp"
+#include "../../funny_lidar_slam_amd/csrc/replicas.hpp"
 #include "../../oracle/flo_api.h"
 #include <cstdio>
 #include <cstring>
@@ -242,6 +243,21 @@ int main() {
         CHECK(iv.add_points(&out, 1) == FLS_OK);
         CHECK(!img.collect_incremental(iv));
     }
+    // ---- the job partition of the native replica set (csrc/replicas.hpp) = funny_lidar_slam_amd/batch.py::partition: contiguous blocks,
+    // sizes differ by at most one, the first n % world ranks take the extra job, every job exactly once
+    for (size_t world = 1; world <= 9; ++world)
+        for (size_t n = 0; n <= 40; ++n) {
+            size_t next = 0;
+            for (size_t r = 0; r < world; ++r) {
+                size_t b = 0, e = 0;
+                fls_replicas::block(n, world, r, b, e);
+                CHECK(b == next && e >= b);
+                const size_t base = n / world, extra = n % world;
+                CHECK(e - b == base + (r < extra ? 1 : 0));
+                next = e;
+            }
+            CHECK(next == n);
+        }
     std::printf("host logic ok\n");
     return 0;
 }
