@@ -569,6 +569,25 @@ __device__ __forceinline__ void icp_point_terms(const double (&T)[16], const flo
     res = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
 }
 
+// the same correspondence as the three rows of its Jacobian + the residual vector (what the matrix-core reduction consumes)
+__device__ __forceinline__ void icp_point_rows(const double (&T)[16], const float px, const float py, const float pz, const float4 m, double (&J)[18],
+                                               double (&e)[3], double& res) {
+    const RtFloat rt = load_rt_float(T);
+    float qx, qy, qz;
+    xform_f(rt, px, py, pz, qx, qy, qz);
+    e[0] = (double)qx - (double)m.x; e[1] = (double)qy - (double)m.y; e[2] = (double)qz - (double)m.z;
+    const double o0 = px, o1 = py, o2 = pz;
+    const double hat[9] = {0.0, o2, -o1, -o2, 0.0, o0, o1, -o0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            J[r + j * 3] = (r == j) ? 1.0 : 0.0;
+            J[r + (j + 3) * 3] = -((T[r] * hat[0 + j * 3] + T[r + 4] * hat[1 + j * 3]) + T[r + 8] * hat[2 + j * 3]);
+        }
+    res = sqrt((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+}
+
 // IcpOptimized correspondence search AND fit in one launch: the 1-NN of a query ends up in lane 0 of its 8-lane group, which
 // forms the point's terms at once (no neighbour arrays through memory, one launch per iteration fewer); every workgroup of the
 // search grid writes one partial row (rows of idle workgroups are zero), gn_solve_lu_kernel sums them in row order.
@@ -587,12 +606,36 @@ icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
     double T[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) T[k] = first ? T0.m[k] : st->T[k];
+    const int lane = threadIdx.x & 63;
+    double* row = &wsum[threadIdx.x >> 6][0];
+    bool contrib = false;
+#if FLS_FIT_MFMA
+    // the point's three Jacobian rows go to the matrix cores (kernels_p2plane.hpp::reduce_rank1x3_mfma_and_store): no per-point 21 + 6 products,
+    // no 522-instruction DPP tree per wave
+    double Jr[18], er[3] = {0.0, 0.0, 0.0}, res = 0.0;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) Jr[k] = 0.0;
+    if ((threadIdx.x & 7) == 0 && r.q >= 0) {
+        int id = -1;
+        if (r.found >= 1 && r.key != ~0ull && !((double)r.kth > max_corr)) {
+            const float4 m = cg.g.pts[r.slot];
+            id = __float_as_int(m.w);
+            icp_point_rows(T, sx[r.q], sy[r.q], sz[r.q], m, Jr, er, res);
+            contrib = true;
+        }
+        nn_id[r.q] = id;  // ids are reported for accepted correspondences only
+        eff[r.q] = contrib ? 1 : 0;
+    }
+    __shared__ __attribute__((aligned(64))) double mfma_tile[4][512];
+    reduce_rank1x3_mfma_and_store(contrib, Jr, er, row, &mfma_tile[threadIdx.x >> 6][0]);
+    const double sr = wave_sum_dpp(res);
+    if (lane == 63) row[27] = sr;
+#else
     double Hc[21], Bc[6], res = 0.0;
 #pragma unroll
     for (int k = 0; k < 21; ++k) Hc[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) Bc[k] = 0.0;
-    bool contrib = false;
     if ((threadIdx.x & 7) == 0 && r.q >= 0) {
         int id = -1;
         if (r.found >= 1 && r.key != ~0ull && !((double)r.kth > max_corr)) {
@@ -604,14 +647,13 @@ icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
         nn_id[r.q] = id;  // ids are reported for accepted correspondences only
         eff[r.q] = contrib ? 1 : 0;
     }
-    const int lane = threadIdx.x & 63;
-    double* row = &wsum[threadIdx.x >> 6][0];
 #pragma unroll
     for (int k = 0; k < 21; ++k) { const double v = wave_sum_dpp(Hc[k]); if (lane == 63) row[k] = v; }
 #pragma unroll
     for (int k = 0; k < 6; ++k) { const double v = wave_sum_dpp(Bc[k]); if (lane == 63) row[21 + k] = v; }
     const double sr = wave_sum_dpp(res), sc = wave_sum_dpp(contrib ? 1.0 : 0.0);
     if (lane == 63) { row[27] = sr; row[28] = sc; }
+#endif
     if (!ticket) { block_row_from_wave_sums(wsum, partials); return; }
     // fused Gauss-Newton tail (round 3): the row goes out write-through, the last workgroup to arrive solves and publishes
     __syncthreads();

@@ -143,6 +143,54 @@ __device__ __forceinline__ void reduce_rank1_mfma_and_store(const bool contrib, 
     }
 }
 
+// The same for IcpOptimized, whose point contributes THREE rank-1 terms (the rows of its 3 x 6 Jacobian: H = J^T J, B = -J^T e): the lane
+// that holds a correspondence (lane 0 of an 8-lane search group) writes the vectors (J_r0 .. J_r5, e_r, [r == 0]) of its three rows into
+// three of its group's eight tile slots, the other slots are zero -- 24 vectors per wave, the same eight issues.  Row [27] (sum of |e|, not a
+// product of the vector's entries) stays a DPP sum; the caller stores it after this call.
+__device__ __forceinline__ void reduce_rank1x3_mfma_and_store(const bool contrib, const double (&J)[18] /* 3 x 6 column-major */, const double (&e)[3],
+                                                              double* __restrict__ partial_row, double* __restrict__ tile /* LDS, 512 doubles of this wave */) {
+    const int lane = threadIdx.x & 63, sub = lane & 7;
+    auto slot = [&](const int p) { return reinterpret_cast<double2*>(tile + ((p >> 3) * 64 + (p & 3) * 16 + ((p >> 2) & 1) * 8)); };
+    const double z = 0.0;
+    if (sub == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double2* const dst = slot(lane + r);
+            dst[0] = make_double2(contrib ? J[r + 0] : z, contrib ? J[r + 3] : z);
+            dst[1] = make_double2(contrib ? J[r + 6] : z, contrib ? J[r + 9] : z);
+            dst[2] = make_double2(contrib ? J[r + 12] : z, contrib ? J[r + 15] : z);
+            dst[3] = make_double2(contrib ? e[r] : z, (contrib && r == 0) ? 1.0 : z);
+        }
+    } else if (sub >= 3) {
+        double2* const dst = slot(lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = make_double2(z, z);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    fls_double4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const double x = tile[s * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+    }
+    const double h0 = acc[0] + __shfl_down(acc[2], 8, 64);
+    const double h1 = acc[1] + __shfl_down(acc[3], 8, 64);
+    const int j = lane & 15, i0 = lane >> 4;
+    if (j < 8) {
+        if (j < 6 && i0 <= j) partial_row[i0 * 6 - (i0 * (i0 - 1)) / 2 + (j - i0)] = h0;
+        if (j == 6) partial_row[21 + i0] = -h0;
+        const int i1 = i0 + 4;
+        if (i1 < 6) {
+            if (j < 6 && i1 <= j) partial_row[i1 * 6 - (i1 * (i1 - 1)) / 2 + (j - i1)] = h1;
+            if (j == 6) partial_row[21 + i1] = -h1;
+        } else if (i1 == 7 && j == 7) {
+            partial_row[28] = h1;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // fixed-order reduction of partial rows: rows [0,nrows) of `partials`, 32 columns, by a workgroup of
 // NT threads = NT/32 row-groups x 32 columns; every thread keeps 16 independent loads in flight per trip
