@@ -479,6 +479,52 @@ def bench_ndt_mapping_mode(reg, synth, n_scans=6):
     return out
 
 
+def bench_c5_native(m, reg, scans, n_gpus, share, table_torch, lanes=8):
+    """BASELINE configs[4] through fls_replicas_match_batch: one process, device list 0..N-1 (N x device 0 with FLS_BENCH_SHARE_DEVICE=1)."""
+    from funny_lidar_slam_amd import batch
+
+    devices = [0] * n_gpus if share else list(range(n_gpus))
+    t0 = time.perf_counter()
+    rs = m.Replicas(devices)
+    t_create = time.perf_counter() - t0
+    clusters = [reg.PointcloudCluster(planar_cloud_=s) for s in scans]
+    T0s = [np.eye(4)] * len(clusters)
+    rs.MatchBatch(clusters[:16 * n_gpus], T0s[:16 * n_gpus], lanes=lanes)  # lane creation, buffer growth
+    rs.MatchBatch(clusters, T0s, lanes=lanes)                              # one untimed pass (host pages of every scan touched)
+    reps = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oks, Tb, sb = rs.MatchBatch(clusters, T0s, lanes=lanes)
+        reps.append(time.perf_counter() - t0)
+    tb = float(np.median(reps))
+    rows = np.stack([batch.pack_result(Tb[k], oks[k], sb[k].iterations, sb[k].n_valid, sb[k].sum_res) for k in range(len(clusters))])
+    out = {"jobs": len(clusters), "devices": devices, "lanes_per_gpu": lanes, "scans_per_s": len(clusters) / tb, "ms_total": 1e3 * tb,
+           "ms_passes": [1e3 * t for t in reps], "converged_jobs": int(np.sum(rows[:, 16] == 1.0)), "replica_set_create_ms": 1e3 * t_create,
+           "import_ms_per_device": [float(t) for t in rs.import_ms()],
+           "note": "fls_replicas_match_batch: one process, one host thread + one replica handle per device, block partition, no collective; "
+                   "uploads from host memory inside the timed region"}
+    if table_torch is not None and table_torch.shape == rows.shape:
+        out["table_equals_torch_form_bitwise"] = bool(np.array_equal(rows, table_torch))
+    rs.close()
+    return out
+
+
+def self_launch(n: int) -> int:
+    """Re-run this command line under torch.distributed.run with n ranks on this node (127.0.0.1 rendezvous, a free port)."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks through torch.distributed.run (port {port})", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -486,12 +532,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the configs[4] batch measurement")
+    ap.add_argument("--no-native-batch", action="store_true", help="skip c5_batch_native (configs[4] through fls_replicas_match_batch, one process / N devices)")
     ap.add_argument("--no-extras", action="store_true", help="skip configs[0,2,3], mapping_mode, inclusive_h2d (N = 1 extras)")
     ap.add_argument("--batch-jobs", type=int, default=512, help="configs[4] jobs in total at 8 GPUs (64 per GPU); scaled by n_gpus / 8 below 8 GPUs unless --batch-jobs-total")
     ap.add_argument("--batch-jobs-total", type=int, default=0, help="configs[4]: total number of jobs (default: 512 at N = 1 and at N = 8, 64 * N otherwise)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl == RCCL; gloo + FLS_BENCH_SHARE_DEVICE=1 exercises the N > 1 code path on a 1-GPU box)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Called bare (`python bench.py --gpus 8`, the shape of the driver's N = 1 command): launch the ranks ourselves -- one process
+        # per GPU through torch.distributed.run, RCCL over xGMI -- and hand its exit code back.  Never a quiet 1-GPU run.
+        sys.exit(self_launch(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -503,11 +555,16 @@ def main():
 
     # configs[4] inputs first (host cores, forked workers: nothing GPU-side may be initialised yet)
     n_jobs = args.batch_jobs_total or (512 if n_gpus in (1, 8) else 64 * n_gpus)
-    my_scans, job_range = [], (0, 0)
+    my_scans, all_scans, job_range = [], [], (0, 0)
     if not args.no_batch:
         job_range = batch.partition(n_jobs, n_gpus, rank)
         t_gen = time.perf_counter()
-        my_scans = make_batch_scans(range(*job_range))
+        if rank == 0 and not args.no_native_batch:
+            # rank 0 also drives the native one-process form over ALL jobs (c5_batch_native), so it casts every scan
+            all_scans = make_batch_scans(range(n_jobs))
+            my_scans = all_scans[job_range[0]:job_range[1]]
+        else:
+            my_scans = make_batch_scans(range(*job_range))
         t_gen = time.perf_counter() - t_gen
 
     import torch
@@ -523,8 +580,13 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend="gloo")
-    if args.gpus != n_gpus and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
+    if args.gpus != n_gpus:
+        # a launcher that started a different number of ranks than --gpus says: refuse rather than report a line for the wrong N
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to run", file=sys.stderr)
+        if distributed:
+            dist.destroy_process_group()
+        sys.exit(2)
 
     from funny_lidar_slam_amd import _lib, registration as reg
 
@@ -664,6 +726,22 @@ def main():
         if map_bcast is not None:
             c5["map_image_broadcast"] = map_bcast
 
+    # configs[4] in its NATIVE form (SURVEY.md 8e "one process + N host threads"; include/fls_reg.h fls_replicas_*): rank 0's process holds one
+    # replica handle per device 0..N-1 (the owner's map image imported per device on that device's own host thread), the same n_jobs jobs are
+    # block-partitioned like batch.partition and run through fls_match_batch per device; results land in the caller's arrays, no collective.
+    # The other ranks idle on a CPU-side (gloo) barrier meanwhile -- an RCCL barrier would spin a kernel on the GPUs being measured.
+    c5n = None
+    if not args.no_batch and not args.no_native_batch:
+        idle = dist.new_group(backend="gloo") if distributed else None
+        if rank == 0:
+            try:
+                c5n = bench_c5_native(m, reg, all_scans, n_gpus, share, tab if c5 is not None else None)
+            except Exception as e:  # never at the expense of the line
+                c5n = {"error": repr(e)[:300]}
+        if distributed:
+            dist.barrier(group=idle)
+    del all_scans
+
     if rank == 0:
         from oracle import oracle as O
         from tests import util
@@ -707,6 +785,8 @@ def main():
             line["roofline"]["detail"] = detail
         if c5 is not None:
             line["c5_batch"] = c5
+        if c5n is not None:
+            line["c5_batch_native"] = c5n
         if n_gpus == 1:
             # the CPU oracle on the same inputs: pose error of the headline result, and the device counters against the oracle's
             # (the timed steps re-register the same scan on ONE handle, and nearest_points_ persists from Match to Match in the

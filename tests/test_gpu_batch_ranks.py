@@ -84,3 +84,28 @@ def test_two_ranks_real_blob_hip_matcher_equals_serial(built, tmp_path):
     line = [l for l in run.stdout.splitlines() if l.startswith("IMPORT_MS_MAX_OVER_RANKS")]
     assert line, run.stdout[-1000:]
     print(line[0])
+
+
+def test_bare_bench_gpus_2_reports_two_ranks(built):
+    """`python bench.py --gpus 2` with NO launcher around it: bench.py starts its two ranks itself, the line says
+    n_gpus = 2, configs[4] is sharded over both ranks, and the native one-process form (c5_batch_native, fls_replicas_match_batch over
+    the device list) returns the same table bit for bit.  One GPU is visible here: FLS_BENCH_SHARE_DEVICE=1 puts both ranks on it
+    and the process group on gloo -- the launch path, the partition, the blob broadcast and the gathers are the ones an 8-GPU node runs."""
+    import json
+
+    assert _lib.device_count() >= 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FLS_BENCH_SHARE_DEVICE"] = "1"
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--no-extras",
+                          "--no-cpu-baseline", "--batch-jobs-total", "24"], env=env, capture_output=True, text=True, timeout=1500)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, run.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "weak"
+    assert abs(line["value"] - 2 * 6 / (line["ms_per_step"] * 6e-3)) < 1e-6 * line["value"]  # whole-job throughput over both ranks
+    c5, c5n = line["c5_batch"], line["c5_batch_native"]
+    assert c5["jobs"] == 24 and c5["jobs_per_gpu"] == 12 and c5["converged_jobs"] == 24 and "map_image_broadcast" in c5
+    assert "error" not in c5n, c5n
+    assert c5n["jobs"] == 24 and c5n["devices"] == [0, 0] and c5n["converged_jobs"] == 24 and c5n["table_equals_torch_form_bitwise"] is True
+    print("bare --gpus 2:", {k: line[k] for k in ("value", "n_gpus", "ms_per_step")}, "c5", c5["scans_per_s"], "native", c5n["scans_per_s"], c5["map_image_broadcast"])
