@@ -286,14 +286,19 @@ inline void exact_sort_worker(ExactSortShared<T>& sh) {
     using namespace exact_sort_detail;
     constexpr long kGrain = 2048;  // ranges below this are finished by the thread that owns them
     std::vector<Task<T>> local;
+    // An exception in here (bad_alloc from a push_back) must not leave `open` counting a task nobody will finish -- every other
+    // participant, the caller included, would spin on it forever: the thrower marks the sort failed, which is an exit
+    // condition of its own for every worker; the caller then redoes the work sequentially on the untouched input.
+    try {
     for (;;) {
+        if (sh.failed.load(std::memory_order_acquire)) return;
         Task<T> t{nullptr, nullptr, 0};
         {
             std::lock_guard<std::mutex> lk(sh.mx);
             if (!sh.tasks.empty()) { t = sh.tasks.back(); sh.tasks.pop_back(); }
         }
         if (t.first == nullptr) {
-            if (sh.open.load(std::memory_order_acquire) == 0) return;
+            if (sh.open.load(std::memory_order_acquire) <= 0) return;
             HostPool::spin_pause();
             continue;
         }
@@ -319,6 +324,10 @@ inline void exact_sort_worker(ExactSortShared<T>& sh) {
             if (!sh.failed.load(std::memory_order_relaxed)) insertion_sort(u.first, u.last);
         }
         sh.open.fetch_sub(1, std::memory_order_acq_rel);
+    }
+    } catch (...) {
+        sh.failed.store(true, std::memory_order_release);
+        sh.open.store(0, std::memory_order_release);
     }
 }
 

@@ -118,8 +118,39 @@ __device__ __forceinline__ void knn_grid(const CellGridDev& cg, const float qx, 
         if (r.found == K && (double)r.d[K - 1] <= rad2) complete = true;
         if (rad2 >= (double)gate * (1.0 + 1e-5)) complete = true;
     }
+    if (!complete && cg.win.cells) {
+        // Dense cell window: keep walking rings instead of brute-forcing the map (a loop-closure source point whose nearest
+        // target lies tens of metres away -- sub-maps that only partly overlap -- used to scan the WHOLE target cloud in one lane).
+        // Only the part of a shell that intersects the window is visited, face by face, so all rings together cost at most one visit
+        // per window cell; the search ends with the usual bound (K-th distance inside the covered radius) or when the shell has left
+        // the window on every side (every cell seen).
+        const int wx = cx - cg.win.ox, wy = cy - cg.win.oy, wz = cz - cg.win.oz;  // query cell relative to the window (may be outside)
+        const int reach = max(max(max(wx, cg.win.nx - 1 - wx), max(wy, cg.win.ny - 1 - wy)), max(wz, cg.win.nz - 1 - wz));
+        for (int rho = kMaxRing + 1; rho <= reach && !complete; ++rho) {
+            const int z0 = max(-rho, -wz), z1 = min(rho, cg.win.nz - 1 - wz);
+            const int y0 = max(-rho, -wy), y1 = min(rho, cg.win.ny - 1 - wy);
+            const int x0 = max(-rho, -wx), x1 = min(rho, cg.win.nx - 1 - wx);
+            for (int dz = z0; dz <= z1; ++dz) {
+                const bool zface = dz == -rho || dz == rho;
+                for (int dy = y0; dy <= y1; ++dy) {
+                    const bool face = zface || dy == -rho || dy == rho;
+                    if (face) {
+                        for (int dx = x0; dx <= x1; ++dx) { probes++; knn_scan_cell<K>(cg, cx + dx, cy + dy, cz + dz, qx, qy, qz, r, hits, cand); }
+                    } else {
+                        if (-rho >= x0) { probes++; knn_scan_cell<K>(cg, cx - rho, cy + dy, cz + dz, qx, qy, qz, r, hits, cand); }
+                        if (rho <= x1) { probes++; knn_scan_cell<K>(cg, cx + rho, cy + dy, cz + dz, qx, qy, qz, r, hits, cand); }
+                    }
+                }
+            }
+            const double rad = (double)rho * cg.cell;
+            const double rad2 = rad * rad * (1.0 - 1e-5);
+            if (r.found == K && (double)r.d[K - 1] <= rad2) complete = true;
+            if (rad2 >= (double)gate * (1.0 + 1e-5)) complete = true;
+        }
+        complete = true;  // rho > reach: every cell of the window has been visited
+    }
     if (!complete) {
-        // brute force over the whole map (exact by construction)
+        // brute force over the whole map (exact by construction; hash-table grids only)
 #pragma unroll
         for (int j = 0; j < K; ++j) { r.d[j] = INFINITY; r.id[j] = 0x7fffffff; r.slot[j] = 0; }
         r.found = 0;

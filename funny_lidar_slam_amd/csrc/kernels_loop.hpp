@@ -123,7 +123,17 @@ struct NdtP2dTarget {
     const float* centroid;     // [rows][3]
     int min_b[3], div_b[3];
     float inv_leaf, radius2;   // 1 / resolution (float), resolution^2 (float)
+    const int2* leaf_hash;     // sparse form (leaf_row == nullptr): open addressing {cell, row}, cell = -1 empty; hash = cell * 2654435761
+    unsigned hash_mask;
 };
+__device__ __forceinline__ int ndt_leaf_row(const NdtP2dTarget& tg, const int cell) {
+    if (tg.leaf_row) return tg.leaf_row[cell];
+    for (unsigned h = ((unsigned)cell * 2654435761u) & tg.hash_mask;; h = (h + 1u) & tg.hash_mask) {
+        const int2 e = tg.leaf_hash[h];
+        if (e.x == cell) return e.y;
+        if (e.x < 0) return -1;
+    }
+}
 struct NdtP2dPose {
     LoopMat4f T;
     double gauss_d1, gauss_d2;
@@ -173,7 +183,7 @@ ndt_p2d_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const
                 for (int dx = -1; dx <= 1; ++dx) {
                     const int cx = c0 + dx, cy = c1 + dy, cz = c2 + dz;
                     if ((unsigned)cx >= (unsigned)tg.div_b[0] || (unsigned)cy >= (unsigned)tg.div_b[1] || (unsigned)cz >= (unsigned)tg.div_b[2]) continue;
-                    const int row = tg.leaf_row[(cz * tg.div_b[1] + cy) * tg.div_b[0] + cx];
+                    const int row = ndt_leaf_row(tg, (cz * tg.div_b[1] + cy) * tg.div_b[0] + cx);
                     if (row < 0) continue;
                     const float ex = xt[0] - tg.centroid[3 * row], ey = xt[1] - tg.centroid[3 * row + 1], ez = xt[2] - tg.centroid[3 * row + 2];
                     float d2 = 0.0f;  // flann::L2_Simple

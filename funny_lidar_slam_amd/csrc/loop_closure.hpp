@@ -178,7 +178,22 @@ struct LoopMatcher {
         DevBuf<int> d_leaf_row;
         DevBuf<double> d_mean, d_icov;
         DevBuf<float> d_centroid;
+        // sparse form (grid volume above kMaxDenseLeafCells: a stray far point must not cost gigabytes): cell -> row through an
+        // open-addressing table of {cell, row} pairs instead of the dense [div2][div1][div0] table
+        std::vector<int2> leaf_hash;
+        DevBuf<int2> d_leaf_hash;
+        unsigned hash_mask = 0;
+        bool sparse = false;
     };
+    static constexpr size_t kMaxDenseLeafCells = size_t(32) << 20;  // 32 Mi cells: 128 MiB per dense int table (host x 2, device x 1)
+    static unsigned leaf_hash_of(const int cell) { return unsigned(cell) * 2654435761u; }
+    // release host / device tables an outlier call inflated (the matcher is cached for the life of the process)
+    template <class V> static void shrink_if_oversized(V& v, const size_t need) {
+        if (v.capacity() > (size_t(4) << 20) && v.capacity() > 4 * need) { V().swap(v); }
+    }
+    template <class T> static void shrink_if_oversized(DevBuf<T>& b, const size_t need) {
+        if (b.cap > (size_t(4) << 20) && b.cap > 4 * need) { (void)hipDeviceSynchronize(); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    }
     struct LeafAcc { int n = 0; double sum[3] = {0, 0, 0}, xx[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; float csum[3] = {0, 0, 0}; };
     std::vector<int> acc_of;
     std::vector<LeafAcc> accs;
@@ -220,25 +235,65 @@ struct LoopMatcher {
         // emission order come from a dense cell -> accumulator table (the grid volume is bounded above) walked in ascending cell index.
         // (A std::map here cost ~100 ns per point: 4-5 ms per Match.)
         const size_t n_cells = size_t(tl.div_b[0]) * tl.div_b[1] * tl.div_b[2];
-        acc_of.assign(n_cells, -1);
+        tl.sparse = n_cells > kMaxDenseLeafCells;
         accs.clear();
-        for (const PtI& p : in) {
-            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
-            const int i0 = int(std::floor(p.x * inv) - float(tl.min_b[0])), i1 = int(std::floor(p.y * inv) - float(tl.min_b[1])), i2 = int(std::floor(p.z * inv) - float(tl.min_b[2]));
-            int& slot = acc_of[size_t(i0 + i1 * m1 + i2 * m2)];
-            if (slot < 0) { slot = int(accs.size()); accs.emplace_back(); }
-            LeafAcc& l = accs[size_t(slot)];
+        auto accumulate = [](LeafAcc& l, const PtI& p) {
             const double q[3] = {double(p.x), double(p.y), double(p.z)};
             for (int a = 0; a < 3; ++a) l.sum[a] += q[a];
             for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) l.xx[r + 3 * c] += q[r] * q[c];
             l.csum[0] += p.x; l.csum[1] += p.y; l.csum[2] += p.z;
             ++l.n;
+        };
+        auto cell_of = [&](const PtI& p) {
+            const int i0 = int(std::floor(p.x * inv) - float(tl.min_b[0])), i1 = int(std::floor(p.y * inv) - float(tl.min_b[1])), i2 = int(std::floor(p.z * inv) - float(tl.min_b[2]));
+            return i0 + i1 * m1 + i2 * m2;  // < INT_MAX (checked above)
+        };
+        // occupied cells in ascending cell index with their accumulators: `order` = {cell, accumulator}
+        std::vector<std::pair<int, int>> order;
+        if (!tl.sparse) {
+            shrink_if_oversized(acc_of, n_cells);
+            acc_of.assign(n_cells, -1);
+            for (const PtI& p : in) {
+                if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+                int& slot = acc_of[size_t(cell_of(p))];
+                if (slot < 0) { slot = int(accs.size()); accs.emplace_back(); }
+                accumulate(accs[size_t(slot)], p);
+            }
+            order.reserve(accs.size());
+            for (size_t cell_i = 0; cell_i < n_cells; ++cell_i)
+                if (acc_of[cell_i] >= 0) order.emplace_back(int(cell_i), acc_of[cell_i]);
+        } else {
+            // sparse: O(points) memory whatever the extent.  (cell, point) pairs sorted: ascending cell, a cell's points in cloud order --
+            // the same sums in the same order as the dense table gives
+            std::vector<std::pair<int, unsigned>> cp;
+            cp.reserve(in.size());
+            for (size_t k = 0; k < in.size(); ++k) {
+                const PtI& p = in[k];
+                if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+                cp.emplace_back(cell_of(p), unsigned(k));
+            }
+            std::sort(cp.begin(), cp.end());
+            for (size_t a = 0; a < cp.size();) {
+                size_t b = a;
+                accs.emplace_back();
+                for (; b < cp.size() && cp[b].first == cp[a].first; ++b) accumulate(accs.back(), in[cp[b].second]);
+                order.emplace_back(cp[a].first, int(accs.size()) - 1);
+                a = b;
+            }
+            std::vector<int>().swap(acc_of);
         }
-        tl.leaf_row.assign(n_cells, -1);
+        if (!tl.sparse) { shrink_if_oversized(tl.leaf_row, n_cells); tl.leaf_row.assign(n_cells, -1); }
+        else {
+            std::vector<int>().swap(tl.leaf_row);
+            size_t hs = 1024;
+            while (hs < 2 * order.size() + 2) hs <<= 1;
+            tl.hash_mask = unsigned(hs - 1);
+            tl.leaf_hash.assign(hs, make_int2(-1, -1));
+        }
         tl.mean.clear(); tl.icov.clear(); tl.centroid.clear();
-        for (size_t cell_i = 0; cell_i < n_cells; ++cell_i) {
-            if (acc_of[cell_i] < 0) continue;
-            const LeafAcc& l = accs[size_t(acc_of[cell_i])];
+        for (const std::pair<int, int>& oc : order) {
+            const size_t cell_i = size_t(oc.first);
+            const LeafAcc& l = accs[size_t(oc.second)];
             const int n = l.n;
             if (n < 6) continue;
             double mean[3], cov[9], icov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -260,15 +315,26 @@ struct LoopMatcher {
                 }
                 hm::inv3(cov, icov);
             }
-            tl.leaf_row[cell_i] = int(tl.rows);
+            if (!tl.sparse) tl.leaf_row[cell_i] = int(tl.rows);
+            else {
+                unsigned h = leaf_hash_of(int(cell_i)) & tl.hash_mask;
+                while (tl.leaf_hash[h].x >= 0) h = (h + 1) & tl.hash_mask;
+                tl.leaf_hash[h] = make_int2(int(cell_i), int(tl.rows));
+            }
             for (int a = 0; a < 3; ++a) { tl.mean.push_back(mean[a]); tl.centroid.push_back(l.csum[a] / float(n)); }
             for (int a = 0; a < 9; ++a) tl.icov.push_back(icov[a]);
             ++tl.rows;
         }
         if (tl.rows == 0) return false;
-        tl.d_leaf_row.reserve(tl.leaf_row.size());
+        shrink_if_oversized(tl.d_leaf_row, tl.leaf_row.size());
         tl.d_mean.reserve(tl.mean.size()); tl.d_icov.reserve(tl.icov.size()); tl.d_centroid.reserve(tl.centroid.size());
-        FLS_HIP(hipMemcpyAsync(tl.d_leaf_row.p, tl.leaf_row.data(), tl.leaf_row.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        if (!tl.sparse) {
+            tl.d_leaf_row.reserve(tl.leaf_row.size());
+            FLS_HIP(hipMemcpyAsync(tl.d_leaf_row.p, tl.leaf_row.data(), tl.leaf_row.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        } else {
+            tl.d_leaf_hash.reserve(tl.leaf_hash.size());
+            FLS_HIP(hipMemcpyAsync(tl.d_leaf_hash.p, tl.leaf_hash.data(), tl.leaf_hash.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+        }
         FLS_HIP(hipMemcpyAsync(tl.d_mean.p, tl.mean.data(), tl.mean.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         FLS_HIP(hipMemcpyAsync(tl.d_icov.p, tl.icov.data(), tl.icov.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         FLS_HIP(hipMemcpyAsync(tl.d_centroid.p, tl.centroid.data(), tl.centroid.size() * sizeof(float), hipMemcpyHostToDevice, stream));
@@ -311,8 +377,8 @@ struct LoopMatcher {
         angle_derivatives(p, r.pose);
         r.pose.T = T;
         const TargetLeaves& tl = *r.tl;
-        NdtP2dTarget tg{tl.d_leaf_row.p, tl.d_mean.p, tl.d_icov.p, tl.d_centroid.p, {tl.min_b[0], tl.min_b[1], tl.min_b[2]}, {tl.div_b[0], tl.div_b[1], tl.div_b[2]},
-                        tl.inv, r.resolution * r.resolution};
+        NdtP2dTarget tg{tl.sparse ? nullptr : tl.d_leaf_row.p, tl.d_mean.p, tl.d_icov.p, tl.d_centroid.p, {tl.min_b[0], tl.min_b[1], tl.min_b[2]}, {tl.div_b[0], tl.div_b[1], tl.div_b[2]},
+                        tl.inv, r.resolution * r.resolution, tl.sparse ? tl.d_leaf_hash.p : nullptr, tl.hash_mask};
         const int n = int(r.src->n), nb = (n + kLoopBlock - 1) / kLoopBlock;
         ++r.evaluations;
         const double* v = reduce(nb, hessian ? 44 : 8, [&](const LoopOut rows) {

@@ -96,3 +96,16 @@ def test_loop_match_degenerate_inputs():
     T = np.eye(4)
     f, st = reg.LoopClosureMatch(empty, few, T)
     assert f == float(np.finfo(np.float32).max) and np.array_equal(T, np.eye(4))
+
+
+def test_loop_match_with_stray_far_points_takes_the_sparse_leaf_table():
+    """a few stray points kilometres away blow the target's bounding box up to > 32 Mi leaf cells at the 1 m / 2 m
+    stages -- the leaf table then lives in an open-addressing {cell, row} table instead of a multi-GB dense one; and the fitness /
+    correspondence searches of source points far from every target point walk rings over the cell window instead of scanning the
+    whole target cloud.  Same results as the oracle, and the next (ordinary) call on the cached matcher is unaffected."""
+    src, tgt, Tt = loopdata.make_pair(job=3, n_az=200, n_t=2, n_s=2)
+    stray = np.array([[3000.0, 2000.0, 40.0], [-2500.0, 1800.0, -30.0], [2999.0, 2001.0, 41.0]], np.float32)
+    tgt2 = np.concatenate([tgt, stray.astype(tgt.dtype)]) if tgt.shape[1] == 3 else np.concatenate([tgt, np.pad(stray, ((0, 0), (0, tgt.shape[1] - 3)))])
+    src2 = np.concatenate([src, (stray[:1] + np.float32(5.0)).astype(src.dtype)]) if src.shape[1] == 3 else np.concatenate([src, np.pad(stray[:1] + 5.0, ((0, 0), (0, src.shape[1] - 3))).astype(src.dtype)])
+    _compare(src2, tgt2, np.eye(4), None, "sub-maps + stray points 3.6 km away")
+    _compare(src, tgt, np.eye(4), Tt, "the same matcher afterwards, ordinary extent")
