@@ -45,6 +45,56 @@ struct DenseWindow {
     int nx, ny, nz;
 };
 
+// Two-level voxel image of the iVox map (round 4; replaces the bounding-box window for the iVox kind -- the reference's IVoxMap bounds the
+// NUMBER of voxels, never the extent, include/ivox_map/ivox_map.h:35): the voxel key space is cut into BRICKS of 8 x 8 x 8 voxels; a brick
+// that holds (or borders) an occupied voxel owns a slab of {begin, count} cells, found through a small open-addressing directory
+// {packed brick key, brick index}.  A slab stores 10 x 10 x 10 cells: the brick's own 8^3 plus a one-cell HALO that mirrors the boundary
+// cells of the neighbouring bricks, so that all 19 NEARBY18 probes of a query resolve inside the slab of the query's own brick -- ONE
+// directory look-up per query (one aligned 16-byte load, the same address for the lanes of a group), then plain slab offsets, no bounds
+// checks.  Invariant kept by every writer (host build, journal scatter, device AddPoints / evictions): a halo cell equals the interior
+// cell it mirrors, and a brick exists whenever one of its interior or (face / edge) halo cells is occupied -- so "brick missing" means
+// "no candidate in any of the 19 voxels".  NEARBY18 has no (+-1, +-1, +-1) offsets: corner halo cells are never read nor maintained.
+// Extent independent: bricks anywhere in the +-2^20 key range; a 1e6-point map is ~3.5 k bricks = 28 MB of cells (the bounding-box
+// window it replaces: 17 M cells = 136 MB) and a 56 KB directory.
+constexpr int kBrickLog = 3;
+constexpr int kBrickSide = 1 << kBrickLog;
+constexpr int kBrickStored = kBrickSide + 2;   // interior + halo
+constexpr unsigned kBrickStride = 1024u;       // cells per slab (1000 used), also the stride of every per-cell side array
+constexpr unsigned kBrickPending = 0xFFFFFFFFu;  // directory entry claimed, index not yet published (device-side creation)
+constexpr unsigned kBrickInvalid = 0xFFFFFFFEu;  // the brick pool was full when the entry was claimed (the batch is refused, the host rebuilds)
+struct BrickDir {
+    const HashEntry* table;  // {packed brick key, brick index, unused}; nullptr: image not in brick form
+    unsigned mask;           // table size - 1
+    const uint2* cells;      // [n_cap][kBrickStride] {begin, count}
+    unsigned n_cap;          // brick pool size (an index >= n_cap is "missing")
+};
+__host__ __device__ __forceinline__ unsigned brick_hash(const int bx, const int by, const int bz) {
+    const unsigned h = ((unsigned)bx * 73856093u) ^ ((unsigned)by * 19349663u) ^ ((unsigned)bz * 83492791u);
+    return h ^ (h >> 15);
+}
+// slab index of stored coordinates (0..9 per axis; interior voxel l = 0..7 sits at l + 1)
+__host__ __device__ __forceinline__ unsigned brick_slab_index(const int sx, const int sy, const int sz) {
+    return (unsigned)((sz * kBrickStored + sy) * kBrickStored + sx);
+}
+__host__ __device__ __forceinline__ bool brick_slab_interior(const unsigned l, int& sx, int& sy, int& sz) {
+    sz = (int)(l / (unsigned)(kBrickStored * kBrickStored));
+    const unsigned r = l - (unsigned)sz * (unsigned)(kBrickStored * kBrickStored);
+    sy = (int)(r / (unsigned)kBrickStored);
+    sx = (int)(r - (unsigned)sy * (unsigned)kBrickStored);
+    return sz >= 1 && sz <= kBrickSide && sy >= 1 && sy <= kBrickSide && sx >= 1 && sx <= kBrickSide;  // (l >= 1000: sz >= 10 -> false)
+}
+// The bricks whose halo mirrors interior voxel (lx, ly, lz): f(dx, dy, dz) for every non-zero face / edge combination of the
+// per-axis directions e = -1 (l == 0), +1 (l == 7), 0 (inside).  The mirrored cell sits at stored coordinate l + 1 - 8 d.
+template <class F>
+__host__ __device__ __forceinline__ void brick_for_each_mirror(const int lx, const int ly, const int lz, F&& f) {
+    const int ex = lx == 0 ? -1 : lx == kBrickSide - 1 ? 1 : 0, ey = ly == 0 ? -1 : ly == kBrickSide - 1 ? 1 : 0, ez = lz == 0 ? -1 : lz == kBrickSide - 1 ? 1 : 0;
+    if ((ex | ey | ez) == 0) return;
+    for (int m = 1; m < 7; ++m) {  // (m == 7: the corner, never probed)
+        if (((m & 1) && !ex) || ((m & 2) && !ey) || ((m & 4) && !ez)) continue;
+        f((m & 1) ? ex : 0, (m & 2) ? ey : 0, (m & 4) ? ez : 0);
+    }
+}
+
 struct GnState {
     double T[16];  // current pose, column-major 4x4 (world <- body)
     double last_rot, last_pos;

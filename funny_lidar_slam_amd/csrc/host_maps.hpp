@@ -1,10 +1,9 @@
 // host_maps.hpp -- host-side map bookkeeping of the product (C++), and flattening into the
 // device image (hash table + voxel-bucketed float4 points) the kernels read.
 //
-//   HostIvox      : authoritative iVox state with the reference's exact insert / LRU-evict
-//                   semantics (src/ivox_map/ivox_map.cpp:122-143, capacity rule :133-136).
-//                   Round 1 keeps it on the host and re-flattens after an update; the
-//                   device-side incremental insert is SURVEY.md 8f rank 1 ("next").
+//   HostIvox      : the iVox state with the reference's exact insert / LRU-evict semantics
+//                   (src/ivox_map/ivox_map.cpp:122-143, capacity rule :133-136): the exact host path and
+//                   the mirror of the device image (ivox_image.hpp; kernels_ivox_update.hpp maintains it).
 //   voxel_grid    : pcl::VoxelGrid<PointXYZI>::filter semantics (centroid per leaf, ascending
 //                   leaf index) used inside Match by ICP/NDT and by the kd-tree map updates
 //                   (include/common/pointcloud_utility.h:216-271).
@@ -229,7 +228,8 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------
-// Device image of a hash grid: built on the host, uploaded in two copies.
+// Device image of a cell grid (the kd-tree kinds' CellGridImage): hash table and / or dense cell window.
+// (The iVox map has its own two-level brick image: ivox_image.hpp.)
 // ---------------------------------------------------------------------------------------------
 struct GridImage {
     std::vector<HashEntry> table;
@@ -277,189 +277,10 @@ struct GridImage {
                            : DenseWindow{nullptr, 0, 0, 0, 0, 0, 0};
     }
 
-    // ---- incremental maintenance (iVox, dense-window images) ------------------------------------------
-    // Every voxel owns a slot region with slack (capacity = next power of two >= its count, >= 4).  An
-    // AddCloudToLocalMap that adds a few thousand points then costs one small host-to-device copy of
-    // {slot, point} / {cell, begin, count} records and one scatter kernel, instead of re-flattening and
-    // re-uploading the whole map (~125 ms for 1e6 points).  A full rebuild happens only when a voxel falls
-    // outside the window, the point array runs out of room, or more than half of it is garbage.
-    struct PtUpd { unsigned slot; float x, y, z; int id; };
-    struct CellUpd { unsigned long long idx; unsigned begin, count; };
-    std::vector<PtUpd> pt_upd;
-    std::vector<CellUpd> cell_upd;
-    DevBuf<PtUpd> d_pt_upd;
-    DevBuf<CellUpd> d_cell_upd;
-    size_t garbage = 0, n_pts_live = 0;
-    bool want_hash = true;  // build the hash table too (fallback / FLS_IVOX_DENSE=0)
-    // per-cell arrays of the device-side AddPoints (kernels_ivox_update.hpp): region capacity, LRU stamp, two scratch words
-    DevBuf<unsigned char> d_cap_log2;
-    DevBuf<unsigned long long> d_stamp;  // (64-bit like the NDT path's: the stamp base grows by the inserted points of every batch)
-    DevBuf<unsigned> d_pend, d_rank_mm;
-    size_t n_cells_alloc = 0;
-
-    static unsigned cap_for(size_t n) {
-        unsigned c = 4;
-        while (c < n) c <<= 1;
-        return c;
-    }
     bool cell_index(int x, int y, int z, size_t& idx) const {
         const long cx = long(x) - win_o[0], cy = long(y) - win_o[1], cz = long(z) - win_o[2];
         if (cx < 0 || cy < 0 || cz < 0 || cx >= win_n[0] || cy >= win_n[1] || cz >= win_n[2]) return false;
         idx = (size_t(cz) * win_n[1] + size_t(cy)) * win_n[0] + size_t(cx);
-        return true;
-    }
-
-    void build_from_ivox(HostIvox& m, hipStream_t s) {
-        // voxels in window order (z, y, x): spatially adjacent voxels get adjacent point buckets
-        struct Ref { int x, y, z; HostIvox::Voxel* v; };
-        std::vector<Ref> refs;
-        refs.reserve(m.n_alive);
-        int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-        size_t slots = 0;
-        for (auto& v : m.pool) {
-            if (!v.alive) continue;
-            Ref r;
-            unpack_key(v.key, r.x, r.y, r.z);
-            r.v = &v;
-            refs.push_back(r);
-            slots += cap_for(v.pts.size());
-            mn[0] = std::min(mn[0], r.x); mx[0] = std::max(mx[0], r.x);
-            mn[1] = std::min(mn[1], r.y); mx[1] = std::max(mx[1], r.y);
-            mn[2] = std::min(mn[2], r.z); mx[2] = std::max(mx[2], r.z);
-        }
-        std::sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) {
-            if (a.z != b.z) return a.z < b.z;
-            if (a.y != b.y) return a.y < b.y;
-            return a.x < b.x;
-        });
-        have_window = false;
-        size_t ncell = 0;
-        if (!refs.empty()) {
-            // margin for map growth: as much of (64, 64, 16) cells per side as the cell budget allows, at least 1
-            for (int shrink = 0; shrink < 8 && !have_window; ++shrink) {
-                const int mh = std::max(1, 64 >> shrink), mv = std::max(1, 16 >> shrink);
-                const int marg[3] = {mh, mh, mv};
-                for (int a = 0; a < 3; ++a) { win_o[a] = mn[a] - marg[a]; win_n[a] = mx[a] - mn[a] + 1 + 2 * marg[a]; }
-                ncell = size_t(win_n[0]) * size_t(win_n[1]) * size_t(win_n[2]);
-                have_window = ncell <= kMaxWindowCells;
-            }
-        }
-        const bool hash = want_hash || !have_window;
-        if (hash) begin_build(m.n_alive, slots);
-        else { table.clear(); mask = 0; pts.clear(); pts.reserve(slots); }
-        if (have_window) cells.assign(ncell, make_uint2(0u, 0u));
-        for (const Ref& r : refs) {
-            HostIvox::Voxel& v = *r.v;
-            const unsigned beg = unsigned(pts.size()), cap = cap_for(v.pts.size());
-            if (hash) {
-                unsigned h = hash_key(v.key) & mask;
-                while (table[h].key != kEmptyKey) h = (h + 1) & mask;
-                table[h] = HashEntry{v.key, beg, unsigned(v.pts.size())};
-            }
-            pts.insert(pts.end(), v.pts.begin(), v.pts.end());
-            pts.resize(size_t(beg) + cap, Pt4{0.f, 0.f, 0.f, -1});  // slack
-            v.img_begin = beg; v.img_cap = cap; v.img_cnt = unsigned(v.pts.size());
-            if (have_window) {
-                size_t idx;
-                cell_index(r.x, r.y, r.z, idx);
-                cells[idx] = make_uint2(beg, unsigned(v.pts.size()));
-            }
-        }
-        used = pts.size();
-        garbage = 0;
-        n_pts_live = m.n_points;
-        m.clear_journal();
-        if (have_window) {
-            d_cells.reserve(cells.size());
-            FLS_HIP(hipMemcpyAsync(d_cells.p, cells.data(), cells.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
-        }
-        if (hash) d_table.reserve(table.size());
-        d_pts.reserve(used + used / 2 + (size_t(1) << 16));  // room for growth without reallocation
-        if (hash) FLS_HIP(hipMemcpyAsync(d_table.p, table.data(), table.size() * sizeof(HashEntry), hipMemcpyHostToDevice, s));
-        if (used) FLS_HIP(hipMemcpyAsync(d_pts.p, pts.data(), used * sizeof(Pt4), hipMemcpyHostToDevice, s));
-        FLS_HIP(hipStreamSynchronize(s));
-        std::vector<uint2>().swap(cells);  // the device copy is authoritative from here on
-        std::vector<Pt4>().swap(pts);
-    }
-
-    // Per-cell arrays of the device-side AddPoints, regenerated from the mirror (which must be in sync with the image: right after
-    // build_from_ivox or a journal update).  LRU stamps 1..n_alive from the tail (oldest) to the head.  Returns the stamp base.
-    unsigned long long upload_update_meta(const HostIvox& m, hipStream_t s) {
-        const size_t ncell = size_t(win_n[0]) * size_t(win_n[1]) * size_t(win_n[2]);
-        std::vector<unsigned char> cap(ncell, 0);
-        std::vector<unsigned long long> stamp(ncell, 0ull);
-        unsigned long long t = 0;
-        for (int v = m.tail; v >= 0; v = m.pool[v].prev) {
-            int x, y, z;
-            unpack_key(m.pool[v].key, x, y, z);
-            size_t idx;
-            if (!cell_index(x, y, z, idx)) continue;
-            unsigned l = 0;
-            while ((1u << l) < m.pool[v].img_cap) ++l;
-            cap[idx] = (unsigned char)l;
-            stamp[idx] = (unsigned long long)(++t);
-        }
-        d_cap_log2.reserve(ncell);
-        d_stamp.reserve(ncell);
-        d_pend.reserve(ncell);
-        d_rank_mm.reserve(ncell);
-        n_cells_alloc = ncell;
-        FLS_HIP(hipMemcpyAsync(d_cap_log2.p, cap.data(), ncell, hipMemcpyHostToDevice, s));
-        FLS_HIP(hipMemcpyAsync(d_stamp.p, stamp.data(), ncell * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-        FLS_HIP(hipMemsetAsync(d_pend.p, 0, ncell * sizeof(unsigned), s));
-        FLS_HIP(hipMemsetAsync(d_rank_mm.p, 0xff, ncell * sizeof(unsigned), s));
-        FLS_HIP(hipStreamSynchronize(s));  // (the host vectors go out of scope)
-        return t;
-    }
-
-    // Collect the journal of `m` into update records.  Returns false when a full rebuild is required.
-    bool collect_incremental(HostIvox& m) {
-        if (!have_window || want_hash) return false;
-        pt_upd.clear();
-        cell_upd.clear();
-        for (unsigned long long key : m.evicted_keys) {
-            int x, y, z;
-            unpack_key(key, x, y, z);
-            size_t idx;
-            if (cell_index(x, y, z, idx)) cell_upd.push_back(CellUpd{idx, 0u, 0u});
-        }
-        size_t new_used = used, new_garbage = garbage;
-        for (int vi : m.touched) {
-            HostIvox::Voxel& v = m.pool[vi];
-            if (!v.alive) continue;  // created and evicted inside the same batch
-            int x, y, z;
-            unpack_key(v.key, x, y, z);
-            size_t idx;
-            if (!cell_index(x, y, z, idx)) return false;  // grew out of the window
-            const unsigned cnt = unsigned(v.pts.size());
-            unsigned from = v.img_cnt;
-            if (cnt > v.img_cap) {  // relocate the bucket to the end of the array, twice the room
-                const unsigned cap = cap_for(cnt);
-                if (new_used + cap > d_pts.cap) return false;
-                new_garbage += v.img_cap;
-                v.img_begin = unsigned(new_used);
-                v.img_cap = cap;
-                new_used += cap;
-                from = 0;
-            }
-            for (unsigned k = from; k < cnt; ++k) pt_upd.push_back(PtUpd{v.img_begin + k, v.pts[k].x, v.pts[k].y, v.pts[k].z, v.pts[k].id});
-            v.img_cnt = cnt;
-            cell_upd.push_back(CellUpd{idx, v.img_begin, cnt});
-        }
-        // a voxel evicted and re-created inside one batch yields two records for the same cell: the scatter kernel
-        // writes records in parallel, so keep only the LAST record per cell (stable sort, then unique from the back)
-        std::stable_sort(cell_upd.begin(), cell_upd.end(), [](const CellUpd& a, const CellUpd& b) { return a.idx < b.idx; });
-        size_t w = 0;
-        for (size_t r = 0; r < cell_upd.size(); ++r) {
-            if (r + 1 < cell_upd.size() && cell_upd[r + 1].idx == cell_upd[r].idx) continue;
-            cell_upd[w++] = cell_upd[r];
-        }
-        cell_upd.resize(w);
-        if (new_garbage * 2 > new_used && new_used > (size_t(1) << 20)) return false;  // compact
-        used = new_used;
-        garbage = new_garbage;
-        n_pts_live = m.n_points;
-        m.clear_journal();
         return true;
     }
 };

@@ -157,7 +157,7 @@ __device__ __forceinline__ void store_nn_row(float4* p, const float4 v) {
 template <int G, bool COUNT, bool DENSE, bool FIRST, bool BAL = false>
 __global__ void __launch_bounds__(256)
 ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
-                const GnState* __restrict__ st, const Pose16 T0, const DevGrid grid, const DenseWindow win,
+                const GnState* __restrict__ st, const Pose16 T0, const DevGrid grid, const BrickDir bd,
                 const float inv_res, float4* __restrict__ nn_pts /* [n][5] */, unsigned char* __restrict__ nn_cnt,
                 unsigned char* __restrict__ flag, TrafficCounters* __restrict__ tc, const int chunk,
                 unsigned* __restrict__ nn_ids /* [n][8]: map slots of the neighbours (ids form); nullptr: rows form */) {
@@ -227,14 +227,26 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
     };
     unsigned b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
     if (DENSE) {
-        // dense window: one 8-byte load per probe, addresses of neighbouring voxels are neighbours
+        // brick image (device_common.hpp): ONE directory look-up per query -- the same 16-byte entry for the lanes of a group -- then
+        // every probe is a slab offset from the query's own cell (the slab's halo mirrors the neighbouring bricks' boundary cells):
+        // no bounds checks, one aligned 8-byte load per probe, neighbouring voxels share cache lines
+        const int bx = kx >> kBrickLog, by = ky >> kBrickLog, bz = kz >> kBrickLog;
+        const unsigned long long bkey = pack_key(bx, by, bz);
+        unsigned h = brick_hash(bx, by, bz) & bd.mask;
+        HashEntry be = bd.table[h];
+        while (be.key != bkey && be.key != kEmptyKey) {  // (linear probing; the directory is at most a quarter full)
+            h = (h + 1) & bd.mask;
+            be = bd.table[h];
+        }
+        const bool have = in_range && be.key == bkey && be.begin < bd.n_cap;
+        const unsigned cbase = (have ? be.begin : 0u) * kBrickStride +
+                               brick_slab_index((kx & (kBrickSide - 1)) + 1, (ky & (kBrickSide - 1)) + 1, (kz & (kBrickSide - 1)) + 1);
         auto cell = [&](const int r, unsigned& beg, unsigned& cnt) {
             const int k = sub + G * r;
             int ox, oy, oz;
             nearby18(k < 19 ? k : 0, ox, oy, oz);
-            const int cx = kx + ox - win.ox, cy = ky + oy - win.oy, cz = kz + oz - win.oz;
-            const bool ok = in_range && k < 19 && (unsigned)cx < (unsigned)win.nx && (unsigned)cy < (unsigned)win.ny && (unsigned)cz < (unsigned)win.nz;
-            const uint2 e = win.cells[ok ? (unsigned)((cz * win.ny + cy) * win.nx + cx) : 0u];  // < 2^31 cells (host_maps.hpp)
+            const bool ok = have && k < 19;
+            const uint2 e = bd.cells[cbase + (unsigned)((oz * kBrickStored + oy) * kBrickStored + ox)];  // (always inside the slab)
             beg = e.x;
             cnt = ok ? e.y : 0u;
             if (COUNT && in_range && k < 19) { c_probes++; if (cnt) { c_hits++; c_cand += cnt; } }

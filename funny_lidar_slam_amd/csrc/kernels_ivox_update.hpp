@@ -52,6 +52,8 @@ struct IvoxUpdState {
     unsigned evict;           // voxels this batch evicts (LRU capacity reached inside the batch)
     unsigned evict_ready, n_list;  // the host queued the eviction selection; entries of the stamp-sorted list of alive cells
     unsigned long long evicted_points, evicted_slots;  // totals of the evicted voxels (ivox_evict_apply)
+    unsigned n_bricks;        // bricks in the directory (device-side creation: ivox_upd_seq); may overshoot the pool inside a refused batch, clamped at commit
+    unsigned pad_;
 };
 // what the host reads back (host-mapped pinned memory, written by ivox_upd_commit)
 struct IvoxUpdMailbox {
@@ -59,7 +61,7 @@ struct IvoxUpdMailbox {
     unsigned n_alive, status, added, touched;
     int next_id;
     unsigned seq;
-    unsigned evicted, pad;
+    unsigned evicted, n_bricks;
 };
 
 struct IvoxUpdArrays {
@@ -69,9 +71,66 @@ struct IvoxUpdArrays {
     unsigned long long* stamp;  // per cell: LRU stamp of the last insertion (larger = more recent); 64-bit, never wraps
     unsigned* pend;          // per cell scratch: points of this batch (0 between batches)
     unsigned* rank_mm;       // per cell scratch: first, later last, rank of this batch (kUpdNoRank between batches)
-    int ox, oy, oz, nx, ny, nz;
+    HashEntry* dir;          // brick directory {packed brick key, brick index} (device_common.hpp BrickDir), open addressing
+    unsigned dir_mask;
+    unsigned n_bricks_cap;   // brick pool size: slabs [0, n_bricks_cap) x kBrickStride cells exist (zero beyond the bricks in use)
+    unsigned long long* brick_key;  // [n_bricks_cap] packed key of brick i
     float inv_res;
 };
+
+// ---- brick directory on the device ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned brick_find(const IvoxUpdArrays& a, const int bx, const int by, const int bz) {
+    const unsigned long long key = pack_key(bx, by, bz);
+    for (unsigned h = brick_hash(bx, by, bz) & a.dir_mask;; h = (h + 1u) & a.dir_mask) {
+        const unsigned long long k = a.dir[h].key;
+        if (k == key) return a.dir[h].begin;
+        if (k == kEmptyKey) return kBrickInvalid;
+    }
+}
+// Find the brick or create it (ivox_upd_seq only: the one kernel that may add bricks).  A creation claims an empty directory entry with
+// a 64-bit CAS on its key, draws the next slab of the pre-zeroed pool and publishes the index; a thread that meets a claimed entry whose
+// index is still pending retries -- the winner publishes inside the SAME loop iteration it won in, so lanes of one wave cannot wait on
+// each other.  A new brick is empty (all cells zero) whatever happens to the batch: creating it early is harmless if the batch is refused.
+// Pool or directory exhausted: the entry gets kBrickInvalid, the batch is refused (kUpdArrayFull) and the host rebuilds with more room.
+__device__ __forceinline__ unsigned brick_find_or_create(const IvoxUpdArrays& a, IvoxUpdState* __restrict__ st, const int bx, const int by, const int bz) {
+    const unsigned long long key = pack_key(bx, by, bz);
+    unsigned h = brick_hash(bx, by, bz) & a.dir_mask;
+    for (unsigned tries = 0; tries < 65536u; ++tries) {
+        const unsigned long long k = __hip_atomic_load(&a.dir[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == key) {
+            const unsigned idx = __hip_atomic_load(&a.dir[h].begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (idx != kBrickPending) return idx;
+            continue;  // claimed by another thread, index not yet published
+        }
+        if (k == kEmptyKey) {
+            const unsigned long long prev = atomicCAS((unsigned long long*)&a.dir[h].key, kEmptyKey, key);
+            if (prev == kEmptyKey) {
+                unsigned idx = atomicAdd(&st->n_bricks, 1u);
+                if (idx >= a.n_bricks_cap) { idx = kBrickInvalid; atomicOr(&st->status, kUpdArrayFull); }
+                else a.brick_key[idx] = key;
+                __hip_atomic_store(&a.dir[h].begin, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return idx;
+            }
+            if (prev == key) continue;  // lost the race for the same brick: read its index
+        }
+        h = (h + 1u) & a.dir_mask;
+    }
+    atomicOr(&st->status, kUpdArrayFull);
+    return kBrickInvalid;
+}
+// the halo copies of primary cell `cell` (a boundary voxel of its brick) in the neighbouring bricks' slabs
+__device__ __forceinline__ void brick_write_mirrors(const IvoxUpdArrays& a, const unsigned cell, const uint2 val) {
+    int sx, sy, sz;
+    if (!brick_slab_interior(cell & (kBrickStride - 1u), sx, sy, sz)) return;
+    int bx = 0, by = 0, bz = 0;
+    bool have_key = false;
+    brick_for_each_mirror(sx - 1, sy - 1, sz - 1, [&](const int dx, const int dy, const int dz) {
+        if (!have_key) { unpack_key(a.brick_key[cell / kBrickStride], bx, by, bz); have_key = true; }
+        const unsigned nb = brick_find(a, bx + dx, by + dy, bz + dz);
+        if (nb < a.n_bricks_cap)  // (exists by the invariant: ivox_upd_seq / the host build created it with the voxel)
+            a.cells[nb * kBrickStride + brick_slab_index(sx - kBrickSide * dx, sy - kBrickSide * dy, sz - kBrickSide * dz)] = val;
+    });
+}
 struct IvoxUpdBatch {
     const unsigned char* code;  // [n] 0 drop, 1 points_to_add, 2 point_no_need_downsample (ivox_add_decide_kernel)
     const float4* pw;           // [n] world points
@@ -157,13 +216,23 @@ ivox_upd_seq(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restri
     const float fx = roundf(p.x * a.inv_res), fy = roundf(p.y * a.inv_res), fz = roundf(p.z * a.inv_res);
     unsigned cell = kUpdInvalidCell;
     if (fabsf(fx) < (float)kKeyLimit && fabsf(fy) < (float)kKeyLimit && fabsf(fz) < (float)kKeyLimit) {
-        const int cx = (int)fx - a.ox, cy = (int)fy - a.oy, cz = (int)fz - a.oz;
-        if ((unsigned)cx < (unsigned)a.nx && (unsigned)cy < (unsigned)a.ny && (unsigned)cz < (unsigned)a.nz)
-            cell = (unsigned)((cz * a.ny + cy) * a.nx + cx);
+        // the voxel's brick, and -- for a voxel on its brick's boundary -- the neighbouring bricks whose halo mirrors it: all of them
+        // exist from here on (created empty if need be)
+        const int kx = (int)fx, ky = (int)fy, kz = (int)fz;
+        const int bx = kx >> kBrickLog, by = ky >> kBrickLog, bz = kz >> kBrickLog;
+        const int lx = kx & (kBrickSide - 1), ly = ky & (kBrickSide - 1), lz = kz & (kBrickSide - 1);
+        const unsigned bi = brick_find_or_create(a, st, bx, by, bz);
+        bool all = bi < a.n_bricks_cap;
+        brick_for_each_mirror(lx, ly, lz, [&](const int dx, const int dy, const int dz) {
+            if (all) all = brick_find_or_create(a, st, bx + dx, by + dy, bz + dz) < a.n_bricks_cap;
+        });
+        if (all) cell = bi * kBrickStride + brick_slab_index(lx + 1, ly + 1, lz + 1);
+    } else {
+        atomicOr(&st->status, kUpdOutside);  // (a key beyond +-2^20: the host path reports FLS_ERR_RANGE)
     }
     b.seq_src[r] = (unsigned)i;
     b.seq_cell[r] = cell;
-    if (cell == kUpdInvalidCell) { atomicOr(&st->status, kUpdOutside); b.jj[r] = 0u; return; }
+    if (cell == kUpdInvalidCell) { b.jj[r] = 0u; return; }  // (status already says why: kUpdOutside or kUpdArrayFull)
     b.jj[r] = atomicAdd(&a.pend[cell], 1u);
     atomicMin(&a.rank_mm[cell], r);
 }
@@ -231,14 +300,18 @@ ivox_upd_scan2(const IvoxUpdBatch b, IvoxUpdState* __restrict__ st, const unsign
     }
 }
 
-// ---- eviction selection: the alive cells of the window as a list sorted by LRU stamp ------------------------------------------
+// ---- eviction selection: the alive cells of the image as a list sorted by LRU stamp ------------------------------------------
 constexpr int kEvBlock = 1024;
+__device__ __forceinline__ bool brick_cell_is_primary(const unsigned c) {  // an interior cell of its slab (halo cells are mirrors)
+    int sx, sy, sz;
+    return brick_slab_interior(c & (kBrickStride - 1u), sx, sy, sz);
+}
 // pass 1: alive cells per block of kEvBlock cells
 __global__ void __launch_bounds__(kEvBlock)
 ivox_evict_count(const uint2* __restrict__ cells, const unsigned ncell, unsigned* __restrict__ bt) {
     __shared__ unsigned wsum[kEvBlock / 64];
     const unsigned c = blockIdx.x * kEvBlock + threadIdx.x;
-    const bool alive = c < ncell && cells[c].y != 0u;
+    const bool alive = c < ncell && brick_cell_is_primary(c) && cells[c].y != 0u;
     const unsigned long long m = __ballot(alive);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (unsigned)__popcll(m);
     __syncthreads();
@@ -250,7 +323,7 @@ ivox_evict_list(const uint2* __restrict__ cells, const unsigned long long* __res
                 unsigned* __restrict__ key, unsigned* __restrict__ val) {
     __shared__ unsigned wsum[kEvBlock / 64];
     const unsigned c = blockIdx.x * kEvBlock + threadIdx.x;
-    const bool alive = c < ncell && cells[c].y != 0u;
+    const bool alive = c < ncell && brick_cell_is_primary(c) && cells[c].y != 0u;
     const unsigned long long m = __ballot(alive);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) wsum[w] = (unsigned)__popcll(m);
@@ -334,6 +407,7 @@ ivox_evict_apply(const unsigned* __restrict__ evict_list, const IvoxUpdArrays a,
     atomicAdd(&st->evicted_points, (unsigned long long)e.y);
     atomicAdd(&st->evicted_slots, cl ? (unsigned long long)(1u << cl) : 0ull);
     a.cells[cell] = make_uint2(0u, 0u);  // the region's slots are garbage from here on (never read: count 0)
+    brick_write_mirrors(a, cell, make_uint2(0u, 0u));
     a.cap_log2[cell] = 0;
     a.stamp[cell] = 0ull;
 }
@@ -372,6 +446,7 @@ ivox_upd_regions(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState
         a.cap_log2[cell] = (unsigned char)upd_log2(ncap);
     }
     a.cells[cell] = make_uint2(begin, total);
+    brick_write_mirrors(a, cell, make_uint2(begin, total));
     b.tlist[base.z + loc.z] = cell;
 }
 
@@ -431,9 +506,10 @@ ivox_upd_finish(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState*
     }
 }
 
-__global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* __restrict__ mb, const unsigned seq) {
+__global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* __restrict__ mb, const unsigned seq, const unsigned n_bricks_cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const unsigned A = st->n1 + st->n2;
+    if (st->n_bricks > n_bricks_cap) st->n_bricks = n_bricks_cap;  // (a refused batch overshot the pool)
     if (st->apply) {
         st->n_alive += st->creations;
         st->n_alive -= st->evict;
@@ -444,6 +520,7 @@ __global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* _
         st->garbage += st->relocated_garbage + st->evicted_slots;
         st->stamp_base += A;
     }
+    __hip_atomic_store(&mb->n_bricks, st->n_bricks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&mb->n_points, st->n_points, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&mb->used, st->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&mb->garbage, st->garbage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -455,6 +532,42 @@ __global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* _
     __hip_atomic_store(&mb->evicted, st->apply ? st->evict : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- image <-> host mirror ---------------------------------------------------------------------------------------------------------
+// every alive voxel of the image as a record (sync_host_from_device: the device image back into the host mirror), in any order
+struct IvoxAliveRec { unsigned long long key; unsigned begin, count, cap_log2, pad; unsigned long long stamp; };
+__global__ void __launch_bounds__(256)
+ivox_list_alive_kernel(const uint2* __restrict__ cells, const unsigned long long* __restrict__ brick_key, const unsigned ncell,
+                       const unsigned char* __restrict__ cap_log2, const unsigned long long* __restrict__ stamp, IvoxAliveRec* __restrict__ out,
+                       unsigned* __restrict__ counter, const unsigned out_cap) {
+    const unsigned c = blockIdx.x * 256u + threadIdx.x;
+    int sx = 0, sy = 0, sz = 0;
+    const bool prim = c < ncell && brick_slab_interior(c & (kBrickStride - 1u), sx, sy, sz);
+    const uint2 e = prim ? cells[c] : make_uint2(0u, 0u);
+    const bool alive = prim && e.y != 0u;
+    const unsigned long long m = __ballot(alive);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0u;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (unsigned)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1, 64);
+    if (!alive) return;
+    const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    if (pos >= out_cap) return;
+    int bx, by, bz;
+    unpack_key(brick_key[c / kBrickStride], bx, by, bz);
+    out[pos] = IvoxAliveRec{pack_key(bx * kBrickSide + sx - 1, by * kBrickSide + sy - 1, bz * kBrickSide + sz - 1), e.x, e.y, (unsigned)cap_log2[c], 0u, stamp[c]};
+}
+// per-voxel update metadata scattered into the (zeroed) per-cell arrays (enter_device_mode)
+struct IvoxMetaRec { unsigned cell, cap_log2; unsigned long long stamp; };
+__global__ void __launch_bounds__(256)
+ivox_meta_scatter_kernel(const IvoxMetaRec* __restrict__ rec, const unsigned n, unsigned char* __restrict__ cap_log2, unsigned long long* __restrict__ stamp) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const IvoxMetaRec r = rec[i];
+    cap_log2[r.cell] = (unsigned char)r.cap_log2;
+    stamp[r.cell] = r.stamp;
 }
 
 }  // namespace fls

@@ -12,6 +12,7 @@
 #include "kernels_knn.hpp"
 #include "kernels_ivox_coop.hpp"
 #include "kernels_ivox_update.hpp"
+#include "ivox_image.hpp"
 #include "fitness_host.hpp"
 #include "device_voxelgrid.hpp"
 #include <thread>
@@ -22,11 +23,12 @@ namespace fls {
 
 struct P2PlaneIvoxMatcher final : fls_matcher {
     HostIvox ivox;
-    GridImage image;
+    IvoxImage image;
     bool image_dirty = true, image_built = false;
+    bool rebuild_after_replay = false;  // the device refused a batch for lack of room: the next refresh re-flattens
     size_t n_incremental = 0, n_full_rebuilds = 0;
     // a batch lane (fls_match_batch) reads its owner's resident map image
-    const GridImage* borrowed = nullptr;
+    const IvoxImage* borrowed = nullptr;
     bool host_timing = false;  // FLS_HOST_TIMING=1: print the host-side cost of every map update
     // ---- device-side AddPoints (kernels_ivox_update.hpp): while `device_map` is set the DEVICE image is the authoritative map
     // (points, voxel table, LRU stamps, counters) and the host mirror `ivox` is stale; sync_host_from_device() brings it back.
@@ -41,7 +43,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     IvoxUpdMailbox* upd_mb_host = nullptr;
     IvoxUpdMailbox* upd_mb_dev = nullptr;
     unsigned upd_seq = 0;
-    size_t dev_n_points = 0, dev_n_alive = 0;  // mirrored from the update mailbox
+    size_t dev_n_points = 0, dev_n_alive = 0, dev_n_bricks = 0;  // mirrored from the update mailbox
     unsigned long long stamp_bound = 0;        // upper bound of every LRU stamp on the device (sizes the second sort round)
     DevBuf<uint2> d_lx, d_bt;
     DevBuf<unsigned> d_seq_src, d_seq_cell, d_jj, d_tlist;
@@ -121,27 +123,13 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     void refresh_image() {
         if (!image_dirty) return;
         image.want_hash = !use_dense;
+        if (rebuild_after_replay) { image_built = false; rebuild_after_replay = false; }
         if (image_built && image.collect_incremental(ivox)) {
-            const size_t np = image.pt_upd.size(), nc = image.cell_upd.size();
-            if (np + nc) {
-                image.d_pt_upd.reserve(std::max<size_t>(np, 1));
-                image.d_cell_upd.reserve(std::max<size_t>(nc, 1));
-                upd_stage.reserve(np * sizeof(GridImage::PtUpd) + nc * sizeof(GridImage::CellUpd) + 16);
-                std::memcpy(upd_stage.p, image.pt_upd.data(), np * sizeof(GridImage::PtUpd));
-                char* cpos = upd_stage.p + np * sizeof(GridImage::PtUpd);
-                std::memcpy(cpos, image.cell_upd.data(), nc * sizeof(GridImage::CellUpd));
-                if (np) FLS_HIP(hipMemcpyAsync(image.d_pt_upd.p, upd_stage.p, np * sizeof(GridImage::PtUpd), hipMemcpyHostToDevice, stream));
-                if (nc) FLS_HIP(hipMemcpyAsync(image.d_cell_upd.p, cpos, nc * sizeof(GridImage::CellUpd), hipMemcpyHostToDevice, stream));
-                const size_t m = std::max(np, nc);
-                hipLaunchKernelGGL(ivox_apply_updates_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, stream,
-                                   (const PtUpdDev*)image.d_pt_upd.p, int(np), (const CellUpdDev*)image.d_cell_upd.p, int(nc), image.d_pts.p,
-                                   image.d_cells.p);
-                FLS_HIP(hipGetLastError());
-                FLS_HIP(hipStreamSynchronize(stream));  // the staging buffer is reused by the next update
-            }
+            if (image.dir_dirty) image.upload_directory(stream);  // the host path created bricks (their slabs are still zero)
+            image.scatter_cell_records(stream, upd_stage);
             ++n_incremental;
         } else {
-            image.build_from_ivox(ivox, stream);
+            image.build_from_ivox(ivox, stream, upd_stage);
             image_built = true;
             ++n_full_rebuilds;
         }
@@ -149,50 +137,54 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         enter_device_mode();
     }
 
-    // Hand the map over to the device-side AddPoints when that path can be exact: dense voxel window, and the LRU capacity far
-    // enough away that the next batches will not evict (a batch that would is refused by the device and replayed on the host).
+    // Hand the map over to the device-side AddPoints: the brick image has no extent limit, so the only conditions left are the A/B
+    // switches (and, without device evictions, a margin below the LRU capacity).
     void enter_device_mode() {
         device_map = false;
-        if (!allow_device_map || borrowed || !use_dense || !image.have_window || image.want_hash || p.is_localization_mode) return;
+        if (!allow_device_map || borrowed || !use_dense || !image.have_bricks || image.want_hash || p.is_localization_mode) return;
         if (!device_evict && ivox.n_alive + device_margin >= ivox.capacity) return;  // without device evictions: stay clear of the capacity
         if (ivox.capacity < 4) return;
-        const unsigned long long stamp_base = image.upload_update_meta(ivox, stream);
+        const unsigned long long stamp_base = image.upload_update_meta(ivox, stream, upd_stage);
         IvoxUpdState st{};
         st.n_points = ivox.n_points; st.used = image.used; st.garbage = image.garbage; st.stamp_base = stamp_base;
         st.pts_capacity = image.d_pts.cap; st.n_alive = unsigned(ivox.n_alive); st.lru_capacity = unsigned(std::min<size_t>(ivox.capacity, 0xffffffffu));
         st.next_id = ivox.next_id;
+        st.n_bricks = unsigned(image.n_bricks());
         FLS_HIP(hipMemcpyAsync(d_upd_state.p, &st, sizeof(st), hipMemcpyHostToDevice, stream));
         FLS_HIP(hipStreamSynchronize(stream));
-        dev_n_points = ivox.n_points; dev_n_alive = ivox.n_alive;
+        dev_n_points = ivox.n_points; dev_n_alive = ivox.n_alive; dev_n_bricks = image.n_bricks();
         stamp_bound = stamp_base;
         device_map = true;
     }
 
-    // The device image back into the host mirror (device mode ends): voxel table, points, LRU order from the stamps.
+    // The device image back into the host mirror (device mode ends): the alive voxels as records (one compaction kernel), their
+    // points, the LRU order from the stamps, and the bricks the device created.
     void sync_host_from_device() {
         if (!device_map) return;
         IvoxUpdState st{};
         FLS_HIP(hipMemcpyAsync(&st, d_upd_state.p, sizeof(st), hipMemcpyDeviceToHost, stream));
         FLS_HIP(hipStreamSynchronize(stream));
-        const size_t ncell = image.n_cells_alloc;
-        std::vector<uint2> cells(ncell);
-        std::vector<unsigned long long> stamp(ncell);
-        std::vector<unsigned char> cap(ncell);
+        const size_t nb = std::min<size_t>(st.n_bricks, image.n_bricks_cap), ncell = nb * kBrickStride, n_alive = st.n_alive;
+        image.d_alive_rec.reserve(std::max<size_t>(n_alive, 1));
+        image.d_counter.reserve(1);
+        FLS_HIP(hipMemsetAsync(image.d_counter.p, 0, sizeof(unsigned), stream));
+        if (ncell)
+            hipLaunchKernelGGL(ivox_list_alive_kernel, dim3(unsigned((ncell + 255) / 256)), dim3(256), 0, stream, (const uint2*)image.d_cells.p,
+                               (const unsigned long long*)image.d_brick_key.p, unsigned(ncell), (const unsigned char*)image.d_cap_log2.p,
+                               (const unsigned long long*)image.d_stamp.p, image.d_alive_rec.p, image.d_counter.p, unsigned(n_alive));
+        FLS_HIP(hipGetLastError());
+        unsigned n_listed = 0;
+        std::vector<IvoxAliveRec> recs(n_alive);
         std::vector<Pt4> pts(st.used);
-        FLS_HIP(hipMemcpyAsync(cells.data(), image.d_cells.p, ncell * sizeof(uint2), hipMemcpyDeviceToHost, stream));
-        FLS_HIP(hipMemcpyAsync(stamp.data(), image.d_stamp.p, ncell * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-        FLS_HIP(hipMemcpyAsync(cap.data(), image.d_cap_log2.p, ncell, hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipMemcpyAsync(&n_listed, image.d_counter.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        if (n_alive) FLS_HIP(hipMemcpyAsync(recs.data(), image.d_alive_rec.p, n_alive * sizeof(IvoxAliveRec), hipMemcpyDeviceToHost, stream));
         if (st.used) FLS_HIP(hipMemcpyAsync(pts.data(), image.d_pts.p, st.used * sizeof(Pt4), hipMemcpyDeviceToHost, stream));
         FLS_HIP(hipStreamSynchronize(stream));
+        if (n_listed != n_alive) throw std::runtime_error("iVox image: the alive-voxel count of the device state does not match its cells");
+        image.download_directory(nb, stream);
         std::vector<HostIvox::ImageVoxel> vox;
-        vox.reserve(st.n_alive);
-        const int nx = image.win_n[0], ny = image.win_n[1];
-        for (size_t idx = 0; idx < ncell; ++idx) {
-            if (cells[idx].y == 0u) continue;
-            const int cx = int(idx % size_t(nx)), cy = int((idx / size_t(nx)) % size_t(ny)), cz = int(idx / (size_t(nx) * size_t(ny)));
-            vox.push_back(HostIvox::ImageVoxel{pack_key(cx + image.win_o[0], cy + image.win_o[1], cz + image.win_o[2]), cells[idx].x, cells[idx].y,
-                                               cap[idx] ? (1u << cap[idx]) : 0u, stamp[idx]});
-        }
+        vox.reserve(n_alive);
+        for (const IvoxAliveRec& r : recs) vox.push_back(HostIvox::ImageVoxel{r.key, r.begin, r.count, r.cap_log2 ? (1u << r.cap_log2) : 0u, r.stamp});
         const float res = ivox.resolution, inv = ivox.inv_resolution;
         const size_t capacity = ivox.capacity;
         ivox.rebuild_from_image(vox, pts.data(), size_t(st.n_points), st.next_id);
@@ -211,7 +203,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         d_px.reserve(n); d_bt2.reserve(size_t(nb)); d_fbit.reserve(n);
         const IvoxUpdBatch b{d_code.p, d_pw.p, int(n), d_lx.p, d_bt.p, d_seq_src.p, d_seq_cell.p, d_jj.p, d_px.p, d_bt2.p, d_fbit.p, d_tlist.p};
         const IvoxUpdArrays a{image.d_cells.p, image.d_pts.p, image.d_cap_log2.p, image.d_stamp.p, image.d_pend.p, image.d_rank_mm.p,
-                              image.win_o[0], image.win_o[1], image.win_o[2], image.win_n[0], image.win_n[1], image.win_n[2], ivox.inv_resolution};
+                              image.d_dir.p, image.dir_mask, unsigned(image.n_bricks_cap), image.d_brick_key.p, ivox.inv_resolution};
         upd_seq = (upd_seq + 1u) & 0x7fffffffu;
         if (upd_seq == 0u) upd_seq = 1u;
         const dim3 g{unsigned(nb), 1u, 1u}, t{unsigned(kUpdBlock), 1u, 1u};
@@ -224,7 +216,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         const bool may_evict = device_evict && dev_n_alive + n >= ivox.capacity && dev_n_alive > 0;
         unsigned n_list = 0;
         if (may_evict) {
-            const unsigned ncell = unsigned(image.n_cells_alloc), nbe = (ncell + kEvBlock - 1) / kEvBlock;
+            const unsigned ncell = unsigned(dev_n_bricks * kBrickStride), nbe = (ncell + kEvBlock - 1) / kEvBlock;  // (bricks this batch creates hold no candidate)
             n_list = unsigned(dev_n_alive);
             d_ev_bt.reserve(size_t(2) * nbe);
             ev_sort.prepare(n_list);
@@ -250,7 +242,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         hipLaunchKernelGGL(ivox_upd_regions, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_points, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_finish, dim3(unsigned((n + kUpdBlock / 64 - 1) / (kUpdBlock / 64))), t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
-        hipLaunchKernelGGL(ivox_upd_commit, dim3(1), dim3(64), 0, stream, d_upd_state.p, upd_mb_dev, upd_seq);
+        hipLaunchKernelGGL(ivox_upd_commit, dim3(1), dim3(64), 0, stream, d_upd_state.p, upd_mb_dev, upd_seq, unsigned(image.n_bricks_cap));
         FLS_HIP(hipGetLastError());
         // the verdict of the batch (a few words in host-mapped memory; no copy, no stream synchronisation)
         for (unsigned long long spin = 1;; ++spin) {
@@ -264,9 +256,10 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             __builtin_ia32_pause();
 #endif
         }
+        dev_n_bricks = std::min<size_t>(upd_mb_host->n_bricks, image.n_bricks_cap);  // (bricks are created whatever the verdict)
         if (upd_mb_host->status != kUpdOk) {
             if (upd_mb_host->status & kUpdEvictConflict) ++n_refused_conflict;
-            if (upd_mb_host->status & kUpdArrayFull) ++n_refused_full;
+            if (upd_mb_host->status & kUpdArrayFull) { ++n_refused_full; rebuild_after_replay = true; }  // point array or brick pool: re-flatten with more room
             if (upd_mb_host->status & kUpdOutside) ++n_refused_outside;
             return false;
         }
@@ -291,7 +284,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     // ids form -> rows form for every point (the ids are slots of the image as it is NOW: call before anything moves slots)
     void ensure_nn_rows() {
         if (nn_rows_current || nn_n == 0) { nn_rows_current = true; return; }
-        const GridImage& im = borrowed ? *borrowed : image;
+        const IvoxImage& im = borrowed ? *borrowed : image;
         hipLaunchKernelGGL(ivox_nn_materialize_kernel, dim3(unsigned((nn_n + 255) / 256)), dim3(256), 0, stream, (const unsigned*)d_nn_ids.p, d_nn_cnt.p, int(nn_n),
                            (const float4*)im.d_pts.p, unsigned(im.d_pts.cap), d_nn.p);  // (slot bound = the allocation: in device mode the host's `used` is stale)
         FLS_HIP(hipGetLastError());
@@ -446,7 +439,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     // i.e. the kernel's execution time as a kernel trace sees it -- a hipEventRecord bracket also times the dispatch of
     // the kernel between its two marker packets (about 3 us more on an 18 us kernel)
     template <int G>
-    void launch_knn(const size_t n, const int first, const Pose16& T0, const DevGrid& g, const DenseWindow& win, hipEvent_t e0 = nullptr,
+    void launch_knn(const size_t n, const int first, const Pose16& T0, const DevGrid& g, const BrickDir& win, hipEvent_t e0 = nullptr,
                     hipEvent_t e1 = nullptr) {
         unsigned* const ids_arg = nn_ids_mode ? d_nn_ids.p : nullptr;
         const size_t nblk = (n * G + 255) / 256, gran = size_t(8) * size_t(xcd_chunk);
@@ -487,7 +480,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             return FLS_NOT_CONVERGED;
         }
         if (!borrowed) refresh_image();
-        const GridImage& im = borrowed ? *borrowed : image;
+        const IvoxImage& im = borrowed ? *borrowed : image;
         // nearest_points_.resize(n) semantics (:257): grown tail is empty, shrink forgets
         d_nn.reserve(n * 5, /*keep=*/true, stream);
         d_nn_cnt.reserve(n, /*keep=*/true, stream);
@@ -504,7 +497,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         d_partials_b.reserve(size_t(nwg) * kPartialStride);
         const int iters = int(p.max_iterations);
         const DevGrid g = im.dev();
-        const DenseWindow win = use_dense ? im.window() : DenseWindow{nullptr, 0, 0, 0, 0, 0, 0};
+        const BrickDir win = use_dense ? im.bricks() : BrickDir{nullptr, 0u, nullptr, 0u};
         Pose16 T0;
         std::memcpy(T0.m, T, sizeof(T0.m));
         const unsigned word = run_mailbox_loop(iters, n, [&](int it, int first) {

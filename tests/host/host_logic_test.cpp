@@ -1,9 +1,10 @@
 // Host-logic checks of the PRODUCT's C++ bookkeeping that need no GPU (compiled with hipcc, run on the CPU):
 //   * HostIvox insert / LRU-evict semantics vs a straightforward list+map model and vs the oracle's iVox
 //   * voxel_grid (PCL VoxelGrid semantics) vs the oracle's
-//   * GridImage::collect_incremental invariants (disjoint slot regions, unique cell records, eviction records)
+//   * IvoxImage::collect_incremental invariants (disjoint slot regions, unique cell records, eviction records, halo mirrors of the brick image)
 // No HIP runtime call is made: only host members are touched.
 #include "../../funny_lidar_slam_amd/csrc/host_maps.hpp"
+#include "../../funny_lidar_slam_amd/csrc/ivox_image.hpp"
 #include "../../funny_lidar_slam_amd/csrc/host_math.hpp"
 #include "../../funny_lidar_slam_amd/csrc/replicas.hpp"
 #include "../../oracle/flo_api.h"
@@ -203,45 +204,77 @@ int main() {
         Hn[0] = 1.0; gn[2] = std::nan("");
         CHECK(!hm::ldlt_solve6(Hn, gn, xn));
     }
-    // ---- 4. incremental image bookkeeping --------------------------------------------------------------
+    // ---- 4. brick-image bookkeeping on the host (ivox_image.hpp): journal records, halo mirrors, brick creation ---------------
     {
         HostIvox iv;
         iv.capacity = 400;
-        GridImage img;
+        IvoxImage img;
         img.want_hash = false;
-        img.have_window = true;
-        img.win_o[0] = img.win_o[1] = img.win_o[2] = -64;
-        img.win_n[0] = img.win_n[1] = img.win_n[2] = 128;
+        img.have_bricks = true;
+        img.n_bricks_cap = 64;  // small pool: the test also reaches "pool full -> rebuild"
+        img.dir.assign(256, HashEntry{kEmptyKey, kBrickPending, 0u});
+        img.dir_mask = 255;
         img.d_pts.cap = size_t(1) << 22;  // pretend the device array is large (never dereferenced here)
-        std::set<size_t> live_cells;
-        for (int round = 0; round < 8; ++round) {
+        std::map<unsigned long long, std::pair<unsigned, unsigned>> cells;  // the image's cell array as a map {cell -> begin, count}
+        bool pool_filled = false;
+        for (int round = 0; round < 8 && !pool_filled; ++round) {
             const auto cloud = random_cloud(rng, 1500, 4.0f + 2.0f * round);
             CHECK(iv.add_points(cloud.data(), cloud.size()) == FLS_OK);
-            CHECK(img.collect_incremental(iv));
+            if (!img.collect_incremental(iv)) { pool_filled = true; CHECK(img.n_bricks() == img.n_bricks_cap); break; }
             CHECK(iv.touched.empty() && iv.evicted_keys.empty());
             std::set<unsigned long long> seen_cells;
             for (const auto& c : img.cell_upd) CHECK(seen_cells.insert(c.idx).second);  // unique per cell
             std::set<unsigned> seen_slots;
             for (const auto& u : img.pt_upd) CHECK(seen_slots.insert(u.slot).second);    // unique per slot
-            for (const auto& c : img.cell_upd) { if (c.count) live_cells.insert(c.idx); else live_cells.erase(c.idx); }
+            for (const auto& c : img.cell_upd) { if (c.count) cells[c.idx] = {c.begin, c.count}; else cells.erase(c.idx); }
             // regions of alive voxels are disjoint and hold exactly the voxel's points
             std::vector<std::pair<unsigned, unsigned>> regions;
-            size_t alive = 0;
+            size_t alive = 0, expected_cells = 0;
             for (const auto& v : iv.pool) {
                 if (!v.alive) continue;
                 ++alive;
                 CHECK(v.img_cnt == v.pts.size() && v.img_cnt <= v.img_cap && v.img_begin + v.img_cap <= img.used);
                 regions.push_back({v.img_begin, v.img_begin + v.img_cap});
+                // the brick invariant: the voxel's primary cell AND every halo copy hold {begin, count}; all those bricks exist
+                int x, y, z;
+                unpack_key(v.key, x, y, z);
+                size_t idx;
+                CHECK(img.cell_index(x, y, z, idx));
+                CHECK(cells.count(idx) && cells[idx] == std::make_pair(v.img_begin, v.img_cnt));
+                ++expected_cells;
+                const int bx = x >> kBrickLog, by = y >> kBrickLog, bz = z >> kBrickLog, lx = x & 7, ly = y & 7, lz = z & 7;
+                bool ok = true;
+                brick_for_each_mirror(lx, ly, lz, [&](int dx, int dy, int dz) {
+                    const int nb = img.find_brick(bx + dx, by + dy, bz + dz);
+                    if (nb < 0) { ok = false; return; }
+                    const unsigned long long m = (unsigned long long)nb * kBrickStride + brick_slab_index(lx + 1 - 8 * dx, ly + 1 - 8 * dy, lz + 1 - 8 * dz);
+                    if (!cells.count(m) || cells[m] != std::make_pair(v.img_begin, v.img_cnt)) ok = false;
+                    ++expected_cells;
+                });
+                CHECK(ok);
             }
             std::sort(regions.begin(), regions.end());
             for (size_t i = 1; i < regions.size(); ++i) CHECK(regions[i - 1].second <= regions[i].first);
-            CHECK(live_cells.size() == alive);  // every alive voxel has a live cell, every evicted one was cleared
+            CHECK(cells.size() == expected_cells);  // nothing but the alive voxels' cells and mirrors is set: every evicted voxel was cleared everywhere
+            // the host directory answers like the device's: every brick reachable by linear probing from its hash
+            for (size_t b2 = 0; b2 < img.n_bricks(); ++b2) {
+                unsigned h = IvoxImage::brick_hash_of_key(img.brick_keys[b2]) & img.dir_mask;
+                while (img.dir[h].key != img.brick_keys[b2]) { CHECK(img.dir[h].key != kEmptyKey); h = (h + 1) & img.dir_mask; }
+                CHECK(img.dir[h].begin == b2);
+            }
         }
-        CHECK(GridImage::cap_for(0) == 4 && GridImage::cap_for(5) == 8 && GridImage::cap_for(8) == 8 && GridImage::cap_for(9) == 16);
-        // a point outside the window forces a full rebuild
-        PtI out{200.f, 0.f, 0.f, 0.f};
-        CHECK(iv.add_points(&out, 1) == FLS_OK);
-        CHECK(!img.collect_incremental(iv));
+        CHECK(pool_filled);  // 64 bricks cannot hold the later rounds: collect_incremental asked for a rebuild
+        CHECK(IvoxImage::cap_for(0) == 4 && IvoxImage::cap_for(5) == 8 && IvoxImage::cap_for(8) == 8 && IvoxImage::cap_for(9) == 16);
+        // slab geometry: interior cells are exactly the 8^3 block at stored coordinates 1..8; mirrors of a corner voxel are its 3 faces + 3 edges
+        int n_int = 0, sx, sy, sz;
+        for (unsigned l = 0; l < kBrickStride; ++l) n_int += brick_slab_interior(l, sx, sy, sz) ? 1 : 0;
+        CHECK(n_int == 512);
+        int n_m = 0;
+        bool shape_ok = true;
+        brick_for_each_mirror(0, 7, 0, [&](int dx, int dy, int dz) { ++n_m; shape_ok = shape_ok && dx <= 0 && dy >= 0 && dz <= 0 && (dx || dy || dz) && !(dx && dy && dz); });
+        CHECK(n_m == 6 && shape_ok);
+        n_m = 0; brick_for_each_mirror(3, 7, 4, [&](int dx, int dy, int dz) { ++n_m; shape_ok = shape_ok && dx == 0 && dy == 1 && dz == 0; }); CHECK(n_m == 1 && shape_ok);
+        n_m = 0; brick_for_each_mirror(3, 5, 4, [&](int, int, int) { ++n_m; }); CHECK(n_m == 0);
     }
     // ---- the job partition of the native replica set (csrc/replicas.hpp) = funny_lidar_slam_amd/batch.py::partition: contiguous blocks,
     // sizes differ by at most one, the first n % world ranks take the extra job, every job exactly once
