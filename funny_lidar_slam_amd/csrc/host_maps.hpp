@@ -464,6 +464,7 @@ struct CellGridImage : GridImage {
     DevBuf<float4> d_by_id;  // optional: the cloud in its own order (see CellGridDev::by_id)
     fls_status build(const std::vector<PtI>& cloud, float cell_size, hipStream_t s, int n_rings = 1, bool with_by_id = false) {
         rings = n_rings;
+        used = 0;  // (a grid the device builder filled earlier left its own point count here: dev() must report THIS build's)
         if (with_by_id && !cloud.empty()) {
             std::vector<Pt4> ordered(cloud.size());
             for (size_t i = 0; i < cloud.size(); ++i) ordered[i] = Pt4{cloud[i].x, cloud[i].y, cloud[i].z, int(i)};
