@@ -202,15 +202,16 @@ ivox_upd_scan1(const IvoxUpdBatch b, const int nblocks, IvoxUpdState* __restrict
     if (threadIdx.x == 0) { st->n1 = tot[0]; st->n2 = tot[1]; st->status = kUpdOk; st->apply = 0u; }
 }
 
-// rank of every inserted point, its window cell, the sequence arrays, and the per-cell scratch (count, first rank)
-__global__ void __launch_bounds__(kUpdBlock)
-ivox_upd_seq(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st) {
-    const int i = blockIdx.x * kUpdBlock + threadIdx.x;
-    if (i >= b.n) return;
-    const unsigned c = b.code[i];
-    if (c == 0u) return;
-    const uint2 l = b.lx[i], base = b.bt[blockIdx.x];
-    const unsigned r = c == 1u ? base.x + l.x : st->n1 + base.y + l.y;
+// loads of words other threads of the SAME launch may have changed with atomics (the fused one-workgroup form below runs all phases
+// in one launch: an L2 atomic does not update a line the CU's L1 already holds)
+__device__ __forceinline__ unsigned upd_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint2 upd_ld_cell(const uint2* p) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((unsigned)(v & 0xffffffffull), (unsigned)(v >> 32));
+}
+
+// sequence rank r = source point i: its cell (bricks created on demand), the sequence arrays, the per-cell scratch (count, first rank)
+__device__ __forceinline__ void upd_seq_rank(const IvoxUpdBatch& b, const IvoxUpdArrays& a, IvoxUpdState* __restrict__ st, const unsigned r, const unsigned i) {
     const float4 p = b.pw[i];
     // IVoxMap::Pos2Grid (ivox_map.cpp:145-147): round half away from zero of the float product
     const float fx = roundf(p.x * a.inv_res), fy = roundf(p.y * a.inv_res), fz = roundf(p.z * a.inv_res);
@@ -230,11 +231,88 @@ ivox_upd_seq(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restri
     } else {
         atomicOr(&st->status, kUpdOutside);  // (a key beyond +-2^20: the host path reports FLS_ERR_RANGE)
     }
-    b.seq_src[r] = (unsigned)i;
+    b.seq_src[r] = i;
     b.seq_cell[r] = cell;
     if (cell == kUpdInvalidCell) { b.jj[r] = 0u; return; }  // (status already says why: kUpdOutside or kUpdArrayFull)
     b.jj[r] = atomicAdd(&a.pend[cell], 1u);
     atomicMin(&a.rank_mm[cell], r);
+}
+// what the batch does to the voxel whose first point has rank r: {new region slots, creation, touched, capacity left behind}
+__device__ __forceinline__ bool upd_plan_rank(const IvoxUpdBatch& b, const IvoxUpdArrays& a, const unsigned r, unsigned (&v)[4]) {
+    v[0] = v[1] = v[2] = v[3] = 0u;
+    const unsigned cell = b.seq_cell[r];
+    if (cell == kUpdInvalidCell || upd_ld(&a.rank_mm[cell]) != r) return false;
+    const uint2 old = upd_ld_cell(&a.cells[cell]);
+    const unsigned total = old.y + upd_ld(&a.pend[cell]);
+    const unsigned cl = a.cap_log2[cell];
+    const unsigned cap = cl ? (1u << cl) : 0u;
+    const bool grow = total > cap;
+    v[0] = grow ? upd_cap_for(total) : 0u;
+    v[1] = old.y == 0u ? 1u : 0u;
+    v[2] = 1u;
+    v[3] = grow ? cap : 0u;
+    return true;
+}
+// the all-or-nothing verdict of a batch from its totals {alloc, creations, touched, relocated} (one thread)
+__device__ __forceinline__ void upd_decide_totals(IvoxUpdState* __restrict__ st, const unsigned (&tot)[4], const unsigned evict_ready, const unsigned n_list) {
+    st->alloc = tot[0]; st->creations = tot[1]; st->touched = tot[2]; st->relocated_garbage = tot[3];
+    unsigned status = __hip_atomic_load(&st->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // all-or-nothing: room in the point array.  LRU evictions inside the batch (ivox_map.cpp:133-136 evicts the list's back when
+    // the count REACHES the capacity after a creation): with n alive voxels and k creations the batch evicts
+    // E = max(0, n + k - (capacity - 1)) voxels; they are the E least recently touched ones as long as none of those is touched by
+    // this batch (ivox_evict_check) -- the host queues the selection (alive cells sorted by stamp) whenever the batch could get there.
+    if (st->used + (unsigned long long)tot[0] > st->pts_capacity) status |= kUpdArrayFull;
+    const unsigned long long total = (unsigned long long)st->n_alive + tot[1];
+    unsigned e = 0u;
+    if (total >= (unsigned long long)st->lru_capacity) {
+        e = (unsigned)(total - (unsigned long long)st->lru_capacity + 1ull);
+        if (!evict_ready || e > n_list) status |= kUpdNeedHost;
+    }
+    st->evict_ready = evict_ready;  // (round 3: a one-thread launch of their own used to set these two words)
+    st->n_list = n_list;
+    st->evict = e;
+    st->evicted_points = 0ull;
+    st->evicted_slots = 0ull;
+    st->status = status;
+    if (!evict_ready) st->apply = status == kUpdOk ? 1u : 0u;  // no eviction selection follows: this is the verdict (ivox_upd_decide otherwise)
+}
+// the slot region of the voxel first touched by rank r: relocated when it outgrows its capacity; cell + halo copies; touched list
+__device__ __forceinline__ void upd_region_rank(const IvoxUpdBatch& b, const IvoxUpdArrays& a, const IvoxUpdState* __restrict__ st, const unsigned r,
+                                                const unsigned alloc_before, const unsigned touched_before) {
+    const unsigned cell = b.seq_cell[r];
+    const uint2 old = upd_ld_cell(&a.cells[cell]);
+    const unsigned total = old.y + upd_ld(&a.pend[cell]);
+    const unsigned cl = a.cap_log2[cell];
+    const unsigned cap = cl ? (1u << cl) : 0u;
+    unsigned begin = old.x;
+    if (total > cap) {  // grown past its region (or new): a fresh region at the end of the array, in first-touch order
+        const unsigned ncap = upd_cap_for(total);
+        begin = (unsigned)st->used + alloc_before;
+        for (unsigned k = 0; k < old.y; ++k) a.pts[begin + k] = a.pts[old.x + k];
+        for (unsigned k = total; k < ncap; ++k) a.pts[begin + k] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // slack
+        a.cap_log2[cell] = (unsigned char)upd_log2(ncap);
+    }
+    a.cells[cell] = make_uint2(begin, total);
+    brick_write_mirrors(a, cell, make_uint2(begin, total));
+    b.tlist[touched_before] = cell;
+}
+__device__ __forceinline__ void upd_point_rank(const IvoxUpdBatch& b, const IvoxUpdArrays& a, const IvoxUpdState* __restrict__ st, const unsigned r) {
+    const unsigned cell = b.seq_cell[r];
+    const uint2 e = upd_ld_cell(&a.cells[cell]);
+    const float4 p = b.pw[b.seq_src[r]];
+    a.pts[e.x + (e.y - upd_ld(&a.pend[cell])) + b.jj[r]] = make_float4(p.x, p.y, p.z, __int_as_float(st->next_id + (int)r));
+}
+
+// rank of every inserted point, its window cell, the sequence arrays, and the per-cell scratch (count, first rank)
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_seq(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st) {
+    const int i = blockIdx.x * kUpdBlock + threadIdx.x;
+    if (i >= b.n) return;
+    const unsigned c = b.code[i];
+    if (c == 0u) return;
+    const uint2 l = b.lx[i], base = b.bt[blockIdx.x];
+    const unsigned r = c == 1u ? base.x + l.x : st->n1 + base.y + l.y;
+    upd_seq_rank(b, a, st, r, (unsigned)i);
 }
 
 // first-toucher flags and, per touched voxel, what the batch does to it; block-local scans of the four counters
@@ -244,23 +322,7 @@ ivox_upd_plan(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState* _
     const unsigned A = st->n1 + st->n2;
     const unsigned r = blockIdx.x * kUpdBlock + threadIdx.x;
     unsigned v[4] = {0u, 0u, 0u, 0u}, tot[4];
-    bool first = false;
-    if (r < A) {
-        const unsigned cell = b.seq_cell[r];
-        if (cell != kUpdInvalidCell && a.rank_mm[cell] == r) {
-            first = true;
-            const uint2 old = a.cells[cell];
-            const unsigned total = old.y + a.pend[cell];
-            const unsigned cl = a.cap_log2[cell];
-            const unsigned cap = cl ? (1u << cl) : 0u;
-            const bool grow = total > cap;
-            v[0] = grow ? upd_cap_for(total) : 0u;
-            v[1] = old.y == 0u ? 1u : 0u;
-            v[2] = 1u;
-            v[3] = grow ? cap : 0u;
-        }
-        b.fbit[r] = first ? 1 : 0;
-    }
+    if (r < A) b.fbit[r] = upd_plan_rank(b, a, r, v) ? 1 : 0;
     block_excl_scan<4>(v, tot, wsum);
     if (r < A) b.px[r] = make_uint4(v[0], v[1], v[2], v[3]);
     if (threadIdx.x == 0) b.bt2[blockIdx.x] = make_uint4(tot[0], tot[1], tot[2], tot[3]);
@@ -276,28 +338,7 @@ ivox_upd_scan2(const IvoxUpdBatch b, IvoxUpdState* __restrict__ st, const unsign
     unsigned v[4] = {t.x, t.y, t.z, t.w}, tot[4];
     block_excl_scan<4>(v, tot, wsum);
     if ((int)threadIdx.x < nblocks) b.bt2[threadIdx.x] = make_uint4(v[0], v[1], v[2], v[3]);
-    if (threadIdx.x == 0) {
-        st->alloc = tot[0]; st->creations = tot[1]; st->touched = tot[2]; st->relocated_garbage = tot[3];
-        unsigned status = st->status;
-        // all-or-nothing: room in the point array.  LRU evictions inside the batch (ivox_map.cpp:133-136 evicts the list's back when
-        // the count REACHES the capacity after a creation): with n alive voxels and k creations the batch evicts
-        // E = max(0, n + k - (capacity - 1)) voxels; they are the E least recently touched ones as long as none of those is touched by
-        // this batch (ivox_evict_check) -- the host queues the selection (alive cells sorted by stamp) whenever the batch could get there.
-        if (st->used + (unsigned long long)tot[0] > st->pts_capacity) status |= kUpdArrayFull;
-        const unsigned long long total = (unsigned long long)st->n_alive + tot[1];
-        unsigned e = 0u;
-        if (total >= (unsigned long long)st->lru_capacity) {
-            e = (unsigned)(total - (unsigned long long)st->lru_capacity + 1ull);
-            if (!evict_ready || e > n_list) status |= kUpdNeedHost;
-        }
-        st->evict_ready = evict_ready;  // (round 3: a one-thread launch of their own used to set these two words)
-        st->n_list = n_list;
-        st->evict = e;
-        st->evicted_points = 0ull;
-        st->evicted_slots = 0ull;
-        st->status = status;
-        if (!evict_ready) st->apply = status == kUpdOk ? 1u : 0u;  // no eviction selection follows: this is the verdict (ivox_upd_decide otherwise)
-    }
+    if (threadIdx.x == 0) upd_decide_totals(st, tot, evict_ready, n_list);
 }
 
 // ---- eviction selection: the alive cells of the image as a list sorted by LRU stamp ------------------------------------------
@@ -431,23 +472,8 @@ ivox_upd_regions(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState
     const unsigned A = st->n1 + st->n2;
     const unsigned r = blockIdx.x * kUpdBlock + threadIdx.x;
     if (r >= A || !b.fbit[r]) return;
-    const unsigned cell = b.seq_cell[r];
     const uint4 loc = b.px[r], base = b.bt2[blockIdx.x];
-    const uint2 old = a.cells[cell];
-    const unsigned total = old.y + a.pend[cell];
-    const unsigned cl = a.cap_log2[cell];
-    const unsigned cap = cl ? (1u << cl) : 0u;
-    unsigned begin = old.x;
-    if (total > cap) {  // grown past its region (or new): a fresh region at the end of the array, in first-touch order
-        const unsigned ncap = upd_cap_for(total);
-        begin = (unsigned)st->used + base.x + loc.x;
-        for (unsigned k = 0; k < old.y; ++k) a.pts[begin + k] = a.pts[old.x + k];
-        for (unsigned k = total; k < ncap; ++k) a.pts[begin + k] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // slack
-        a.cap_log2[cell] = (unsigned char)upd_log2(ncap);
-    }
-    a.cells[cell] = make_uint2(begin, total);
-    brick_write_mirrors(a, cell, make_uint2(begin, total));
-    b.tlist[base.z + loc.z] = cell;
+    upd_region_rank(b, a, st, r, base.x + loc.x, base.z + loc.z);
 }
 
 __global__ void __launch_bounds__(kUpdBlock)
@@ -456,10 +482,7 @@ ivox_upd_points(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState*
     const unsigned A = st->n1 + st->n2;
     const unsigned r = blockIdx.x * kUpdBlock + threadIdx.x;
     if (r >= A) return;
-    const unsigned cell = b.seq_cell[r];
-    const uint2 e = a.cells[cell];
-    const float4 p = b.pw[b.seq_src[r]];
-    a.pts[e.x + (e.y - a.pend[cell]) + b.jj[r]] = make_float4(p.x, p.y, p.z, __int_as_float(st->next_id + (int)r));
+    upd_point_rank(b, a, st, r);
 }
 
 // per touched voxel: its new points into insertion (id) order, LRU stamp, scratch reset.  ONE WAVE per voxel: the new points are
@@ -467,31 +490,30 @@ ivox_upd_points(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState*
 // writes them back in place.  (A voxel next to the sensor receives hundreds of points from one scan: the first version, one thread
 // per voxel with an insertion sort in global memory, took up to 1.2 ms.)
 constexpr int kUpdFinishMaxK = 1024;  // new points of one voxel staged per wave; more than that: serial fallback by lane 0
-__global__ void __launch_bounds__(kUpdBlock)
-ivox_upd_finish(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState* __restrict__ st) {
-    if (!st->apply) return;
-    __shared__ float4 s_pts[kUpdBlock / 64][kUpdFinishMaxK];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const unsigned t = blockIdx.x * (kUpdBlock / 64) + w;  // one wave per touched voxel
-    if (t >= st->touched) return;
+// one wave: the new points of touched voxel number t into id order (s_row: MAXK float4 of LDS owned by this wave), stamp, scratch reset
+template <int MAXK>
+__device__ __forceinline__ void upd_finish_voxel(const IvoxUpdBatch& b, const IvoxUpdArrays& a, const IvoxUpdState* __restrict__ st, const unsigned t,
+                                                 float4* __restrict__ s_row, const int lane) {
     const unsigned cell = b.tlist[t];
-    const uint2 e = a.cells[cell];
-    const unsigned k = a.pend[cell];
+    const uint2 e = upd_ld_cell(&a.cells[cell]);
+    const unsigned k = upd_ld(&a.pend[cell]);
     float4* const q = a.pts + e.x + (e.y - k);
-    if (k > 1u && k <= (unsigned)kUpdFinishMaxK) {
-        for (unsigned i = lane; i < k; i += 64) s_pts[w][i] = q[i];
+    if (k > 1u && k <= (unsigned)MAXK) {
+        for (unsigned i = lane; i < k; i += 64) s_row[i] = q[i];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (unsigned i = lane; i < k; i += 64) {
-            const float4 x = s_pts[w][i];
+            const float4 x = s_row[i];
             const int id = __float_as_int(x.w);
             unsigned pos = 0;
-            for (unsigned j = 0; j < k; ++j) pos += __float_as_int(s_pts[w][j].w) < id ? 1u : 0u;  // ids are distinct
+            for (unsigned j = 0; j < k; ++j) pos += __float_as_int(s_row[j].w) < id ? 1u : 0u;  // ids are distinct
             q[pos] = x;
         }
-    } else if (k > (unsigned)kUpdFinishMaxK && lane == 0) {
-        for (unsigned i = 1; i < k; ++i) {  // (never seen: > 1024 points of one scan in one 0.5 m voxel)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the row is reused by the wave's next voxel in the fused form)
+    } else if (k > (unsigned)MAXK && lane == 0) {
+        for (unsigned i = 1; i < k; ++i) {  // (rare: more new points in one 0.5 m voxel than the wave stages)
             const float4 x = q[i];
             const int id = __float_as_int(x.w);
             unsigned j = i;
@@ -500,14 +522,22 @@ ivox_upd_finish(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState*
         }
     }
     if (lane == 0) {
-        a.stamp[cell] = st->stamp_base + a.rank_mm[cell] + 1ull;
+        a.stamp[cell] = st->stamp_base + upd_ld(&a.rank_mm[cell]) + 1ull;
         a.pend[cell] = 0u;
         a.rank_mm[cell] = kUpdNoRank;
     }
 }
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_finish(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState* __restrict__ st) {
+    if (!st->apply) return;
+    __shared__ float4 s_pts[kUpdBlock / 64][kUpdFinishMaxK];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned t = blockIdx.x * (kUpdBlock / 64) + w;  // one wave per touched voxel
+    if (t >= st->touched) return;
+    upd_finish_voxel<kUpdFinishMaxK>(b, a, st, t, &s_pts[w][0], lane);
+}
 
-__global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* __restrict__ mb, const unsigned seq, const unsigned n_bricks_cap) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* __restrict__ mb, const unsigned seq, const unsigned n_bricks_cap) {
     const unsigned A = st->n1 + st->n2;
     if (st->n_bricks > n_bricks_cap) st->n_bricks = n_bricks_cap;  // (a refused batch overshot the pool)
     if (st->apply) {
@@ -532,6 +562,94 @@ __global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* _
     __hip_atomic_store(&mb->evicted, st->apply ? st->evict : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* __restrict__ mb, const unsigned seq, const unsigned n_bricks_cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    upd_commit(st, mb, seq, n_bricks_cap);
+}
+
+// ---- the whole batch in ONE launch of ONE workgroup (small batches: the 0.5 m-filtered planar cloud the pipeline feeds, ~10 k points) ----
+// The ten launches above are 2-5 us of work each with ~4 us of dispatch latency between dependent launches: ~90 us for microseconds of
+// work.  Up to kFusedMaxN source points the same phases run inside one 1024-thread workgroup, separated by
+// __syncthreads() instead of kernel boundaries: the two block scans happen once (16 consecutive codes per thread; a contiguous slice of
+// the ranks per thread), the per-rank phases stride over the ranks.  Same device functions, same arithmetic, same result -- ranks,
+// regions in first-touch order, ids, stamps.  Batches that may evict (the selection sorts the alive cells: a grid-wide job) and larger
+// batches keep the multi-launch form.
+constexpr int kFusedThreads = 1024, kFusedItems = 16, kFusedMaxN = kFusedThreads * kFusedItems, kFusedFinishK = 256;
+__global__ void __launch_bounds__(kFusedThreads)
+ivox_upd_fused_kernel(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st, IvoxUpdMailbox* __restrict__ mb, const unsigned seq) {
+    __shared__ unsigned wsum2[kFusedThreads / 64][2];
+    __shared__ unsigned wsum4[kFusedThreads / 64][4];
+    __shared__ uint4 s_base[kFusedThreads];
+    __shared__ float4 s_pts[kFusedThreads / 64][kFusedFinishK];
+    __shared__ unsigned s_apply;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) { st->status = kUpdOk; st->apply = 0u; }
+    // ---- count + rank: 16 consecutive decision codes per thread ----
+    unsigned char cd[kFusedItems];
+    unsigned v2[2] = {0u, 0u}, tot2[2];
+#pragma unroll
+    for (int k = 0; k < kFusedItems; ++k) {
+        const int i = t * kFusedItems + k;
+        cd[k] = i < b.n ? b.code[i] : (unsigned char)0;
+        v2[0] += cd[k] == 1 ? 1u : 0u;
+        v2[1] += cd[k] == 2 ? 1u : 0u;
+    }
+    block_excl_scan<2>(v2, tot2, wsum2);  // (its barriers also order the status reset above before any atomicOr below)
+    const unsigned n1 = tot2[0], A = tot2[0] + tot2[1];
+    {
+        unsigned r1 = v2[0], r2 = n1 + v2[1];
+#pragma unroll
+        for (int k = 0; k < kFusedItems; ++k) {
+            const unsigned i = (unsigned)(t * kFusedItems + k);
+            if (cd[k] == 1) b.seq_src[r1++] = i;
+            else if (cd[k] == 2) b.seq_src[r2++] = i;
+        }
+    }
+    if (t == 0) { st->n1 = n1; st->n2 = tot2[1]; }
+    __syncthreads();
+    // ---- seq: cell of every rank (bricks on demand), arrival number, first rank per cell ----
+    for (unsigned r = t; r < A; r += kFusedThreads) upd_seq_rank(b, a, st, r, b.seq_src[r]);
+    __syncthreads();
+    // ---- plan: a contiguous slice of the ranks per thread; exclusive {alloc, creations, touched, relocated} of the first-touchers ----
+    const unsigned per = (A + kFusedThreads - 1) / kFusedThreads, r_lo = min(A, (unsigned)t * per), r_hi = min(A, r_lo + per);
+    unsigned v4[4] = {0u, 0u, 0u, 0u}, tot4[4];
+    for (unsigned r = r_lo; r < r_hi; ++r) {
+        unsigned inc[4];
+        const bool first = upd_plan_rank(b, a, r, inc);
+        b.fbit[r] = first ? 1 : 0;
+        b.px[r] = make_uint4(v4[0], v4[1], v4[2], v4[3]);  // exclusive inside the slice
+        v4[0] += inc[0]; v4[1] += inc[1]; v4[2] += inc[2]; v4[3] += inc[3];
+    }
+    block_excl_scan<4>(v4, tot4, wsum4);
+    s_base[t] = make_uint4(v4[0], v4[1], v4[2], v4[3]);
+    if (t == 0) {
+        upd_decide_totals(st, tot4, 0u, 0u);  // (no eviction selection in this form: a batch that reaches the capacity is sent to the multi-launch form by the host)
+        s_apply = st->apply;
+    }
+    __syncthreads();
+    const bool apply = s_apply != 0u;
+    // ---- last: first rank -> last rank per cell, or scratch reset when the batch is refused ----
+    for (unsigned r = t; r < A; r += kFusedThreads) {
+        const unsigned cell = b.seq_cell[r];
+        if (cell == kUpdInvalidCell) continue;
+        if (apply) atomicMax(&a.rank_mm[cell], r);
+        else { a.pend[cell] = 0u; a.rank_mm[cell] = kUpdNoRank; }
+    }
+    if (apply) {
+        __syncthreads();
+        // ---- regions (slice order = first-touch order), points, per-voxel id order ----
+        const uint4 base = s_base[t];
+        for (unsigned r = r_lo; r < r_hi; ++r)
+            if (b.fbit[r]) { const uint4 loc = b.px[r]; upd_region_rank(b, a, st, r, base.x + loc.x, base.z + loc.z); }
+        __syncthreads();
+        for (unsigned r = t; r < A; r += kFusedThreads) upd_point_rank(b, a, st, r);
+        __syncthreads();
+        const unsigned touched = tot4[2];
+        for (unsigned tv = w; tv < touched; tv += kFusedThreads / 64) upd_finish_voxel<kFusedFinishK>(b, a, st, tv, &s_pts[w][0], lane);
+    }
+    __syncthreads();
+    if (t == 0) upd_commit(st, mb, seq, a.n_bricks_cap);
 }
 
 // ---- image <-> host mirror ---------------------------------------------------------------------------------------------------------

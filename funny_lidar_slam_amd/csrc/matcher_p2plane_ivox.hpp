@@ -36,6 +36,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     bool allow_device_map = true;  // FLS_IVOX_DEVICE_UPDATE=0: always the host path (A/B)
     size_t device_margin = 4096;   // voxels of head-room below the LRU capacity required to (re-)enter device mode (FLS_IVOX_DEVICE_MARGIN: test hook)
     size_t n_device_updates = 0, n_host_fallbacks = 0, n_device_evictions = 0, n_refused_conflict = 0, n_refused_full = 0, n_refused_outside = 0;
+    bool fused_update = true;      // FLS_IVOX_FUSED_UPDATE=0: always the multi-launch form of the device AddPoints (A/B)
+    size_t n_fused_updates = 0;
     bool device_evict = true;      // FLS_IVOX_DEVICE_EVICT=0: a batch that reaches the LRU capacity is refused (round-2 behaviour, with the margin rule)
     DevicePairSort ev_sort;
     DevBuf<unsigned> d_ev_bt, d_crank, d_evict_list;
@@ -104,6 +106,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (const char* e = std::getenv("FLS_IVOX_DEVICE_UPDATE")) allow_device_map = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_DEVICE_MARGIN")) { const long c = std::atol(e); if (c >= 0) device_margin = size_t(c); }
         if (const char* e = std::getenv("FLS_IVOX_DEVICE_EVICT")) device_evict = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_IVOX_FUSED_UPDATE")) fused_update = std::atoi(e) != 0;
         d_upd_state.reserve(1);
         FLS_HIP(hipHostMalloc((void**)&upd_mb_host, sizeof(IvoxUpdMailbox), hipHostMallocMapped));
         std::memset(upd_mb_host, 0, sizeof(IvoxUpdMailbox));
@@ -207,6 +210,12 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         upd_seq = (upd_seq + 1u) & 0x7fffffffu;
         if (upd_seq == 0u) upd_seq = 1u;
         const dim3 g{unsigned(nb), 1u, 1u}, t{unsigned(kUpdBlock), 1u, 1u};
+        // small batch that cannot reach the LRU capacity: every phase in ONE launch of one workgroup (ivox_upd_fused_kernel)
+        const bool fused = fused_update && n <= size_t(kFusedMaxN) && dev_n_alive + n < ivox.capacity;
+        if (fused) {
+            hipLaunchKernelGGL(ivox_upd_fused_kernel, dim3(1), dim3(kFusedThreads), 0, stream, b, a, d_upd_state.p, upd_mb_dev, upd_seq);
+            ++n_fused_updates;
+        } else {
         hipLaunchKernelGGL(ivox_upd_count, g, t, 0, stream, b);
         hipLaunchKernelGGL(ivox_upd_scan1, dim3(1), dim3(kUpdMaxBlocks), 0, stream, b, nb, d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_seq, g, t, 0, stream, b, a, d_upd_state.p);
@@ -243,6 +252,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         hipLaunchKernelGGL(ivox_upd_points, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_finish, dim3(unsigned((n + kUpdBlock / 64 - 1) / (kUpdBlock / 64))), t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
         hipLaunchKernelGGL(ivox_upd_commit, dim3(1), dim3(64), 0, stream, d_upd_state.p, upd_mb_dev, upd_seq, unsigned(image.n_bricks_cap));
+        }
         FLS_HIP(hipGetLastError());
         // the verdict of the batch (a few words in host-mapped memory; no copy, no stream synchronisation)
         for (unsigned long long spin = 1;; ++spin) {
@@ -668,6 +678,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (slot == 101) return n_full_rebuilds;  //                ... as full re-flatten + upload
         if (slot == 103) return n_device_updates;  //                ... by the device-side AddPoints
         if (slot == 104) return n_host_fallbacks;  //                batches the device refused (replayed on the host)
+        if (slot == 122) return n_fused_updates;    //                ... of which in the one-launch form
         if (slot == 117) return n_device_evictions;  //              voxels evicted inside device batches
         if (slot == 119) return n_refused_conflict;  //              refusals by reason: eviction order conflict / point array full / point outside the window
         if (slot == 120) return n_refused_full;

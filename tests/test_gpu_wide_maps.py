@@ -177,3 +177,39 @@ def test_ndt_on_a_multi_site_map():
         util.assert_same_registration(m, o, ok, T, ok_ref, T_ref)
         assert m.map_size() == o.map_size(), k
     m.close(); o.close()
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_device_addpoints_one_launch_and_multi_launch_forms(fused, monkeypatch):
+    """The device AddPoints of a small batch runs as ONE launch of one workgroup (ivox_upd_fused_kernel) by default, as ten launches with
+    FLS_IVOX_FUSED_UPDATE=0 -- the same device functions either way: the 8-scan mapping replay equals the oracle in both forms."""
+    monkeypatch.setenv("FLS_IVOX_FUSED_UPDATE", fused)
+    m, o = _replay(8)
+    assert m.map_size(103) >= 7 and m.map_size(104) == 0
+    assert (m.map_size(122) >= 7) if fused == "1" else (m.map_size(122) == 0), m.map_size(122)
+    m.close(); o.close()
+
+
+def test_device_addpoints_large_batch_takes_the_multi_launch_form():
+    """A raw 64 x 600 scan (38,400 points > the one-workgroup limit) goes through the multi-launch form; a following small one through the fused form."""
+    scene = synth.make_scene()
+    rng = synth.rng_for(1, 77)
+    mp = synth.sample_map(scene, 120000, synth.rng_for(1, 0, 8), radius=40.0)
+    y = reg.YAML_NCLT_IVOX
+    m = reg.make_matcher("PointToPlane_IVOX", y)
+    o = util.oracle_for("PointToPlane_IVOX", y)
+    m.AddCloudToLocalMap([mp])
+    o.AddCloudToLocalMap(mp)
+    Tgt, guess = np.eye(4), np.eye(4)
+    for k, n_az in enumerate((600, 60, 600, 60)):
+        Tgt = Tgt @ synth.random_pose(rng, 1.0, 0.5)
+        Tgt[2, 3] = 0.0
+        scan = synth.cast_scan(scene, Tgt, rng=rng, max_range=48.0, **dict(synth.VELODYNE_64, n_az=n_az))
+        T = guess.copy()
+        ok = m.Match(reg.PointcloudCluster(planar_cloud_=scan), T, update_map=True)
+        ok_ref, T_ref = o.Match(scan, guess, update_map=True)
+        util.assert_same_registration(m, o, ok, T, ok_ref, T_ref, sets_only_tail=True, max_tie_rows=int(o.counters().tie_queries))
+        assert m.map_size() == o.map_size() and m.map_size(102) == o.map_voxels(), k
+        guess = T_ref
+    assert m.map_size(103) == 4 and m.map_size(122) == 2 and m.map_size(104) == 0, (m.map_size(103), m.map_size(122), m.map_size(104))
+    m.close(); o.close()
