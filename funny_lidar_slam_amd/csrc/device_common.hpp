@@ -157,6 +157,70 @@ __device__ __forceinline__ void mailbox_publish(Mailbox* __restrict__ mb, const 
 }
 #endif
 
+#ifdef __HIPCC__
+// exclusive block scan of a small vector of counters (wave shuffles + one LDS hop); returns the exclusive prefix, total in `tot`
+template <int NV>
+__device__ __forceinline__ void block_excl_scan(unsigned (&v)[NV], unsigned (&tot)[NV], unsigned (*wsum)[NV] /* LDS [waves][NV] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    unsigned inc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        unsigned x = v[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        inc[k] = x;
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) wsum[w][k] = inc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        unsigned base = 0, t = 0;
+        for (int q = 0; q < nw; ++q) { const unsigned s = wsum[q][k]; if (q < w) base += s; t += s; }
+        v[k] = base + inc[k] - v[k];
+        tot[k] = t;
+    }
+    __syncthreads();
+}
+
+// sum over a small array by a whole workgroup, split at `cut`: pre = sum of v[j] for j < cut, all = sum over [0, n) (every thread gets
+// both).  Used by kernels that derive their block offset from the per-block totals of the previous launch themselves instead of
+// waiting for a one-workgroup scan launch in between (a dependent launch costs ~7 us on this path, the sums a fraction of one).
+template <int NV, class T4>
+__device__ __forceinline__ void block_prefix_total(const T4* __restrict__ v, const int n, const int cut, unsigned (&pre)[NV], unsigned (&all)[NV],
+                                                   unsigned (*wsum)[2 * NV] /* LDS [waves][2 NV] */) {
+    unsigned p[NV], a[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) p[k] = a[k] = 0u;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const T4 e = v[j];
+        const unsigned* w = reinterpret_cast<const unsigned*>(&e);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { a[k] += w[k]; if (j < cut) p[k] += w[k]; }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { p[k] += __shfl_xor(p[k], o, 64); a[k] += __shfl_xor(a[k], o, 64); }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { wsum[wv][k] = p[k]; wsum[wv][NV + k] = a[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        unsigned sp = 0u, sa = 0u;
+        for (int q = 0; q < nw; ++q) { sp += wsum[q][k]; sa += wsum[q][NV + k]; }
+        pre[k] = sp; all[k] = sa;
+    }
+    __syncthreads();
+}
+#endif
+
 // initial pose handed to the first iteration's kernels as a launch argument (no host-to-device copy)
 struct Pose16 { double m[16]; };
 

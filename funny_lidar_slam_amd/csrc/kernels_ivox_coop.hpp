@@ -601,74 +601,89 @@ ivox_nn_materialize_kernel(const unsigned* __restrict__ nn_ids, unsigned char* _
 // MATERIALIZE (round 3): the launch also turns the ids-form lists into rows (what ivox_nn_materialize_kernel does) -- the map update that
 // follows moves slots, and this kernel gathers the same five points anyway: one launch and one gather less per mapping-mode scan.
 // The grid then covers max(n, nn_n) points (lists beyond the points that are decided on still become rows).
+// COUNT (round 4): the launch also does what ivox_upd_count did -- block-local exclusive counts of the two insertion codes (lx) and the
+// block totals (bt) for the device-side AddPoints -- and resets the batch status words: one dependent launch less in front of the update.
 template <bool MATERIALIZE>
 __global__ void __launch_bounds__(256)
 ivox_add_decide_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
                        const Pose16 Tw, float4* __restrict__ nn_pts, unsigned char* __restrict__ nn_cnt, const int nn_n,
                        const double fs /* filter_size_map_min */, unsigned char* __restrict__ code, float4* __restrict__ pw_out,
-                       const unsigned* __restrict__ nn_ids /* may be null */, const float4* __restrict__ map_pts, const unsigned n_slots) {
+                       const unsigned* __restrict__ nn_ids /* may be null */, const float4* __restrict__ map_pts, const unsigned n_slots,
+                       uint2* __restrict__ lx /* may be null: no counting */, uint2* __restrict__ bt, unsigned* __restrict__ st_status,
+                       unsigned* __restrict__ st_apply) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n && (!MATERIALIZE || i >= nn_n)) return;
-    const int cb = i < nn_n ? nn_cnt[i] : 0;
-    const int cnt = cb & 7;
-    const bool ids_form = nn_ids != nullptr && !(cb & 0x80);
-    float4 nb[5];
-    if (MATERIALIZE) {
-        // all five rows now (whatever the decision below needs), written back in rows form
+    unsigned char c = 0;  // this point's code (0 also for the threads beyond n)
+    if (i < n || (MATERIALIZE && i < nn_n)) {
+        const int cb = i < nn_n ? nn_cnt[i] : 0;
+        const int cnt = cb & 7;
+        const bool ids_form = nn_ids != nullptr && !(cb & 0x80);
+        float4 nb[5];
+        if (MATERIALIZE) {
+            // all five rows now (whatever the decision below needs), written back in rows form
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            if (ids_form) {
-                const unsigned sl = nn_ids[(size_t)i * 8 + k];
-                nb[k] = (cnt && sl < n_slots) ? map_pts[sl] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-            } else {
-                nb[k] = (i < nn_n && cnt) ? nn_pts[(size_t)i * 5 + k] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-            }
-        }
-        if (i < nn_n && ids_form) {
-            if (cnt) {
-#pragma unroll
-                for (int k = 0; k < 5; ++k) nn_pts[(size_t)i * 5 + k] = nb[k];
-            }
-            nn_cnt[i] = (unsigned char)(cb | 0x80);
-        }
-        if (i >= n) return;
-    }
-    const double x = sx[i], y = sy[i], z = sz[i];
-    const float wx = (float)(((Tw.m[0] * x + Tw.m[4] * y) + Tw.m[8] * z) + Tw.m[12]);
-    const float wy = (float)(((Tw.m[1] * x + Tw.m[5] * y) + Tw.m[9] * z) + Tw.m[13]);
-    const float wz = (float)(((Tw.m[2] * x + Tw.m[6] * y) + Tw.m[10] * z) + Tw.m[14]);
-    pw_out[i] = make_float4(wx, wy, wz, 0.f);
-    auto neighbour = [&](const int k) -> float4 {
-        if (MATERIALIZE) return nb[k];
-        if (!ids_form) return nn_pts[(size_t)i * 5 + k];
-        const unsigned sl = nn_ids[(size_t)i * 8 + k];
-        return map_pts[sl < n_slots ? sl : 0u];
-    };
-    unsigned char c = 1;  // no neighbours: add (:126)
-    if (cnt > 0) {
-        const double half = 0.5 * fs;
-        const double c0 = (floor((double)wx / fs) + 0.5) * fs, c1 = (floor((double)wy / fs) + 0.5) * fs, c2 = (floor((double)wz / fs) + 0.5) * fs;
-        const float4 n0 = neighbour(0);
-        const double d0 = (double)n0.x - c0, d1 = (double)n0.y - c1, d2 = (double)n0.z - c2;
-        if (fabs(d0) > half && fabs(d1) > half && fabs(d2) > half) {
-            c = 2;  // :103-108
-        } else {
-            const double e0 = (double)wx - c0, e1 = (double)wy - c1, e2 = (double)wz - c2;
-            const double dist = (e0 * e0 + e1 * e1) + e2 * e2;
-            bool need_add = true;
-            if (cnt >= 5) {
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    if (!need_add) break;
-                    const float4 q = neighbour(k);
-                    const double f0 = (double)q.x - c0, f1 = (double)q.y - c1, f2 = (double)q.z - c2;
-                    if ((f0 * f0 + f1 * f1) + f2 * f2 < dist + 1.0e-6) need_add = false;
+            for (int k = 0; k < 5; ++k) {
+                if (ids_form) {
+                    const unsigned sl = nn_ids[(size_t)i * 8 + k];
+                    nb[k] = (cnt && sl < n_slots) ? map_pts[sl] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+                } else {
+                    nb[k] = (i < nn_n && cnt) ? nn_pts[(size_t)i * 5 + k] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
                 }
             }
-            c = need_add ? 1 : 0;
+            if (i < nn_n && ids_form) {
+                if (cnt) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) nn_pts[(size_t)i * 5 + k] = nb[k];
+                }
+                nn_cnt[i] = (unsigned char)(cb | 0x80);
+            }
+        }
+        if (i < n) {
+            const double x = sx[i], y = sy[i], z = sz[i];
+            const float wx = (float)(((Tw.m[0] * x + Tw.m[4] * y) + Tw.m[8] * z) + Tw.m[12]);
+            const float wy = (float)(((Tw.m[1] * x + Tw.m[5] * y) + Tw.m[9] * z) + Tw.m[13]);
+            const float wz = (float)(((Tw.m[2] * x + Tw.m[6] * y) + Tw.m[10] * z) + Tw.m[14]);
+            pw_out[i] = make_float4(wx, wy, wz, 0.f);
+            auto neighbour = [&](const int k) -> float4 {
+                if (MATERIALIZE) return nb[k];
+                if (!ids_form) return nn_pts[(size_t)i * 5 + k];
+                const unsigned sl = nn_ids[(size_t)i * 8 + k];
+                return map_pts[sl < n_slots ? sl : 0u];
+            };
+            c = 1;  // no neighbours: add (:126)
+            if (cnt > 0) {
+                const double half = 0.5 * fs;
+                const double c0 = (floor((double)wx / fs) + 0.5) * fs, c1 = (floor((double)wy / fs) + 0.5) * fs, c2 = (floor((double)wz / fs) + 0.5) * fs;
+                const float4 n0 = neighbour(0);
+                const double d0 = (double)n0.x - c0, d1 = (double)n0.y - c1, d2 = (double)n0.z - c2;
+                if (fabs(d0) > half && fabs(d1) > half && fabs(d2) > half) {
+                    c = 2;  // :103-108
+                } else {
+                    const double e0 = (double)wx - c0, e1 = (double)wy - c1, e2 = (double)wz - c2;
+                    const double dist = (e0 * e0 + e1 * e1) + e2 * e2;
+                    bool need_add = true;
+                    if (cnt >= 5) {
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            if (!need_add) break;
+                            const float4 q = neighbour(k);
+                            const double f0 = (double)q.x - c0, f1 = (double)q.y - c1, f2 = (double)q.z - c2;
+                            if ((f0 * f0 + f1 * f1) + f2 * f2 < dist + 1.0e-6) need_add = false;
+                        }
+                    }
+                    c = need_add ? 1 : 0;
+                }
+            }
+            code[i] = c;
         }
     }
-    code[i] = c;
+    if (lx != nullptr) {  // (uniform)
+        __shared__ unsigned wsum[256 / 64][2];
+        unsigned v[2] = {c == 1 ? 1u : 0u, c == 2 ? 1u : 0u}, tot[2];
+        block_excl_scan<2>(v, tot, wsum);
+        if (i < n) lx[i] = make_uint2(v[0], v[1]);
+        if (threadIdx.x == 0 && blockIdx.x * 256 < n) bt[blockIdx.x] = make_uint2(tot[0], tot[1]);
+        if (threadIdx.x == 0 && blockIdx.x == 0) { *st_status = 0u; *st_apply = 0u; }  // kUpdOk; the batch's verdict is open
+    }
 }
 
 }  // namespace fls

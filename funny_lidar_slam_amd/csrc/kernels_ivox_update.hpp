@@ -30,6 +30,7 @@
 //   ivox_upd_commit     <1>   counters, status to the host-mapped word
 #pragma once
 #include "device_common.hpp"
+#include "kernels_p2plane.hpp"  // fanin_last_arriver
 
 namespace fls {
 
@@ -153,33 +154,6 @@ __device__ __forceinline__ unsigned upd_cap_for(const unsigned n) {  // GridImag
 }
 __device__ __forceinline__ unsigned upd_log2(unsigned c) { return 31u - (unsigned)__clz((int)c); }
 
-// exclusive block scan of a small vector of counters (wave shuffles + one LDS hop); returns the exclusive prefix, total in `tot`
-template <int NV>
-__device__ __forceinline__ void block_excl_scan(unsigned (&v)[NV], unsigned (&tot)[NV], unsigned (*wsum)[NV] /* LDS [waves][NV] */) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    unsigned inc[NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        unsigned x = v[k];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        inc[k] = x;
-    }
-    if (lane == 63) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) wsum[w][k] = inc[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        unsigned base = 0, t = 0;
-        for (int q = 0; q < nw; ++q) { const unsigned s = wsum[q][k]; if (q < w) base += s; t += s; }
-        v[k] = base + inc[k] - v[k];
-        tot[k] = t;
-    }
-    __syncthreads();
-}
-
 __global__ void __launch_bounds__(kUpdBlock)
 ivox_upd_count(const IvoxUpdBatch b) {
     __shared__ unsigned wsum[kUpdBlock / 64][2];
@@ -253,9 +227,10 @@ __device__ __forceinline__ bool upd_plan_rank(const IvoxUpdBatch& b, const IvoxU
     v[3] = grow ? cap : 0u;
     return true;
 }
-// the all-or-nothing verdict of a batch from its totals {alloc, creations, touched, relocated} (one thread)
-__device__ __forceinline__ void upd_decide_totals(IvoxUpdState* __restrict__ st, const unsigned (&tot)[4], const unsigned evict_ready, const unsigned n_list) {
-    st->alloc = tot[0]; st->creations = tot[1]; st->touched = tot[2]; st->relocated_garbage = tot[3];
+// the all-or-nothing verdict of a batch from its totals {alloc, creations, touched, relocated}: the status word and the number of evictions
+// (a pure function of words no thread changes while it is evaluated: several workgroups may evaluate it side by side)
+__device__ __forceinline__ unsigned upd_verdict(const IvoxUpdState* __restrict__ st, const unsigned (&tot)[4], const unsigned evict_ready, const unsigned n_list,
+                                                unsigned& e) {
     unsigned status = __hip_atomic_load(&st->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // all-or-nothing: room in the point array.  LRU evictions inside the batch (ivox_map.cpp:133-136 evicts the list's back when
     // the count REACHES the capacity after a creation): with n alive voxels and k creations the batch evicts
@@ -263,11 +238,17 @@ __device__ __forceinline__ void upd_decide_totals(IvoxUpdState* __restrict__ st,
     // this batch (ivox_evict_check) -- the host queues the selection (alive cells sorted by stamp) whenever the batch could get there.
     if (st->used + (unsigned long long)tot[0] > st->pts_capacity) status |= kUpdArrayFull;
     const unsigned long long total = (unsigned long long)st->n_alive + tot[1];
-    unsigned e = 0u;
+    e = 0u;
     if (total >= (unsigned long long)st->lru_capacity) {
         e = (unsigned)(total - (unsigned long long)st->lru_capacity + 1ull);
         if (!evict_ready || e > n_list) status |= kUpdNeedHost;
     }
+    return status;
+}
+__device__ __forceinline__ void upd_decide_totals(IvoxUpdState* __restrict__ st, const unsigned (&tot)[4], const unsigned evict_ready, const unsigned n_list) {
+    unsigned e;
+    const unsigned status = upd_verdict(st, tot, evict_ready, n_list, e);
+    st->alloc = tot[0]; st->creations = tot[1]; st->touched = tot[2]; st->relocated_garbage = tot[3];
     st->evict_ready = evict_ready;  // (round 3: a one-thread launch of their own used to set these two words)
     st->n_list = n_list;
     st->evict = e;
@@ -566,6 +547,69 @@ __device__ __forceinline__ void upd_commit(IvoxUpdState* __restrict__ st, IvoxUp
 __global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* __restrict__ mb, const unsigned seq, const unsigned n_bricks_cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     upd_commit(st, mb, seq, n_bricks_cap);
+}
+
+// ---- the short chain (round 4): six dependent launches instead of eleven --------------------------------------------------------
+// A dependent launch costs ~7 us on this path (2-5 us of work + ~4 us of dispatch latency), so the launches that only scanned a
+// few hundred block totals, flipped first -> last ranks or published the result are folded into their neighbours:
+//   ivox_add_decide_kernel (+ count)  ->  ivox_upd_seq_nb (every block sums the block totals before it: no scan1)  ->  ivox_upd_plan
+//   ->  ivox_upd_last_regions (every block sums the plan totals and evaluates the verdict itself: no scan2, no separate `last`)
+//   ->  ivox_upd_points  ->  ivox_upd_finish_commit (the last block to finish publishes: no commit launch).
+// Same device functions, same arithmetic.  Batches that may evict keep the long chain (the selection needs grid-wide steps of its own).
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_seq_nb(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st, const int nblocks) {
+    __shared__ unsigned wsum[kUpdBlock / 64][4];
+    unsigned pre[2], all[2];
+    block_prefix_total<2>(b.bt, nblocks, (int)blockIdx.x, pre, all, wsum);  // bt: raw block totals of the decision codes (ivox_add_decide_kernel)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->n1 = all[0]; st->n2 = all[1]; }
+    const int i = blockIdx.x * kUpdBlock + threadIdx.x;
+    if (i >= b.n) return;
+    const unsigned c = b.code[i];
+    if (c == 0u) return;
+    const uint2 l = b.lx[i];
+    const unsigned r = c == 1u ? pre[0] + l.x : all[0] + pre[1] + l.y;
+    upd_seq_rank(b, a, st, r, (unsigned)i);
+}
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_last_regions(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st) {
+    __shared__ unsigned wsum[kUpdBlock / 64][8];
+    const unsigned A = st->n1 + st->n2;
+    const int nblocks = (int)((A + kUpdBlock - 1) / kUpdBlock);
+    if ((int)blockIdx.x >= nblocks && blockIdx.x != 0) return;  // (block 0 always runs: it records the verdict, also of an empty batch)
+    unsigned pre[4], tot[4], e;
+    block_prefix_total<4>(b.bt2, nblocks, (int)blockIdx.x, pre, tot, wsum);  // bt2: raw block totals of ivox_upd_plan
+    const bool apply = upd_verdict(st, tot, 0u, 0u, e) == kUpdOk;  // the same words in every block: the same verdict
+    const unsigned r = blockIdx.x * kUpdBlock + threadIdx.x;
+    if (r < A) {
+        const unsigned cell = b.seq_cell[r];
+        if (cell != kUpdInvalidCell) {
+            if (apply) atomicMax(&a.rank_mm[cell], r);
+            else { a.pend[cell] = 0u; a.rank_mm[cell] = kUpdNoRank; }
+        }
+        if (apply && b.fbit[r]) { const uint4 loc = b.px[r]; upd_region_rank(b, a, st, r, pre[0] + loc.x, pre[2] + loc.z); }
+    }
+    // the record of the verdict (read by the launches that follow); written last: the blocks above only READ the words it is made of,
+    // and the status it stores is the one they computed
+    if (blockIdx.x == 0 && threadIdx.x == 0) upd_decide_totals(st, tot, 0u, 0u);
+}
+// points of rank r in the short chain: the block offsets of ivox_upd_plan were never scanned in place, nothing else differs
+// (ivox_upd_points serves both chains)
+constexpr int kFinishBlocks = 256;
+__global__ void __launch_bounds__(kUpdBlock)
+ivox_upd_finish_commit(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st, IvoxUpdMailbox* __restrict__ mb, const unsigned seq,
+                       unsigned* __restrict__ ticket) {
+    __shared__ float4 s_pts[kUpdBlock / 64][kUpdFinishMaxK];
+    __shared__ unsigned s_last;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (st->apply) {
+        const unsigned touched = st->touched;
+        for (unsigned t = blockIdx.x * (kUpdBlock / 64) + w; t < touched; t += gridDim.x * (kUpdBlock / 64)) upd_finish_voxel<kUpdFinishMaxK>(b, a, st, t, &s_pts[w][0], lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = fanin_last_arriver(ticket, 8);
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) upd_commit(st, mb, seq, a.n_bricks_cap);  // every other block is done with the words this changes
 }
 
 // ---- the whole batch in ONE launch of ONE workgroup (small batches: the 0.5 m-filtered planar cloud the pipeline feeds, ~10 k points) ----

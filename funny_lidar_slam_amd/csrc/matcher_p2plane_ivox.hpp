@@ -36,8 +36,9 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     bool allow_device_map = true;  // FLS_IVOX_DEVICE_UPDATE=0: always the host path (A/B)
     size_t device_margin = 4096;   // voxels of head-room below the LRU capacity required to (re-)enter device mode (FLS_IVOX_DEVICE_MARGIN: test hook)
     size_t n_device_updates = 0, n_host_fallbacks = 0, n_device_evictions = 0, n_refused_conflict = 0, n_refused_full = 0, n_refused_outside = 0;
-    bool fused_update = true;      // FLS_IVOX_FUSED_UPDATE=0: always the multi-launch form of the device AddPoints (A/B)
-    size_t n_fused_updates = 0;
+    bool fused_update = false;     // FLS_IVOX_FUSED_UPDATE=1 (A/B): small batches as ONE launch of one workgroup
+    bool short_chain_update = true;  // FLS_IVOX_SHORT_CHAIN=0 (A/B): the round-3 chain of eleven launches for every batch
+    size_t n_fused_updates = 0, n_short_updates = 0;
     bool device_evict = true;      // FLS_IVOX_DEVICE_EVICT=0: a batch that reaches the LRU capacity is refused (round-2 behaviour, with the margin rule)
     DevicePairSort ev_sort;
     DevBuf<unsigned> d_ev_bt, d_crank, d_evict_list;
@@ -107,6 +108,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (const char* e = std::getenv("FLS_IVOX_DEVICE_MARGIN")) { const long c = std::atol(e); if (c >= 0) device_margin = size_t(c); }
         if (const char* e = std::getenv("FLS_IVOX_DEVICE_EVICT")) device_evict = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_FUSED_UPDATE")) fused_update = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_IVOX_SHORT_CHAIN")) short_chain_update = std::atoi(e) != 0;
         d_upd_state.reserve(1);
         FLS_HIP(hipHostMalloc((void**)&upd_mb_host, sizeof(IvoxUpdMailbox), hipHostMallocMapped));
         std::memset(upd_mb_host, 0, sizeof(IvoxUpdMailbox));
@@ -199,7 +201,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     }
 
     // One batch of the resident scan through the device-side AddPoints.  Returns true when the device applied it.
-    bool device_add_points(const size_t n) {
+    bool device_add_points(const size_t n, const bool counted_by_decide) {
         const int nb = int((n + kUpdBlock - 1) / kUpdBlock);
         if (nb > kUpdMaxBlocks) return false;
         d_lx.reserve(n); d_bt.reserve(size_t(nb)); d_seq_src.reserve(n); d_seq_cell.reserve(n); d_jj.reserve(n); d_tlist.reserve(n);
@@ -210,11 +212,23 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         upd_seq = (upd_seq + 1u) & 0x7fffffffu;
         if (upd_seq == 0u) upd_seq = 1u;
         const dim3 g{unsigned(nb), 1u, 1u}, t{unsigned(kUpdBlock), 1u, 1u};
-        // small batch that cannot reach the LRU capacity: every phase in ONE launch of one workgroup (ivox_upd_fused_kernel)
-        const bool fused = fused_update && n <= size_t(kFusedMaxN) && dev_n_alive + n < ivox.capacity;
+        // three forms of the same phases (kernels_ivox_update.hpp): the SHORT chain (default: five launches behind the decision), the
+        // one-workgroup single launch (FLS_IVOX_FUSED_UPDATE=1, small batches; measured slower: one CU's latency chains), and the LONG
+        // chain, which batches that may reach the LRU capacity need (the eviction selection has grid-wide steps of its own)
+        const bool cannot_evict = dev_n_alive + n < ivox.capacity;
+        const bool fused = fused_update && n <= size_t(kFusedMaxN) && cannot_evict;
+        const bool short_chain = !fused && short_chain_update && cannot_evict && counted_by_decide;
         if (fused) {
             hipLaunchKernelGGL(ivox_upd_fused_kernel, dim3(1), dim3(kFusedThreads), 0, stream, b, a, d_upd_state.p, upd_mb_dev, upd_seq);
             ++n_fused_updates;
+        } else if (short_chain) {
+            hipLaunchKernelGGL(ivox_upd_seq_nb, g, t, 0, stream, b, a, d_upd_state.p, nb);
+            hipLaunchKernelGGL(ivox_upd_plan, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
+            hipLaunchKernelGGL(ivox_upd_last_regions, g, t, 0, stream, b, a, d_upd_state.p);
+            hipLaunchKernelGGL(ivox_upd_points, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
+            const unsigned fb = unsigned(std::min<size_t>(size_t(kFinishBlocks), (n + kUpdBlock / 64 - 1) / (kUpdBlock / 64)));
+            hipLaunchKernelGGL(ivox_upd_finish_commit, dim3(fb), t, 0, stream, b, a, d_upd_state.p, upd_mb_dev, upd_seq, d_ticket.p);
+            ++n_short_updates;
         } else {
         hipLaunchKernelGGL(ivox_upd_count, g, t, 0, stream, b);
         hipLaunchKernelGGL(ivox_upd_scan1, dim3(1), dim3(kUpdMaxBlocks), 0, stream, b, nb, d_upd_state.p);
@@ -332,6 +346,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             std::vector<PtI> to_add, no_downsample;
             const size_t n = std::min(number_planar_point, scan.n);
             const auto tm0 = std::chrono::steady_clock::now();
+            bool counted = false;
             if (n) {
                 d_code.reserve(n);
                 d_pw.reserve(n);
@@ -339,22 +354,32 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
                 h_pw.resize(n);
                 Pose16 Tw;
                 std::memcpy(Tw.m, T_, sizeof(Tw.m));
+                // device mode: the decision launch also counts the insertion codes per block and opens the batch (ivox_upd_count's job)
+                const int nb = int((n + kUpdBlock - 1) / kUpdBlock);
+                const bool count_here = device_map && nb <= kUpdMaxBlocks;
+                if (count_here) { d_lx.reserve(n); d_bt.reserve(size_t(nb)); }
+                uint2* const lx_arg = count_here ? d_lx.p : nullptr;
+                uint2* const bt_arg = count_here ? d_bt.p : nullptr;
+                unsigned* const st_status = count_here ? &d_upd_state.p->status : nullptr;
+                unsigned* const st_apply = count_here ? &d_upd_state.p->apply : nullptr;
+                counted = count_here;
                 // (the update below moves map slots: lists still in ids form become rows in the same launch)
                 if (nn_ids_mode && !nn_rows_current && nn_n > 0) {
                     const size_t m = std::max(n, nn_n);
                     hipLaunchKernelGGL(ivox_add_decide_kernel<true>, dim3(unsigned((m + 255) / 256)), dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p,
                                        int(n), Tw, d_nn.p, d_nn_cnt.p, int(nn_n), filter_size_map_min,
-                                       d_code.p, d_pw.p, (const unsigned*)d_nn_ids.p, (const float4*)image.d_pts.p, unsigned(image.d_pts.cap));
+                                       d_code.p, d_pw.p, (const unsigned*)d_nn_ids.p, (const float4*)image.d_pts.p, unsigned(image.d_pts.cap), lx_arg, bt_arg, st_status, st_apply);
                     nn_rows_current = true;
                 } else {
                     hipLaunchKernelGGL(ivox_add_decide_kernel<false>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p,
                                        int(n), Tw, d_nn.p, d_nn_cnt.p, int(nn_n), filter_size_map_min,
-                                       d_code.p, d_pw.p, (const unsigned*)(nn_ids_mode ? d_nn_ids.p : nullptr), (const float4*)image.d_pts.p, unsigned(image.d_pts.cap));
+                                       d_code.p, d_pw.p, (const unsigned*)(nn_ids_mode ? d_nn_ids.p : nullptr), (const float4*)image.d_pts.p, unsigned(image.d_pts.cap), lx_arg, bt_arg,
+                                       st_status, st_apply);
                 }
                 FLS_HIP(hipGetLastError());
                 ensure_nn_rows();
                 if (device_map) {
-                    if (device_add_points(n)) {
+                    if (device_add_points(n, counted)) {
                         if (host_timing)
                             std::fprintf(stderr, "[fls host] device AddPoints: %u points into %u voxels, %.3f ms\n", upd_mb_host->added, upd_mb_host->touched,
                                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count());
@@ -679,6 +704,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (slot == 103) return n_device_updates;  //                ... by the device-side AddPoints
         if (slot == 104) return n_host_fallbacks;  //                batches the device refused (replayed on the host)
         if (slot == 122) return n_fused_updates;    //                ... of which in the one-launch form
+        if (slot == 123) return n_short_updates;    //                ... of which in the short chain (five launches behind the decision)
         if (slot == 117) return n_device_evictions;  //              voxels evicted inside device batches
         if (slot == 119) return n_refused_conflict;  //              refusals by reason: eviction order conflict / point array full / point outside the window
         if (slot == 120) return n_refused_full;

@@ -179,19 +179,26 @@ def test_ndt_on_a_multi_site_map():
     m.close(); o.close()
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
-def test_device_addpoints_one_launch_and_multi_launch_forms(fused, monkeypatch):
-    """The device AddPoints of a small batch runs as ONE launch of one workgroup (ivox_upd_fused_kernel) by default, as ten launches with
-    FLS_IVOX_FUSED_UPDATE=0 -- the same device functions either way: the 8-scan mapping replay equals the oracle in both forms."""
-    monkeypatch.setenv("FLS_IVOX_FUSED_UPDATE", fused)
+@pytest.mark.parametrize("form", ["short", "long", "one_workgroup"])
+def test_device_addpoints_three_forms(form, monkeypatch):
+    """The device AddPoints runs the same device functions in three launch structures: the SHORT chain (default: the decision launch
+    counts, every block derives its offsets and the verdict itself, the last block to finish publishes -- five launches behind the
+    decision instead of ten), the round-3 LONG chain (FLS_IVOX_SHORT_CHAIN=0; what batches that may evict still use) and ONE launch of
+    one workgroup (FLS_IVOX_FUSED_UPDATE=1).  The 8-scan mapping replay equals the oracle in all of them."""
+    if form == "long":
+        monkeypatch.setenv("FLS_IVOX_SHORT_CHAIN", "0")
+    if form == "one_workgroup":
+        monkeypatch.setenv("FLS_IVOX_FUSED_UPDATE", "1")
     m, o = _replay(8)
     assert m.map_size(103) >= 7 and m.map_size(104) == 0
-    assert (m.map_size(122) >= 7) if fused == "1" else (m.map_size(122) == 0), m.map_size(122)
+    short, one = m.map_size(123), m.map_size(122)
+    assert (short, one) == ((m.map_size(103), 0) if form == "short" else (0, m.map_size(103)) if form == "one_workgroup" else (0, 0)), (form, short, one)
     m.close(); o.close()
 
 
-def test_device_addpoints_large_batch_takes_the_multi_launch_form():
-    """A raw 64 x 600 scan (38,400 points > the one-workgroup limit) goes through the multi-launch form; a following small one through the fused form."""
+def test_device_addpoints_large_and_small_batches_alternate(monkeypatch):
+    """Raw 64 x 600 scans (38,400 points, beyond the one-workgroup limit: short chain) alternate with small ones (one workgroup, switched on here)."""
+    monkeypatch.setenv("FLS_IVOX_FUSED_UPDATE", "1")
     scene = synth.make_scene()
     rng = synth.rng_for(1, 77)
     mp = synth.sample_map(scene, 120000, synth.rng_for(1, 0, 8), radius=40.0)
@@ -211,5 +218,5 @@ def test_device_addpoints_large_batch_takes_the_multi_launch_form():
         util.assert_same_registration(m, o, ok, T, ok_ref, T_ref, sets_only_tail=True, max_tie_rows=int(o.counters().tie_queries))
         assert m.map_size() == o.map_size() and m.map_size(102) == o.map_voxels(), k
         guess = T_ref
-    assert m.map_size(103) == 4 and m.map_size(122) == 2 and m.map_size(104) == 0, (m.map_size(103), m.map_size(122), m.map_size(104))
+    assert m.map_size(103) == 4 and m.map_size(122) == 2 and m.map_size(123) == 2 and m.map_size(104) == 0, (m.map_size(103), m.map_size(122), m.map_size(123), m.map_size(104))
     m.close(); o.close()
