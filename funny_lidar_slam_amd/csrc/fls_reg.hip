@@ -130,7 +130,7 @@ fls_status fls_match(fls_handle h, const float* s0, size_t n0, const float* s1, 
     if (!h || !T || (!s0 && n0) || stride < 3) return FLS_ERR_INVALID;
     return guarded([&]() -> fls_status {
         FLS_HIP(hipSetDevice(h->device));
-        const fls_status rc = h->scan_upload(s0, n0, s1, n1, stride);
+        const fls_status rc = h->scan_upload_for_match(s0, n0, s1, n1, stride);
         if (rc != FLS_OK) return rc;
         return h->match_resident(T, update_map, stats);
     });

@@ -38,6 +38,7 @@ struct IvoxImage {
     DevBuf<HashEntry> d_dir;
     DevBuf<unsigned long long> d_brick_key;
     DevBuf<uint2> d_cells;
+    DevBuf<unsigned> d_nbr;  // device-private neighbour-index cache of the update kernels (kernels_ivox_update.hpp IvoxUpdArrays::nbr)
     // ---- per-cell arrays of the device-side AddPoints: region capacity, LRU stamp, two scratch words ----
     DevBuf<unsigned char> d_cap_log2;
     DevBuf<unsigned long long> d_stamp;
@@ -214,6 +215,8 @@ struct IvoxImage {
         }
         d_cells.reserve(n_bricks_cap * kBrickStride);
         FLS_HIP(hipMemsetAsync(d_cells.p, 0, n_bricks_cap * kBrickStride * sizeof(uint2), s));
+        d_nbr.reserve(n_bricks_cap * 32);
+        FLS_HIP(hipMemsetAsync(d_nbr.p, 0xff, n_bricks_cap * 32 * sizeof(unsigned), s));  // (brick indices change with every build)
         meta_cells = 0;  // (the per-cell arrays follow in upload_update_meta)
         upload_directory(s);
         scatter_cell_records(s, stage);

@@ -160,7 +160,10 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
                 const GnState* __restrict__ st, const Pose16 T0, const DevGrid grid, const BrickDir bd,
                 const float inv_res, float4* __restrict__ nn_pts /* [n][5] */, unsigned char* __restrict__ nn_cnt,
                 unsigned char* __restrict__ flag, TrafficCounters* __restrict__ tc, const int chunk,
-                unsigned* __restrict__ nn_ids /* [n][8]: map slots of the neighbours (ids form); nullptr: rows form */) {
+                unsigned* __restrict__ nn_ids /* [n][8]: map slots of the neighbours (ids form); nullptr: rows form */,
+                const int nn_prev /* FIRST: size of nearest_points_ before this Match; the grown tail starts empty (:257 resize) */,
+                float* __restrict__ dev_copy /* FIRST, may be null: sx / sy / sz point into the pinned staging buffer (host memory);
+                                                leave the device copy x[n] | y[n] | z[n] here for the launches that follow */) {
     static_assert(G == 4 || G == 8, "group size");
     constexpr int QPB = 256 / G;       // queries per workgroup
     constexpr int R = (19 + G - 1) / G;  // probe rounds per lane
@@ -189,7 +192,11 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
     const int qq = active ? q : 0;
     const float px = sx[qq], py = sy[qq], pz = sz[qq];
     if (done) return;
-    if (FIRST && active && sub == 0) flag[q] = 0;
+    if (FIRST && active && sub == 0) {
+        if (dev_copy) { dev_copy[q] = px; dev_copy[(size_t)n + q] = py; dev_copy[2 * (size_t)n + q] = pz; }
+        flag[q] = 0;
+        if (q >= nn_prev) nn_cnt[q] = 0;  // (an unaligned hipMemsetAsync of the tail cost up to three fill kernels in front of the Match)
+    }
     const double x = px, y = py, z = pz;
     const float ptx = (float)(((T[0] * x + T[3] * y) + T[6] * z) + T[9]);
     const float pty = (float)(((T[1] * x + T[4] * y) + T[7] * z) + T[10]);

@@ -76,8 +76,11 @@ struct IvoxUpdArrays {
     unsigned dir_mask;
     unsigned n_bricks_cap;   // brick pool size: slabs [0, n_bricks_cap) x kBrickStride cells exist (zero beyond the bricks in use)
     unsigned long long* brick_key;  // [n_bricks_cap] packed key of brick i
+    unsigned* nbr;           // [n_bricks_cap][32] device-private cache: index of the neighbouring brick with code (dx+1) + 3 (dy+1) + 9 (dz+1), kBrickPending = not looked up yet
+                             // (write-once values: a stale "not yet" only sends the reader through the directory again)
     float inv_res;
 };
+__device__ __forceinline__ int brick_nbr_code(const int dx, const int dy, const int dz) { return (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1); }
 
 // ---- brick directory on the device ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned brick_find(const IvoxUpdArrays& a, const int bx, const int by, const int bz) {
@@ -96,6 +99,11 @@ __device__ __forceinline__ unsigned brick_find(const IvoxUpdArrays& a, const int
 __device__ __forceinline__ unsigned brick_find_or_create(const IvoxUpdArrays& a, IvoxUpdState* __restrict__ st, const int bx, const int by, const int bz) {
     const unsigned long long key = pack_key(bx, by, bz);
     unsigned h = brick_hash(bx, by, bz) & a.dir_mask;
+    {   // fast path: the entry is there and published (one plain 16-byte load; entries are write-once, so a stale line can only look
+        // emptier than the truth and sends us to the careful loop below)
+        const HashEntry e = a.dir[h];
+        if (e.key == key && e.begin < a.n_bricks_cap) return e.begin;
+    }
     for (unsigned tries = 0; tries < 65536u; ++tries) {
         const unsigned long long k = __hip_atomic_load(&a.dir[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k == key) {
@@ -119,15 +127,20 @@ __device__ __forceinline__ unsigned brick_find_or_create(const IvoxUpdArrays& a,
     atomicOr(&st->status, kUpdArrayFull);
     return kBrickInvalid;
 }
-// the halo copies of primary cell `cell` (a boundary voxel of its brick) in the neighbouring bricks' slabs
+// the halo copies of primary cell `cell` (a boundary voxel of its brick) in the neighbouring bricks' slabs; the neighbours' indices come
+// from the brick's cache row (ivox_upd_seq filled it when the voxel's bricks were ensured), the directory is only the fallback
 __device__ __forceinline__ void brick_write_mirrors(const IvoxUpdArrays& a, const unsigned cell, const uint2 val) {
     int sx, sy, sz;
     if (!brick_slab_interior(cell & (kBrickStride - 1u), sx, sy, sz)) return;
-    int bx = 0, by = 0, bz = 0;
-    bool have_key = false;
+    const unsigned bi = cell / kBrickStride;
+    const unsigned* const row = a.nbr + (size_t)bi * 32u;
     brick_for_each_mirror(sx - 1, sy - 1, sz - 1, [&](const int dx, const int dy, const int dz) {
-        if (!have_key) { unpack_key(a.brick_key[cell / kBrickStride], bx, by, bz); have_key = true; }
-        const unsigned nb = brick_find(a, bx + dx, by + dy, bz + dz);
+        unsigned nb = row[brick_nbr_code(dx, dy, dz)];
+        if (nb >= a.n_bricks_cap) {
+            int bx, by, bz;
+            unpack_key(a.brick_key[bi], bx, by, bz);
+            nb = brick_find(a, bx + dx, by + dy, bz + dz);
+        }
         if (nb < a.n_bricks_cap)  // (exists by the invariant: ivox_upd_seq / the host build created it with the voxel)
             a.cells[nb * kBrickStride + brick_slab_index(sx - kBrickSide * dx, sy - kBrickSide * dy, sz - kBrickSide * dz)] = val;
     });
@@ -178,8 +191,16 @@ ivox_upd_scan1(const IvoxUpdBatch b, const int nblocks, IvoxUpdState* __restrict
 
 // loads of words other threads of the SAME launch may have changed with atomics (the fused one-workgroup form below runs all phases
 // in one launch: an L2 atomic does not update a line the CU's L1 already holds)
-__device__ __forceinline__ unsigned upd_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// COH = true only there (an agent-scope load is served from memory, ~3x the latency of an L2 hit: the multi-launch forms, whose phases
+// are separated by kernel boundaries, use plain loads)
+template <bool COH>
+__device__ __forceinline__ unsigned upd_ld(const unsigned* p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH>
 __device__ __forceinline__ uint2 upd_ld_cell(const uint2* p) {
+    if (!COH) return *p;
     const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_uint2((unsigned)(v & 0xffffffffull), (unsigned)(v >> 32));
 }
@@ -198,9 +219,29 @@ __device__ __forceinline__ void upd_seq_rank(const IvoxUpdBatch& b, const IvoxUp
         const int lx = kx & (kBrickSide - 1), ly = ky & (kBrickSide - 1), lz = kz & (kBrickSide - 1);
         const unsigned bi = brick_find_or_create(a, st, bx, by, bz);
         bool all = bi < a.n_bricks_cap;
-        brick_for_each_mirror(lx, ly, lz, [&](const int dx, const int dy, const int dz) {
-            if (all) all = brick_find_or_create(a, st, bx + dx, by + dy, bz + dz) < a.n_bricks_cap;
-        });
+        const int ex = lx == 0 ? -1 : lx == kBrickSide - 1 ? 1 : 0, ey = ly == 0 ? -1 : ly == kBrickSide - 1 ? 1 : 0, ez = lz == 0 ? -1 : lz == kBrickSide - 1 ? 1 : 0;
+        if (all && (ex | ey | ez)) {
+            // cached neighbour indices first (six independent loads in flight), the directory only for the ones never looked up
+            unsigned* const row = a.nbr + (size_t)bi * 32u;
+            unsigned v[6];
+#pragma unroll
+            for (int m = 1; m < 7; ++m) {
+                const bool need = !(((m & 1) && !ex) || ((m & 2) && !ey) || ((m & 4) && !ez));
+                v[m - 1] = need ? row[brick_nbr_code((m & 1) ? ex : 0, (m & 2) ? ey : 0, (m & 4) ? ez : 0)] : 0u;
+            }
+#pragma unroll
+            for (int m = 1; m < 7; ++m) {
+                const bool need = !(((m & 1) && !ex) || ((m & 2) && !ey) || ((m & 4) && !ez));
+                if (!need) continue;
+                unsigned nb = v[m - 1];
+                if (nb >= a.n_bricks_cap) {
+                    const int dx = (m & 1) ? ex : 0, dy = (m & 2) ? ey : 0, dz = (m & 4) ? ez : 0;
+                    nb = brick_find_or_create(a, st, bx + dx, by + dy, bz + dz);
+                    if (nb < a.n_bricks_cap) row[brick_nbr_code(dx, dy, dz)] = nb;
+                }
+                if (nb >= a.n_bricks_cap) all = false;
+            }
+        }
         if (all) cell = bi * kBrickStride + brick_slab_index(lx + 1, ly + 1, lz + 1);
     } else {
         atomicOr(&st->status, kUpdOutside);  // (a key beyond +-2^20: the host path reports FLS_ERR_RANGE)
@@ -212,12 +253,13 @@ __device__ __forceinline__ void upd_seq_rank(const IvoxUpdBatch& b, const IvoxUp
     atomicMin(&a.rank_mm[cell], r);
 }
 // what the batch does to the voxel whose first point has rank r: {new region slots, creation, touched, capacity left behind}
+template <bool COH = false>
 __device__ __forceinline__ bool upd_plan_rank(const IvoxUpdBatch& b, const IvoxUpdArrays& a, const unsigned r, unsigned (&v)[4]) {
     v[0] = v[1] = v[2] = v[3] = 0u;
     const unsigned cell = b.seq_cell[r];
-    if (cell == kUpdInvalidCell || upd_ld(&a.rank_mm[cell]) != r) return false;
-    const uint2 old = upd_ld_cell(&a.cells[cell]);
-    const unsigned total = old.y + upd_ld(&a.pend[cell]);
+    if (cell == kUpdInvalidCell || upd_ld<COH>(&a.rank_mm[cell]) != r) return false;
+    const uint2 old = upd_ld_cell<COH>(&a.cells[cell]);
+    const unsigned total = old.y + upd_ld<COH>(&a.pend[cell]);
     const unsigned cl = a.cap_log2[cell];
     const unsigned cap = cl ? (1u << cl) : 0u;
     const bool grow = total > cap;
@@ -230,8 +272,7 @@ __device__ __forceinline__ bool upd_plan_rank(const IvoxUpdBatch& b, const IvoxU
 // the all-or-nothing verdict of a batch from its totals {alloc, creations, touched, relocated}: the status word and the number of evictions
 // (a pure function of words no thread changes while it is evaluated: several workgroups may evaluate it side by side)
 __device__ __forceinline__ unsigned upd_verdict(const IvoxUpdState* __restrict__ st, const unsigned (&tot)[4], const unsigned evict_ready, const unsigned n_list,
-                                                unsigned& e) {
-    unsigned status = __hip_atomic_load(&st->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                unsigned status /* the batch's status word as the phases before left it */, unsigned& e) {
     // all-or-nothing: room in the point array.  LRU evictions inside the batch (ivox_map.cpp:133-136 evicts the list's back when
     // the count REACHES the capacity after a creation): with n alive voxels and k creations the batch evicts
     // E = max(0, n + k - (capacity - 1)) voxels; they are the E least recently touched ones as long as none of those is touched by
@@ -245,9 +286,10 @@ __device__ __forceinline__ unsigned upd_verdict(const IvoxUpdState* __restrict__
     }
     return status;
 }
-__device__ __forceinline__ void upd_decide_totals(IvoxUpdState* __restrict__ st, const unsigned (&tot)[4], const unsigned evict_ready, const unsigned n_list) {
+__device__ __forceinline__ void upd_decide_totals(IvoxUpdState* __restrict__ st, const unsigned (&tot)[4], const unsigned evict_ready, const unsigned n_list,
+                                                  const unsigned status_in) {
     unsigned e;
-    const unsigned status = upd_verdict(st, tot, evict_ready, n_list, e);
+    const unsigned status = upd_verdict(st, tot, evict_ready, n_list, status_in, e);
     st->alloc = tot[0]; st->creations = tot[1]; st->touched = tot[2]; st->relocated_garbage = tot[3];
     st->evict_ready = evict_ready;  // (round 3: a one-thread launch of their own used to set these two words)
     st->n_list = n_list;
@@ -258,11 +300,12 @@ __device__ __forceinline__ void upd_decide_totals(IvoxUpdState* __restrict__ st,
     if (!evict_ready) st->apply = status == kUpdOk ? 1u : 0u;  // no eviction selection follows: this is the verdict (ivox_upd_decide otherwise)
 }
 // the slot region of the voxel first touched by rank r: relocated when it outgrows its capacity; cell + halo copies; touched list
+template <bool COH = false>
 __device__ __forceinline__ void upd_region_rank(const IvoxUpdBatch& b, const IvoxUpdArrays& a, const IvoxUpdState* __restrict__ st, const unsigned r,
                                                 const unsigned alloc_before, const unsigned touched_before) {
     const unsigned cell = b.seq_cell[r];
-    const uint2 old = upd_ld_cell(&a.cells[cell]);
-    const unsigned total = old.y + upd_ld(&a.pend[cell]);
+    const uint2 old = upd_ld_cell<COH>(&a.cells[cell]);
+    const unsigned total = old.y + upd_ld<COH>(&a.pend[cell]);
     const unsigned cl = a.cap_log2[cell];
     const unsigned cap = cl ? (1u << cl) : 0u;
     unsigned begin = old.x;
@@ -277,11 +320,12 @@ __device__ __forceinline__ void upd_region_rank(const IvoxUpdBatch& b, const Ivo
     brick_write_mirrors(a, cell, make_uint2(begin, total));
     b.tlist[touched_before] = cell;
 }
+template <bool COH = false>
 __device__ __forceinline__ void upd_point_rank(const IvoxUpdBatch& b, const IvoxUpdArrays& a, const IvoxUpdState* __restrict__ st, const unsigned r) {
     const unsigned cell = b.seq_cell[r];
-    const uint2 e = upd_ld_cell(&a.cells[cell]);
+    const uint2 e = upd_ld_cell<COH>(&a.cells[cell]);
     const float4 p = b.pw[b.seq_src[r]];
-    a.pts[e.x + (e.y - upd_ld(&a.pend[cell])) + b.jj[r]] = make_float4(p.x, p.y, p.z, __int_as_float(st->next_id + (int)r));
+    a.pts[e.x + (e.y - upd_ld<COH>(&a.pend[cell])) + b.jj[r]] = make_float4(p.x, p.y, p.z, __int_as_float(st->next_id + (int)r));
 }
 
 // rank of every inserted point, its window cell, the sequence arrays, and the per-cell scratch (count, first rank)
@@ -319,7 +363,7 @@ ivox_upd_scan2(const IvoxUpdBatch b, IvoxUpdState* __restrict__ st, const unsign
     unsigned v[4] = {t.x, t.y, t.z, t.w}, tot[4];
     block_excl_scan<4>(v, tot, wsum);
     if ((int)threadIdx.x < nblocks) b.bt2[threadIdx.x] = make_uint4(v[0], v[1], v[2], v[3]);
-    if (threadIdx.x == 0) upd_decide_totals(st, tot, evict_ready, n_list);
+    if (threadIdx.x == 0) upd_decide_totals(st, tot, evict_ready, n_list, st->status);
 }
 
 // ---- eviction selection: the alive cells of the image as a list sorted by LRU stamp ------------------------------------------
@@ -472,12 +516,12 @@ ivox_upd_points(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState*
 // per voxel with an insertion sort in global memory, took up to 1.2 ms.)
 constexpr int kUpdFinishMaxK = 1024;  // new points of one voxel staged per wave; more than that: serial fallback by lane 0
 // one wave: the new points of touched voxel number t into id order (s_row: MAXK float4 of LDS owned by this wave), stamp, scratch reset
-template <int MAXK>
+template <int MAXK, bool COH = false>
 __device__ __forceinline__ void upd_finish_voxel(const IvoxUpdBatch& b, const IvoxUpdArrays& a, const IvoxUpdState* __restrict__ st, const unsigned t,
                                                  float4* __restrict__ s_row, const int lane) {
     const unsigned cell = b.tlist[t];
-    const uint2 e = upd_ld_cell(&a.cells[cell]);
-    const unsigned k = upd_ld(&a.pend[cell]);
+    const uint2 e = upd_ld_cell<COH>(&a.cells[cell]);
+    const unsigned k = upd_ld<COH>(&a.pend[cell]);
     float4* const q = a.pts + e.x + (e.y - k);
     if (k > 1u && k <= (unsigned)MAXK) {
         for (unsigned i = lane; i < k; i += 64) s_row[i] = q[i];
@@ -503,7 +547,7 @@ __device__ __forceinline__ void upd_finish_voxel(const IvoxUpdBatch& b, const Iv
         }
     }
     if (lane == 0) {
-        a.stamp[cell] = st->stamp_base + upd_ld(&a.rank_mm[cell]) + 1ull;
+        a.stamp[cell] = st->stamp_base + upd_ld<COH>(&a.rank_mm[cell]) + 1ull;
         a.pend[cell] = 0u;
         a.rank_mm[cell] = kUpdNoRank;
     }
@@ -578,7 +622,8 @@ ivox_upd_last_regions(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState*
     if ((int)blockIdx.x >= nblocks && blockIdx.x != 0) return;  // (block 0 always runs: it records the verdict, also of an empty batch)
     unsigned pre[4], tot[4], e;
     block_prefix_total<4>(b.bt2, nblocks, (int)blockIdx.x, pre, tot, wsum);  // bt2: raw block totals of ivox_upd_plan
-    const bool apply = upd_verdict(st, tot, 0u, 0u, e) == kUpdOk;  // the same words in every block: the same verdict
+    const unsigned status_in = st->status;  // (left by ivox_upd_seq_nb; block 0 stores the same bits back below)
+    const bool apply = upd_verdict(st, tot, 0u, 0u, status_in, e) == kUpdOk;  // the same words in every block: the same verdict
     const unsigned r = blockIdx.x * kUpdBlock + threadIdx.x;
     if (r < A) {
         const unsigned cell = b.seq_cell[r];
@@ -590,7 +635,7 @@ ivox_upd_last_regions(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState*
     }
     // the record of the verdict (read by the launches that follow); written last: the blocks above only READ the words it is made of,
     // and the status it stores is the one they computed
-    if (blockIdx.x == 0 && threadIdx.x == 0) upd_decide_totals(st, tot, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) upd_decide_totals(st, tot, 0u, 0u, status_in);
 }
 // points of rank r in the short chain: the block offsets of ivox_upd_plan were never scanned in place, nothing else differs
 // (ivox_upd_points serves both chains)
@@ -660,7 +705,7 @@ ivox_upd_fused_kernel(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState*
     unsigned v4[4] = {0u, 0u, 0u, 0u}, tot4[4];
     for (unsigned r = r_lo; r < r_hi; ++r) {
         unsigned inc[4];
-        const bool first = upd_plan_rank(b, a, r, inc);
+        const bool first = upd_plan_rank<true>(b, a, r, inc);
         b.fbit[r] = first ? 1 : 0;
         b.px[r] = make_uint4(v4[0], v4[1], v4[2], v4[3]);  // exclusive inside the slice
         v4[0] += inc[0]; v4[1] += inc[1]; v4[2] += inc[2]; v4[3] += inc[3];
@@ -668,7 +713,7 @@ ivox_upd_fused_kernel(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState*
     block_excl_scan<4>(v4, tot4, wsum4);
     s_base[t] = make_uint4(v4[0], v4[1], v4[2], v4[3]);
     if (t == 0) {
-        upd_decide_totals(st, tot4, 0u, 0u);  // (no eviction selection in this form: a batch that reaches the capacity is sent to the multi-launch form by the host)
+        upd_decide_totals(st, tot4, 0u, 0u, __hip_atomic_load(&st->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));  // (no eviction selection in this form: a batch that reaches the capacity is sent to the multi-launch form by the host)
         s_apply = st->apply;
     }
     __syncthreads();
@@ -685,12 +730,12 @@ ivox_upd_fused_kernel(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState*
         // ---- regions (slice order = first-touch order), points, per-voxel id order ----
         const uint4 base = s_base[t];
         for (unsigned r = r_lo; r < r_hi; ++r)
-            if (b.fbit[r]) { const uint4 loc = b.px[r]; upd_region_rank(b, a, st, r, base.x + loc.x, base.z + loc.z); }
+            if (b.fbit[r]) { const uint4 loc = b.px[r]; upd_region_rank<true>(b, a, st, r, base.x + loc.x, base.z + loc.z); }
         __syncthreads();
-        for (unsigned r = t; r < A; r += kFusedThreads) upd_point_rank(b, a, st, r);
+        for (unsigned r = t; r < A; r += kFusedThreads) upd_point_rank<true>(b, a, st, r);
         __syncthreads();
         const unsigned touched = tot4[2];
-        for (unsigned tv = w; tv < touched; tv += kFusedThreads / 64) upd_finish_voxel<kFusedFinishK>(b, a, st, tv, &s_pts[w][0], lane);
+        for (unsigned tv = w; tv < touched; tv += kFusedThreads / 64) upd_finish_voxel<kFusedFinishK, true>(b, a, st, tv, &s_pts[w][0], lane);
     }
     __syncthreads();
     if (t == 0) upd_commit(st, mb, seq, a.n_bricks_cap);

@@ -58,6 +58,9 @@ struct fls_matcher {
     }
     virtual fls_status add_cloud(const float* c0, size_t n0, const float* c1, size_t n1, int stride) = 0;
     virtual fls_status scan_upload(const float* s0, size_t n0, const float* s1, size_t n1, int stride) = 0;
+    // fls_match's upload: the Match follows at once, so a kind may leave the scan in its pinned staging buffer and let the first
+    // iteration's kernels read it from there (default: the ordinary upload)
+    virtual fls_status scan_upload_for_match(const float* s0, size_t n0, const float* s1, size_t n1, int stride) { return scan_upload(s0, n0, s1, n1, stride); }
     virtual fls_status match_resident(double* T, int update_map, fls_stats* out) = 0;
     virtual fls_status fitness(float max_range, float* score) = 0;
     virtual int correspondences(int slot, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) = 0;
@@ -261,6 +264,21 @@ struct DevScan {
     // until the next upload, which is all a map update of THIS resident scan needs (fls_match == fls_scan_upload +
     // fls_match_resident for either value of update_map).
     void upload_raw(const float* p, size_t count, int stride, hipStream_t s, bool intensity_too = false) {
+        stage_raw(p, count, stride);
+        if (n) push(s, intensity_too ? 4 : 3);  // the device VoxelGrid averages the intensity as well
+    }
+    // device-side address of the staging buffer (pinned host memory is mapped into the device's address space)
+    const float* stage_dev() const {
+        void* d = nullptr;
+        FLS_HIP(hipHostGetDevicePointer(&d, stage.p, 0));
+        return static_cast<const float*>(d);
+    }
+    // the device allocation x | y | z of the staged scan, without the copy (a kernel fills it: ivox_knn_kernel's first launch)
+    void reserve_device() {
+        xyz.reserve(size_t(3) * n);
+        x.p = xyz.p; y.p = xyz.p + n; z.p = xyz.p + 2 * n;
+    }
+    void stage_raw(const float* p, size_t count, int stride) {
         n = count;
         host.clear();
         if (n == 0) return;
@@ -298,7 +316,6 @@ struct DevScan {
             const float* q = p + i * stride;
             sx[i] = q[0]; sy[i] = q[1]; sz[i] = q[2]; si[i] = intensity_of(q, stride);
         }
-        push(s, intensity_too ? 4 : 3);  // the device VoxelGrid averages the intensity as well
     }
     float staged_intensity(size_t i) const { return stage.p[3 * n + i]; }
     void upload(const std::vector<PtI>& c, hipStream_t s) {

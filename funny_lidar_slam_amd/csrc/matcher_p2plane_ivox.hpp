@@ -39,6 +39,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     bool fused_update = false;     // FLS_IVOX_FUSED_UPDATE=1 (A/B): small batches as ONE launch of one workgroup
     bool short_chain_update = true;  // FLS_IVOX_SHORT_CHAIN=0 (A/B): the round-3 chain of eleven launches for every batch
     size_t n_fused_updates = 0, n_short_updates = 0;
+    bool fused_commit = false;     // FLS_IVOX_FUSED_COMMIT=1 (A/B): the last finishing block publishes instead of a commit launch (measured slower: 15-26 us against 4.6 + 4.1 us)
+    int finish_blocks = kFinishBlocks;  // FLS_IVOX_FINISH_BLOCKS (A/B)
     bool device_evict = true;      // FLS_IVOX_DEVICE_EVICT=0: a batch that reaches the LRU capacity is refused (round-2 behaviour, with the margin rule)
     DevicePairSort ev_sort;
     DevBuf<unsigned> d_ev_bt, d_crank, d_evict_list;
@@ -77,6 +79,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     bool nn_ids_mode = true;          // FLS_IVOX_NN_IDS=0: the kNN kernel writes gathered rows (round-2 behaviour)
     bool nn_rows_current = true;      // every list is in rows form
     size_t nn_n = 0;              // logical size of nearest_points_
+    int nn_prev = 0;              // its size before the Match in flight
     DevBuf<double> d_J;           // [7][n]
     DevBuf<unsigned char> d_flag;
     size_t number_planar_point = 0;
@@ -109,6 +112,9 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (const char* e = std::getenv("FLS_IVOX_DEVICE_EVICT")) device_evict = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_FUSED_UPDATE")) fused_update = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_SHORT_CHAIN")) short_chain_update = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_IVOX_HOST_SRC")) host_src = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_IVOX_FUSED_COMMIT")) fused_commit = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_IVOX_FINISH_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) finish_blocks = v; }
         d_upd_state.reserve(1);
         FLS_HIP(hipHostMalloc((void**)&upd_mb_host, sizeof(IvoxUpdMailbox), hipHostMallocMapped));
         std::memset(upd_mb_host, 0, sizeof(IvoxUpdMailbox));
@@ -208,7 +214,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         d_px.reserve(n); d_bt2.reserve(size_t(nb)); d_fbit.reserve(n);
         const IvoxUpdBatch b{d_code.p, d_pw.p, int(n), d_lx.p, d_bt.p, d_seq_src.p, d_seq_cell.p, d_jj.p, d_px.p, d_bt2.p, d_fbit.p, d_tlist.p};
         const IvoxUpdArrays a{image.d_cells.p, image.d_pts.p, image.d_cap_log2.p, image.d_stamp.p, image.d_pend.p, image.d_rank_mm.p,
-                              image.d_dir.p, image.dir_mask, unsigned(image.n_bricks_cap), image.d_brick_key.p, ivox.inv_resolution};
+                              image.d_dir.p, image.dir_mask, unsigned(image.n_bricks_cap), image.d_brick_key.p, image.d_nbr.p, ivox.inv_resolution};
         upd_seq = (upd_seq + 1u) & 0x7fffffffu;
         if (upd_seq == 0u) upd_seq = 1u;
         const dim3 g{unsigned(nb), 1u, 1u}, t{unsigned(kUpdBlock), 1u, 1u};
@@ -226,8 +232,13 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             hipLaunchKernelGGL(ivox_upd_plan, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
             hipLaunchKernelGGL(ivox_upd_last_regions, g, t, 0, stream, b, a, d_upd_state.p);
             hipLaunchKernelGGL(ivox_upd_points, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
-            const unsigned fb = unsigned(std::min<size_t>(size_t(kFinishBlocks), (n + kUpdBlock / 64 - 1) / (kUpdBlock / 64)));
-            hipLaunchKernelGGL(ivox_upd_finish_commit, dim3(fb), t, 0, stream, b, a, d_upd_state.p, upd_mb_dev, upd_seq, d_ticket.p);
+            if (fused_commit) {
+                const unsigned fb = unsigned(std::min<size_t>(size_t(finish_blocks), (n + kUpdBlock / 64 - 1) / (kUpdBlock / 64)));
+                hipLaunchKernelGGL(ivox_upd_finish_commit, dim3(fb), t, 0, stream, b, a, d_upd_state.p, upd_mb_dev, upd_seq, d_ticket.p);
+            } else {
+                hipLaunchKernelGGL(ivox_upd_finish, dim3(unsigned((n + kUpdBlock / 64 - 1) / (kUpdBlock / 64))), t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
+                hipLaunchKernelGGL(ivox_upd_commit, dim3(1), dim3(64), 0, stream, d_upd_state.p, upd_mb_dev, upd_seq, unsigned(image.n_bricks_cap));
+            }
             ++n_short_updates;
         } else {
         hipLaunchKernelGGL(ivox_upd_count, g, t, 0, stream, b);
@@ -350,8 +361,6 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             if (n) {
                 d_code.reserve(n);
                 d_pw.reserve(n);
-                h_code.resize(n);
-                h_pw.resize(n);
                 Pose16 Tw;
                 std::memcpy(Tw.m, T_, sizeof(Tw.m));
                 // device mode: the decision launch also counts the insertion codes per block and opens the batch (ivox_upd_count's job)
@@ -390,6 +399,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
                     ++n_host_fallbacks;
                     sync_host_from_device();
                 }
+                h_code.resize(n);  // (host copies only on this path: the device applied nothing)
+                h_pw.resize(n);
                 FLS_HIP(hipMemcpyAsync(h_code.data(), d_code.p, n, hipMemcpyDeviceToHost, stream));
                 FLS_HIP(hipMemcpyAsync(h_pw.data(), d_pw.p, n * sizeof(float4), hipMemcpyDeviceToHost, stream));
                 FLS_HIP(hipStreamSynchronize(stream));
@@ -463,7 +474,21 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         return rc;
     }
 
+    // fls_match from host buffers: the scan stays in the pinned staging buffer; the first iteration's correspondence launch reads it
+    // from there over PCIe (the kernel is latency bound: the reads hide behind its probe / candidate chains) and leaves the device copy
+    // the later launches use.  No SDMA copy, no copy-engine -> compute-queue hand-off in front of the first kernel (8 us + 8 us for the
+    // 10 k-point planar cloud the pipeline feeds; FLS_IVOX_HOST_SRC=0 restores the copy).
+    bool host_src = true, scan_in_staging = false;
+    fls_status scan_upload_for_match(const float* s0, size_t n0, const float* s1, size_t n1, int stride) override {
+        if (!host_src || borrowed) return scan_upload(s0, n0, s1, n1, stride);
+        (void)s1; (void)n1;
+        scan.stage_raw(s0, n0, stride);
+        scan_in_staging = n0 != 0;
+        if (scan_in_staging) scan.reserve_device();
+        return FLS_OK;
+    }
     fls_status scan_upload(const float* s0, size_t n0, const float* s1, size_t n1, int stride) override {
+        scan_in_staging = false;
         (void)s1; (void)n1;
         // (the pinned staging buffer is free again: fls_scan_upload synchronises, a Match ends after its copies)
         scan.upload_raw(s0, n0, stride, stream);
@@ -477,18 +502,25 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     void launch_knn(const size_t n, const int first, const Pose16& T0, const DevGrid& g, const BrickDir& win, hipEvent_t e0 = nullptr,
                     hipEvent_t e1 = nullptr) {
         unsigned* const ids_arg = nn_ids_mode ? d_nn_ids.p : nullptr;
+        // first launch of a Match whose scan is still in the staging buffer: read it there, write the device copy
+        const bool from_host = first && scan_in_staging;
+        const float* const hx = from_host ? scan.stage_dev() : nullptr;
+        const float* const src_x = from_host ? hx : (const float*)scan.x.p;
+        const float* const src_y = from_host ? hx + n : (const float*)scan.y.p;
+        const float* const src_z = from_host ? hx + 2 * n : (const float*)scan.z.p;
+        float* const dev_copy = from_host ? scan.xyz.p : nullptr;
         const size_t nblk = (n * G + 255) / 256, gran = size_t(8) * size_t(xcd_chunk);
         const dim3 grid(unsigned((nblk + gran - 1) / gran * gran));  // multiple of 8 * chunk: the XCD re-map is a bijection
 #define FLS_KNN_L(C, D, F, B)                                                                                                        \
     do {                                                                                                                             \
         if (e0 || !plain_launch)                                                                                                     \
-            hipExtLaunchKernelGGL((ivox_knn_kernel<G, C, D, F, B>), grid, dim3(256), 0, stream, e0, e1, 0, (const float*)scan.x.p,   \
-                                  (const float*)scan.y.p, (const float*)scan.z.p, int(n), (const GnState*)d_state.p, T0, g, win,    \
-                                  ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p, xcd_chunk, ids_arg);                   \
+            hipExtLaunchKernelGGL((ivox_knn_kernel<G, C, D, F, B>), grid, dim3(256), 0, stream, e0, e1, 0, src_x,                    \
+                                  src_y, src_z, int(n), (const GnState*)d_state.p, T0, g, win,                                      \
+                                  ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p, xcd_chunk, ids_arg, nn_prev, dev_copy); \
         else                                                                                                                         \
-            hipLaunchKernelGGL((ivox_knn_kernel<G, C, D, F, B>), grid, dim3(256), 0, stream, (const float*)scan.x.p,                 \
-                               (const float*)scan.y.p, (const float*)scan.z.p, int(n), (const GnState*)d_state.p, T0, g, win,       \
-                               ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p, xcd_chunk, ids_arg);                      \
+            hipLaunchKernelGGL((ivox_knn_kernel<G, C, D, F, B>), grid, dim3(256), 0, stream, src_x,                                  \
+                               src_y, src_z, int(n), (const GnState*)d_state.p, T0, g, win,                                         \
+                               ivox.inv_resolution, d_nn.p, d_nn_cnt.p, d_flag.p, d_tc.p, xcd_chunk, ids_arg, nn_prev, dev_copy);   \
     } while (0)
 #define FLS_KNN(C, D)                                                                                                                \
     do {                                                                                                                             \
@@ -520,7 +552,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         d_nn.reserve(n * 5, /*keep=*/true, stream);
         d_nn_cnt.reserve(n, /*keep=*/true, stream);
         if (nn_ids_mode) d_nn_ids.reserve(n * 8, /*keep=*/true, stream);
-        if (n > nn_n) FLS_HIP(hipMemsetAsync(d_nn_cnt.p + nn_n, 0, n - nn_n, stream));
+        nn_prev = int(std::min(nn_n, n));  // the first iteration's kNN launch clears the counts of the grown tail [nn_prev, n)
         nn_n = n;
         d_J.reserve(7 * n);
         d_flag.reserve(n);  // cleared by the first iteration's kNN kernel (std::fill(flags, false) once per Match, :156, Q1)
@@ -558,6 +590,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
 #undef FLS_FIT_NT
 #undef FLS_FIT
         });
+        scan_in_staging = false;  // (the first launch left the device copy)
         if (nn_ids_mode) nn_rows_current = false;  // the lists of every point with candidates are slots of the current image now
         const Mailbox& mb = *mb_host;
         const int used = int(word & 0xffu);
