@@ -5,6 +5,7 @@
 // decides the number of radix passes and the "leaf size too small" refusal, voxel_grid.hpp:69-74) and the output size.
 #pragma once
 #include "kernels_voxelgrid.hpp"
+#include "kernels_exactsort.hpp"
 #include "kernels_gridbuild.hpp"
 #include "matcher_base.hpp"
 #include <cstdlib>
@@ -51,8 +52,106 @@ struct DevicePairSort {
     }
 };
 
+// std::sort's permutation of {key, value} records on the device (kernels_exactsort.hpp), in place.  The host only steers the level
+// loop: it enqueues the expected number of regime-1 levels, polls a host-mapped word (no stream synchronisation) and tops up two
+// levels at a time while ranges longer than kEsLds remain; one es_lds_kernel launch finishes every range.
+struct DeviceExactSort {
+    DevBuf<EsSeg> seg_a, seg_b;
+    DevBuf<EsWork> work;
+    DevBuf<uint2> tile_cnt;
+    DevBuf<unsigned> tile_seg, Lp, Rl;
+    DevBuf<EsState> st;
+    PinnedBuf<EsState> h_st;
+    EsMailbox* mb_host = nullptr;
+    EsMailbox* mb_dev = nullptr;
+    unsigned seq = 0;
+    unsigned long long runs = 0, failures = 0, levels = 0;
+    ~DeviceExactSort() { if (mb_host) (void)hipHostFree(mb_host); }
+    unsigned wait(const unsigned want, hipStream_t s) {
+        for (unsigned long long spin = 1;; ++spin) {
+            if (__atomic_load_n(&mb_host->seq, __ATOMIC_ACQUIRE) == want) return want;
+            if ((spin & 0x3fffu) == 0) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) return __atomic_load_n(&mb_host->seq, __ATOMIC_ACQUIRE);
+                if (q != hipErrorNotReady) FLS_HIP(q);
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    // queues the whole sort on `s`; false: refused before anything ran (sizes).  The verdict of the sort itself (introsort's heap-sort
+    // case) is only known once the stream has drained: failed_after_sync().
+    bool run(unsigned* key, unsigned* val, const size_t n, hipStream_t s) {
+        if (n > (size_t(1) << 22)) return false;
+        if (n < 2) return true;
+        if (!mb_host) {
+            FLS_HIP(hipHostMalloc((void**)&mb_host, sizeof(EsMailbox), hipHostMallocMapped));
+            std::memset(mb_host, 0, sizeof(EsMailbox));
+            FLS_HIP(hipHostGetDevicePointer((void**)&mb_dev, mb_host, 0));
+        }
+        ++runs;
+        const unsigned work_cap = unsigned(64 * (n / kEsLds + 1) + 1024);
+        const unsigned tile_cap = unsigned(n / kEsTile + n / kEsLds + 2);
+        seg_a.reserve(kEsMaxSeg); seg_b.reserve(kEsMaxSeg);
+        work.reserve(work_cap);
+        tile_cnt.reserve(tile_cap); tile_seg.reserve(tile_cap);
+        Lp.reserve(n); Rl.reserve(n);
+        st.reserve(1);
+        h_st.reserve(1);
+        auto next_seq = [&]() { seq = (seq + 1u) & 0x7fffffffu; if (!seq) seq = 1u; return seq; };
+        EsSeg* prev = seg_a.p;
+        EsSeg* cur = seg_b.p;
+        hipLaunchKernelGGL(es_level_begin, dim3(1), dim3(256), 0, s, key, val, unsigned(n), (const EsSeg*)prev, cur, work.p, work_cap, (const unsigned*)Lp.p,
+                           (const unsigned*)Rl.p, st.p, mb_dev, next_seq(), 1, tile_seg.p, tile_cap);
+        int expected = 0;
+        for (size_t m = n; m > size_t(kEsLds); m = (m + 1) / 2) ++expected;
+        int chunk = n > size_t(kEsLds) ? expected + 1 : 0;
+        for (;;) {
+            for (int c = 0; c < chunk; ++c) {
+                hipLaunchKernelGGL(es_count_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, (const unsigned*)key, (const EsSeg*)cur, (const EsState*)st.p,
+                                   (const unsigned*)tile_seg.p, tile_cnt.p);
+                hipLaunchKernelGGL(es_scatter_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, (const unsigned*)key, cur, (const EsState*)st.p, (const unsigned*)tile_seg.p,
+                                   (const uint2*)tile_cnt.p, Lp.p, Rl.p);
+                hipLaunchKernelGGL(es_swap_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, key, val, cur, (const EsState*)st.p, (const unsigned*)tile_seg.p,
+                                   (const unsigned*)Lp.p, (const unsigned*)Rl.p);
+                std::swap(prev, cur);
+                hipLaunchKernelGGL(es_level_begin, dim3(1), dim3(256), 0, s, key, val, unsigned(n), (const EsSeg*)prev, cur, work.p, work_cap, (const unsigned*)Lp.p,
+                                   (const unsigned*)Rl.p, st.p, mb_dev, next_seq(), 0, tile_seg.p, tile_cap);
+                ++levels;
+            }
+            FLS_HIP(hipGetLastError());
+            wait(seq, s);
+            if (mb_host->fail) { ++failures; return false; }
+            if (mb_host->n_cur == 0u) break;
+            chunk = 2;
+        }
+        const unsigned n_work = mb_host->n_work;
+        if (n_work) hipLaunchKernelGGL(es_lds_kernel, dim3(std::min(n_work, 2048u)), dim3(kEsLdsThreads), 0, s, key, val, (const EsWork*)work.p, st.p);
+        FLS_HIP(hipMemcpyAsync(h_st.p, st.p, sizeof(EsState), hipMemcpyDeviceToHost, s));
+        FLS_HIP(hipGetLastError());
+        return true;
+    }
+    // after the caller's stream synchronisation: did a range hit introsort's depth limit inside es_lds_kernel?
+    bool failed_after_sync() {
+        if (h_st.p && h_st.p->fail) { ++failures; return true; }
+        return false;
+    }
+};
+
+// FLS_DEVICE_VOXELGRID: 1 (default) the device filters, leaf sums in std::sort's order = bit-identical to pcl::VoxelGrid (round 4);
+// 0 the exact host filter (worker pool); 2 the device filters with the round-2/3 contract (stable radix sort: leaf sums in ascending
+// point index, last-bit differences on leaves of three or more points) -- A/B only.
+inline int device_voxelgrid_mode() {
+    if (const char* e = std::getenv("FLS_DEVICE_VOXELGRID")) { const int v = std::atoi(e); return v < 0 ? 0 : v > 2 ? 1 : v; }
+    return 1;
+}
+
 struct DeviceVoxelGrid {
     DevicePairSort sort;
+    DeviceExactSort exact;
+    bool exact_order = device_voxelgrid_mode() != 2;  // centroids summed in std::sort's order; false: ascending point index
+    unsigned long long exact_runs = 0, exact_declined = 0;
     DevBuf<unsigned> lx, bt;        // bt: block totals | scanned
     DevBuf<float4> sorted;          // the points in sorted order
     DevBuf<float> out;            // x | y | z | i, capacity n each
@@ -109,7 +208,13 @@ struct DeviceVoxelGrid {
         sorted.reserve(n);
         out.reserve(4 * n);
         hipLaunchKernelGGL(vg_index, dim3(unsigned(nb1)), dim3(kVgBlock), 0, s, x, y, z, ni, g, sort.k0, sort.v0);
-        sort.run(passes, s);
+        if (exact_order) {
+            // the reference sorts the FINITE points only (non-finite ones never enter its index vector): a cloud with any is the host's
+            if (hh.n_bad != 0u || !exact.run(sort.k0, sort.v0, n, s)) { ++exact_declined; return false; }
+            ++exact_runs;
+        } else {
+            sort.run(passes, s);
+        }
         unsigned* const k0 = sort.k0;
         unsigned* const v0 = sort.v0;
         hipLaunchKernelGGL(vg_heads, dim3(unsigned(nb2)), dim3(kVgScanBlock), 0, s, (const unsigned*)k0, (const unsigned*)v0, ni, g.total, x, y, z, in,
@@ -120,6 +225,7 @@ struct DeviceVoxelGrid {
         FLS_HIP(hipMemcpyAsync(&h_hdr.p[1], d_hdr.p, sizeof(VgHeader), hipMemcpyDeviceToHost, s));
         FLS_HIP(hipStreamSynchronize(s));
         FLS_HIP(hipGetLastError());
+        if (exact_order && exact.failed_after_sync()) { ++exact_declined; return false; }  // (introsort's heap-sort case: the host path sorts)
         n_out = h_hdr.p[1].n_out;
         return true;
     }
@@ -267,12 +373,12 @@ struct DeviceCloudRing {
     }
 };
 
-// Map maintenance of one kd-tree kind on the device: the cell-grid build (exact: default) and, opt-in with
-// FLS_DEVICE_VOXELGRID=1, the deque + map-side pcl::VoxelGrid (same centroid contract as the source filter,
-// kernels_voxelgrid.hpp).  The host deque stays authoritative: whatever the device declines is redone by the host path.
+// Map maintenance of one kd-tree kind on the device: the cell-grid build and the deque + map-side pcl::VoxelGrid (bit-identical to
+// the reference's since round 4: kernels_exactsort.hpp; FLS_DEVICE_VOXELGRID=0 = the host filter).  The host deque stays
+// authoritative: whatever the device declines is redone by the host path.
 struct KdMapDevice {
     bool grid_on_device = true;  // FLS_DEVICE_GRID_BUILD=0: host std::sort + bucket loop + upload (A/B)
-    bool vg_on_device = false;   // FLS_DEVICE_VOXELGRID=1
+    bool vg_on_device = true;    // FLS_DEVICE_VOXELGRID=0: the host filter
     DeviceGridBuilder builder;
     DeviceVoxelGrid vg;
     PinnedBuf<float> stage;
@@ -280,7 +386,7 @@ struct KdMapDevice {
     unsigned long long device_filters = 0, host_filters = 0;
     void init() {
         if (const char* e = std::getenv("FLS_DEVICE_GRID_BUILD")) grid_on_device = std::atoi(e) != 0;
-        if (const char* e = std::getenv("FLS_DEVICE_VOXELGRID")) vg_on_device = std::atoi(e) != 0;
+        vg_on_device = device_voxelgrid_mode() != 0;
     }
     // grid over a HOST cloud (the exact host filter's output, or an unfiltered cloud)
     fls_status build_from_host(CellGridImage& grid, const std::vector<PtI>& cloud, float cell, hipStream_t s, int rings = 1, bool by_id = false) {
@@ -315,18 +421,18 @@ struct KdMapDevice {
     }
 };
 
-// the source-scan filter of the kd-tree / NDT matchers (icp_optimized.h:57, incremental_ndt.h:232): host std::sort path by
-// default, the device path with FLS_DEVICE_VOXELGRID=1.  With the device path the filtered cloud stays on the device; the
-// host copy is fetched only when a map update needs it.
+// the source-scan filter of the kd-tree / NDT matchers (icp_optimized.h:57, incremental_ndt.h:232): on the device (default), the
+// host std::sort path with FLS_DEVICE_VOXELGRID=0 and for whatever the device declines.  With the device path the filtered cloud
+// stays on the device; the host copy is fetched only when a map update needs it.
 struct SourceFilter {
-    bool on_device = false;
+    bool on_device = true;
     DevScan raw;
     DeviceVoxelGrid vg;
     bool resident = false;  // `source` has not been downloaded yet
     std::vector<float> tmp;
     unsigned long long device_runs = 0, host_runs = 0;
     void init() {
-        if (const char* e = std::getenv("FLS_DEVICE_VOXELGRID")) on_device = std::atoi(e) != 0;
+        on_device = device_voxelgrid_mode() != 0;
     }
     void filter(const float* s0, size_t n0, int stride, float leaf, hipStream_t s, DevScan& scan, std::vector<PtI>& source) {
         resident = false;

@@ -311,6 +311,32 @@ fls_status fls_debug_voxel_grid(int device_id, const float* pts, size_t n, int s
     });
 }
 
+fls_status fls_debug_exact_sort(int device_id, uint32_t* key, uint32_t* val, size_t n, int on_host) {
+    if ((!key || !val) && n) return FLS_ERR_INVALID;
+    if (on_host) {
+        std::vector<VoxelLeafRec> r(n);
+        for (size_t i = 0; i < n; ++i) r[i] = VoxelLeafRec{key[i], val[i]};
+        std::sort(r.begin(), r.end());  // operator< compares idx only: libstdc++'s introsort decides the order of equal keys
+        for (size_t i = 0; i < n; ++i) { key[i] = r[i].idx; val[i] = r[i].pt; }
+        return FLS_OK;
+    }
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(device_id));
+        if (n == 0) return FLS_OK;
+        DevBuf<unsigned> dk, dv;
+        dk.reserve(n); dv.reserve(n);
+        FLS_HIP(hipMemcpy(dk.p, key, n * sizeof(unsigned), hipMemcpyHostToDevice));
+        FLS_HIP(hipMemcpy(dv.p, val, n * sizeof(unsigned), hipMemcpyHostToDevice));
+        DeviceExactSort es;
+        const bool queued = es.run(dk.p, dv.p, n, nullptr);
+        FLS_HIP(hipDeviceSynchronize());
+        if (!queued || es.failed_after_sync()) return FLS_ERR_STATE;
+        FLS_HIP(hipMemcpy(key, dk.p, n * sizeof(unsigned), hipMemcpyDeviceToHost));
+        FLS_HIP(hipMemcpy(val, dv.p, n * sizeof(unsigned), hipMemcpyDeviceToHost));
+        return FLS_OK;
+    });
+}
+
 fls_status fls_voxel_grid_cloud(int device_id, fls_voxelgrid_mode mode, const float* pts, size_t n, int stride, float leaf, float* out, size_t cap,
                                 size_t* n_out) {
     if (mode == FLS_VOXELGRID_DEVICE) return fls_debug_voxel_grid(device_id, pts, n, stride, leaf, out, cap, n_out);

@@ -255,6 +255,11 @@ fls_status fls_debug_fullpiv_qr6(int device_id, const double* H, const double* g
  * point / PCL's "leaf size too small" case / n > 4,194,304: the matchers then run the host filter), FLS_ERR_INVALID when
  * out is too small (*n_out is still set).  Contract: csrc/kernels_voxelgrid.hpp; tests/test_gpu_voxelgrid.py.          */
 fls_status fls_debug_voxel_grid(int device_id, const float* pts, size_t n, int stride, float leaf, float* out, size_t cap, size_t* n_out);
+/* Test hook of the device VoxelGrid's sort (csrc/kernels_exactsort.hpp): sorts the n records {key[i], val[i]} in place BY KEY ONLY, leaving
+ * records of equal key in exactly the order libstdc++'s std::sort leaves them in (what pcl::VoxelGrid's leaf sums depend on,
+ * include/common/pointcloud_utility.h:216-271).  on_host = 1: std::sort on the host (the reference permutation, no GPU needed);
+ * on_host = 0: the device kernels.  FLS_ERR_STATE: the device declined (introsort's heap-sort case / more than 4 Mi records). */
+fls_status fls_debug_exact_sort(int device_id, uint32_t* key, uint32_t* val, size_t n, int on_host);
 
 const char* fls_status_string(int status);
 int fls_abi_version(void);

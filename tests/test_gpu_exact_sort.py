@@ -1,0 +1,72 @@
+"""std::sort's permutation on the device (csrc/kernels_exactsort.hpp) against std::sort itself (libstdc++, through the same C entry
+point with on_host = 1): records {key, value} compared by key only, so the order of equal keys is introsort's business -- and what
+pcl::VoxelGrid's leaf sums depend on.  The device result must equal the host's record for record."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from funny_lidar_slam_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(built):
+    assert _lib.device_count() >= 1, "gpu tests need an MI355X (gfx950): the HIP path has no CPU fallback"
+
+
+def sort_both(key):
+    L = _lib.lib()
+    val = np.arange(key.size, dtype=np.uint32)
+    out = []
+    for on_host in (1, 0):
+        k, v = key.astype(np.uint32).copy(), val.copy()
+        rc = L.fls_debug_exact_sort(0, k.ctypes.data_as(C.POINTER(C.c_uint32)), v.ctypes.data_as(C.POINTER(C.c_uint32)), k.size, on_host)
+        out.append((rc, k, v))
+    return out
+
+
+def check(key, label):
+    (rh, kh, vh), (rd, kd, vd) = sort_both(key)
+    assert rh == 0 and rd == 0, (label, rh, rd)
+    assert np.array_equal(kh, kd), label
+    bad = np.flatnonzero(vh != vd)
+    assert bad.size == 0, (label, key.size, bad[:5], vh[bad[:5]], vd[bad[:5]])
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 15, 16, 17, 33, 100, 1000, 4095, 4096, 4097, 8193, 20000, 115200, 300001])
+def test_random_keys_with_ties(n):
+    rng = np.random.default_rng(n + 1)
+    for hi in (3, max(2, n // 50 + 1), max(2, n // 3 + 1), 1 << 30):
+        check(rng.integers(0, hi, n), f"n={n} range={hi}")
+
+
+def test_structured_inputs():
+    rng = np.random.default_rng(5)
+    n = 60000
+    base = rng.integers(0, 5000, n)
+    check(np.sort(base), "sorted")
+    check(np.sort(base)[::-1].copy(), "reversed")
+    check(np.zeros(n, np.int64), "all equal")
+    check(np.repeat(np.arange(n // 6), 6), "runs of six")
+    check(np.tile(np.arange(300), n // 300), "sawtooth")
+    k = np.sort(base); k[::97] = rng.integers(0, 5000, k[::97].size)
+    check(k, "nearly sorted")
+
+
+def test_leaf_indices_of_a_real_scan():
+    """the keys the VoxelGrid actually sorts: leaf indices of a ring-major 64 x 1800 scan at the NDT / ICP leaf sizes"""
+    cfg = synth.make_config(2)
+    for leaf in (0.5, 0.1, 1.0):
+        p = cfg["scan"].astype(np.float32)
+        inv = np.float32(1.0) / np.float32(leaf)
+        q = np.floor(p * inv).astype(np.int64)
+        q -= q.min(0)
+        d = q.max(0) + 1
+        check(q[:, 0] + q[:, 1] * d[0] + q[:, 2] * d[0] * d[1], f"scan leaf={leaf}")
+
+
+def test_large_cloud_many_levels():
+    rng = np.random.default_rng(9)
+    check(rng.integers(0, 200000, 1400000), "1.4 M records (a LoamFull planar deque)")

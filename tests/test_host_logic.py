@@ -14,3 +14,11 @@ def test_host_bookkeeping(built, tmp_path):
     subprocess.check_call(cmd)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "host logic ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_exact_sort_closed_form_model(tmp_path):
+    """The partition closed form the device sort is built on (tests/host/exact_sort_model_test.cpp) reproduces std::sort's permutation."""
+    exe = os.path.join(str(tmp_path), "exact_sort_model_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "host", "exact_sort_model_test.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
