@@ -204,12 +204,13 @@ def bench_other_configs(reg, synth, util, O, budget_s=6.0):
         m.set_profiling(False)
         iters = int(m.stats.iterations)
         T_gpu = np.array(Tv)
-        # fls_match from HOST buffers (upload + source VoxelGrid + Match): exact host filter (default) vs the opt-in device filter
+        # fls_match from HOST buffers (upload + source VoxelGrid + Match): the device filter in std::sort's order (default since round 4,
+        # bit-identical to the host filter), the exact host filter, and the round-2/3 device filter (leaf sums in point-index order, A/B)
         from_host = None
         if mode in ("IcpOptimized", "IncrementalNDT"):
             from_host = {}
             prev = os.environ.get("FLS_DEVICE_VOXELGRID")
-            for label, env in (("host_filter_exact_default", "0"), ("device_filter_opt_in", "1")):
+            for label, env in (("device_filter_exact_default", "1"), ("host_filter_exact", "0"), ("device_filter_index_order_ab", "2")):
                 os.environ["FLS_DEVICE_VOXELGRID"] = env
                 m2 = reg.make_matcher(mode, y, is_localization_mode=loc)
                 m2.AddCloudToLocalMap(maps)
@@ -377,7 +378,8 @@ def bench_kd_mapping_mode(reg, synth, n_scans=6):
             Tgt = Tgt @ step
         world = lambda c, T: (c.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
         res = {}
-        for setting, env in (("host_path_round2", ("0", "0")), ("default_device_grid_build", ("1", "0")), ("device_deque_filter_grid_opt_in", ("1", "1"))):
+        for setting, env in (("host_path_round2", ("0", "0")), ("host_filter_device_grid_build_round3_default", ("1", "0")), ("default_device_filter_exact", ("1", "1")),
+                             ("device_filter_index_order_ab", ("1", "2"))):
             os.environ.update(dict(zip(keys, env)))
             m = reg.make_matcher(mode, y)
             s0, c0, T0 = frames[0]
@@ -396,7 +398,7 @@ def bench_kd_mapping_mode(reg, synth, n_scans=6):
                             "map_points_after": [m.map_size(0)] + ([m.map_size(1)] if cid == 3 else []),
                             "grids_built_on_device": m.map_size(114), "map_filters_on_device": m.map_size(115), "map_filters_on_host": m.map_size(116)}
             m.close()
-        a, b = res["host_path_round2"]["ms_keyframe_update_only"], res["device_deque_filter_grid_opt_in"]["ms_keyframe_update_only"]
+        a, b = res["host_path_round2"]["ms_keyframe_update_only"], res["default_device_filter_exact"]["ms_keyframe_update_only"]
         res["keyframe_update_speedup_device_vs_host"] = a / b if b > 0 else None
         res["deque_frames_at_timing"] = prefill + 1
         out[label] = res
@@ -446,7 +448,8 @@ def baseline_metric():
 def bench_ndt_mapping_mode(reg, synth, n_scans=6):
     """configs[2] as the ROS adapter issues it: fls_match from HOST buffers with update_map = 1 (source VoxelGrid + Match + the
     reference's in-Match AddCloud), three settings: everything the round-1 way on the host, the device map update behind the
-    exact host filters (default), and the opt-in device filters (the whole chain on the device)."""
+    exact host filters (the round-3 default), the device filters in std::sort order (default since round 4: bit-identical, the whole chain on the
+    device) and the round-2/3 device filters (leaf sums in point-index order) for A/B."""
     cfg = synth.make_config(2)
     rng = synth.rng_for(2, 321)
     Tgt = cfg["T_gt"].copy()
@@ -457,7 +460,8 @@ def bench_ndt_mapping_mode(reg, synth, n_scans=6):
     out = {}
     keys = ("FLS_NDT_DEVICE_UPDATE", "FLS_DEVICE_VOXELGRID")
     prev = {k: os.environ.get(k) for k in keys}
-    for label, env in (("host_update_host_filters", ("0", "0")), ("device_update_host_filters_default", ("1", "0")), ("device_update_device_filters_opt_in", ("1", "1"))):
+    for label, env in (("host_update_host_filters", ("0", "0")), ("device_update_host_filters_round3_default", ("1", "0")), ("default_device_update_device_filters_exact", ("1", "1")),
+                       ("device_update_device_filters_index_order_ab", ("1", "2"))):
         os.environ.update(dict(zip(keys, env)))
         m = reg.make_matcher("IncrementalNDT", reg.YAML_NCLT_NDT)
         m.AddCloudToLocalMap([cfg["map"]])

@@ -52,21 +52,26 @@ struct DevicePairSort {
     }
 };
 
-// std::sort's permutation of {key, value} records on the device (kernels_exactsort.hpp), in place.  The host only steers the level
-// loop: it enqueues the expected number of regime-1 levels, polls a host-mapped word (no stream synchronisation) and tops up two
-// levels at a time while ranges longer than kEsLds remain; one es_lds_kernel launch finishes every range.
+// std::sort's permutation of {key, value} records on the device (kernels_exactsort.hpp), in place.  Clouds up to kEsTaskMax records
+// (every source scan) are ONE begin launch + ONE persistent task launch; beyond that the host steers the level-synchronous top of the
+// recursion: it enqueues the expected number of levels, polls a host-mapped word (no stream synchronisation) and tops up two levels
+// at a time while ranges longer than kEsTaskMax remain.
+inline EsMailbox*& es_debug_mailbox() { static EsMailbox* p = nullptr; return p; }  // the last sort's host-mapped words (diagnostics)
 struct DeviceExactSort {
     DevBuf<EsSeg> seg_a, seg_b;
     DevBuf<EsWork> work;
     DevBuf<uint2> tile_cnt;
     DevBuf<unsigned> tile_seg, Lp, Rl;
     DevBuf<EsState> st;
+    DevBuf<EsQueue> queue;
+    DevBuf<unsigned> ready;
     PinnedBuf<EsState> h_st;
+    PinnedBuf<EsQueue> h_queue;
     EsMailbox* mb_host = nullptr;
     EsMailbox* mb_dev = nullptr;
     unsigned seq = 0;
     unsigned long long runs = 0, failures = 0, levels = 0;
-    ~DeviceExactSort() { if (mb_host) (void)hipHostFree(mb_host); }
+    ~DeviceExactSort() { if (es_debug_mailbox() == mb_host) es_debug_mailbox() = nullptr; if (mb_host) (void)hipHostFree(mb_host); }
     unsigned wait(const unsigned want, hipStream_t s) {
         for (unsigned long long spin = 1;; ++spin) {
             if (__atomic_load_n(&mb_host->seq, __ATOMIC_ACQUIRE) == want) return want;
@@ -90,23 +95,43 @@ struct DeviceExactSort {
             std::memset(mb_host, 0, sizeof(EsMailbox));
             FLS_HIP(hipHostGetDevicePointer((void**)&mb_dev, mb_host, 0));
         }
+        es_debug_mailbox() = mb_host;
         ++runs;
         const unsigned work_cap = unsigned(64 * (n / kEsLds + 1) + 1024);
-        const unsigned tile_cap = unsigned(n / kEsTile + n / kEsLds + 2);
+        const unsigned tile_cap = unsigned(n / kEsTile + n / kEsTaskMax + 2);
         seg_a.reserve(kEsMaxSeg); seg_b.reserve(kEsMaxSeg);
         work.reserve(work_cap);
+        ready.reserve(work_cap);
         tile_cnt.reserve(tile_cap); tile_seg.reserve(tile_cap);
         Lp.reserve(n); Rl.reserve(n);
         st.reserve(1);
+        queue.reserve(1);
         h_st.reserve(1);
+        h_queue.reserve(1);
+        FLS_HIP(hipMemsetAsync(ready.p, 0, work_cap * sizeof(unsigned), s));
+        if (n <= size_t(kEsTaskMax)) {
+            // every source scan: no begin launch, no host wait -- the array itself is workgroup 0's first task (open = 1 stands for it)
+            FLS_HIP(hipMemsetAsync(st.p, 0, sizeof(EsState), s));
+            *h_queue.p = EsQueue{0u, 0u, 1u, 0u};
+            FLS_HIP(hipMemcpyAsync(queue.p, h_queue.p, sizeof(EsQueue), hipMemcpyHostToDevice, s));
+            const unsigned grid = unsigned(std::min<size_t>(256, std::max<size_t>(8, n / kEsLds + 4)));
+            static const bool dbg_marks = std::getenv("FLS_ES_DEBUG") != nullptr;
+            if (dbg_marks) std::memset(mb_host->mark, 0, sizeof(mb_host->mark));
+            hipLaunchKernelGGL(es_task_kernel, dim3(grid), dim3(kEsTaskThreads), 0, s, key, val, work.p, ready.p, work_cap, queue.p, Lp.p, Rl.p, st.p,
+                               dbg_marks ? mb_dev : (EsMailbox*)nullptr, unsigned(n));
+            FLS_HIP(hipMemcpyAsync(h_st.p, st.p, sizeof(EsState), hipMemcpyDeviceToHost, s));
+            FLS_HIP(hipGetLastError());
+            return true;
+        }
         auto next_seq = [&]() { seq = (seq + 1u) & 0x7fffffffu; if (!seq) seq = 1u; return seq; };
         EsSeg* prev = seg_a.p;
         EsSeg* cur = seg_b.p;
         hipLaunchKernelGGL(es_level_begin, dim3(1), dim3(256), 0, s, key, val, unsigned(n), (const EsSeg*)prev, cur, work.p, work_cap, (const unsigned*)Lp.p,
                            (const unsigned*)Rl.p, st.p, mb_dev, next_seq(), 1, tile_seg.p, tile_cap);
+        // regime 1 (ranges longer than kEsTaskMax: only clouds beyond 131 k points get here)
         int expected = 0;
-        for (size_t m = n; m > size_t(kEsLds); m = (m + 1) / 2) ++expected;
-        int chunk = n > size_t(kEsLds) ? expected + 1 : 0;
+        for (size_t m = n; m > size_t(kEsTaskMax); m = (m + 1) / 2) ++expected;
+        int chunk = expected ? expected + 1 : 0;
         for (;;) {
             for (int c = 0; c < chunk; ++c) {
                 hipLaunchKernelGGL(es_count_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, (const unsigned*)key, (const EsSeg*)cur, (const EsState*)st.p,
@@ -126,14 +151,33 @@ struct DeviceExactSort {
             if (mb_host->n_cur == 0u) break;
             chunk = 2;
         }
+        // regimes 2 + 3: one persistent launch over the task queue (the ranges regime 1 handed over are its first tasks)
         const unsigned n_work = mb_host->n_work;
-        if (n_work) hipLaunchKernelGGL(es_lds_kernel, dim3(std::min(n_work, 2048u)), dim3(kEsLdsThreads), 0, s, key, val, (const EsWork*)work.p, st.p);
+        if (n_work) {
+            *h_queue.p = EsQueue{0u, n_work, n_work, n_work};
+            FLS_HIP(hipMemcpyAsync(queue.p, h_queue.p, sizeof(EsQueue), hipMemcpyHostToDevice, s));
+            const unsigned grid = unsigned(std::min<size_t>(256, std::max<size_t>(8, n / kEsLds + 4)));
+            static const bool skip = std::getenv("FLS_ES_SKIP_TASKS") != nullptr;  // (bisecting aid)
+            if (!skip) hipLaunchKernelGGL(es_task_kernel, dim3(grid), dim3(kEsTaskThreads), 0, s, key, val, work.p, ready.p, work_cap, queue.p, Lp.p, Rl.p, st.p,
+                                          std::getenv("FLS_ES_DEBUG") ? mb_dev : (EsMailbox*)nullptr, 0u);
+            FLS_HIP(hipMemcpyAsync(h_queue.p, queue.p, sizeof(EsQueue), hipMemcpyDeviceToHost, s));
+        }
         FLS_HIP(hipMemcpyAsync(h_st.p, st.p, sizeof(EsState), hipMemcpyDeviceToHost, s));
         FLS_HIP(hipGetLastError());
         return true;
     }
     // after the caller's stream synchronisation: did a range hit introsort's depth limit inside es_lds_kernel?
     bool failed_after_sync() {
+        static const bool dbg = std::getenv("FLS_ES_DEBUG") && std::atoi(std::getenv("FLS_ES_DEBUG")) != 0;
+        if (dbg && mb_host) {
+            const unsigned* mk = mb_host->mark;
+            auto us = [&](int a, int b) { return mk[a] && mk[b] ? 0.01 * double(int(mk[b] - mk[a])) : -1.0; };
+            std::fprintf(stderr, "[fls exact sort] workgroup 0, first task [us]: pop->start %.1f, global partitions %.1f, LDS load %.1f, phase A (workgroup partitions) %.1f, phase B (wave tasks) %.1f, "
+                         "ranks + write-back %.1f\n", us(0, 2), us(2, 9), us(9, 10), us(10, 3), us(3, 4), us(5, 6));
+        }
+        if (dbg && h_st.p)
+            std::fprintf(stderr, "[fls exact sort] regime-1 levels %u, hand-over ranges %u, fail %u; task kernel: %u partitions from global memory, %u ranges (%u records) sorted in LDS\n",
+                         h_st.p->level, h_st.p->n_work, h_st.p->fail, h_st.p->pad[0], h_st.p->pad[1], h_st.p->pad[2]);
         if (h_st.p && h_st.p->fail) { ++failures; return true; }
         return false;
     }

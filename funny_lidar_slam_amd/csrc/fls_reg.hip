@@ -337,6 +337,13 @@ fls_status fls_debug_exact_sort(int device_id, uint32_t* key, uint32_t* val, siz
     });
 }
 
+extern "C" int fls_debug_exact_sort_marks(unsigned* out, int n) {  // diagnostics only (not in the header): progress counters of the sort in flight
+    EsMailbox* m = es_debug_mailbox();
+    if (!m) return -1;
+    for (int i = 0; i < n && i < 12; ++i) out[i] = __atomic_load_n(&m->mark[i], __ATOMIC_RELAXED);
+    return 0;
+}
+
 fls_status fls_voxel_grid_cloud(int device_id, fls_voxelgrid_mode mode, const float* pts, size_t n, int stride, float leaf, float* out, size_t cap,
                                 size_t* n_out) {
     if (mode == FLS_VOXELGRID_DEVICE) return fls_debug_voxel_grid(device_id, pts, n, stride, leaf, out, cap, n_out);

@@ -28,13 +28,11 @@
 
 namespace fls {
 
-constexpr int kEsLds = 4096;        // records a workgroup sorts in LDS
-constexpr int kEsLdsThreads = 512;
-constexpr int kEsLdsItems = kEsLds / kEsLdsThreads;
-constexpr int kEsMaxSub = 256;      // active sub-ranges of one level inside an LDS range (<= kEsLds / 17)
+constexpr int kEsLds = 8192;        // records a workgroup sorts in LDS
+constexpr int kEsTaskMax = 131072;  // ranges up to here are tasks of the persistent kernel; longer ones go through the level-synchronous launches
 constexpr int kEsThreshold = 16;    // _S_threshold
 constexpr int kEsTile = 2048, kEsBlock = 256, kEsItems = kEsTile / kEsBlock;
-constexpr int kEsMaxSeg = 2048;     // regime-1 ranges of one level (n / kEsLds for n <= 4 Mi, with room)
+constexpr int kEsMaxSeg = 64;       // regime-1 ranges of one level (n / kEsTaskMax for n <= 4 Mi, with room)
 
 struct EsSeg { unsigned first, last; int depth; unsigned pivot, nL, nR, K, tile0; };
 struct EsWork { unsigned first, last; int depth, pad; };
@@ -43,11 +41,11 @@ struct EsState {
     unsigned n_tiles;   // their tiles
     unsigned n_work;    // ranges handed to regime 2 so far
     unsigned fail;      // 1: introsort would heap-sort / a table overflowed -> the caller takes the host path
-    unsigned level;
+    unsigned level;     // regime-1 levels run
     unsigned pad[3];
 };
 // what the host polls (host-mapped): written by every es_level_begin
-struct EsMailbox { unsigned seq, n_cur, n_work, fail; };
+struct EsMailbox { unsigned seq, n_cur, n_work, fail; unsigned mark[12]; };  // mark: progress counters of es_task_kernel (diagnostics)
 
 __device__ __forceinline__ void es_swap_rec(unsigned* __restrict__ key, unsigned* __restrict__ val, const unsigned a, const unsigned b) {
     const unsigned ka = key[a], kb = key[b], va = val[a], vb = val[b];
@@ -80,7 +78,7 @@ es_level_begin(unsigned* __restrict__ key, unsigned* __restrict__ val, const uns
     auto child = [&](const unsigned f, const unsigned l, const int depth) {
         const unsigned m = l - f;
         if (m < 2u) return;
-        if (m > (unsigned)kEsLds) {
+        if (m > (unsigned)kEsTaskMax) {
             const unsigned slot = atomicAdd(&s_ncur, 1u);
             if (slot < (unsigned)kEsMaxSeg) cur[slot] = EsSeg{f, l, depth, 0u, 0u, 0u, 0u, 0u};
             else s_fail = 1u;
@@ -232,151 +230,417 @@ es_swap_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsSeg* __
     }
 }
 
-// ---- regime 2: one workgroup per range of <= kEsLds records, every remaining level in LDS -----------------------------------------
-__global__ void __launch_bounds__(kEsLdsThreads)
-es_lds_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, const EsWork* __restrict__ work, EsState* __restrict__ st) {
+// ---- regimes 2 + 3: ONE persistent launch, a task queue of ranges -------------------------------------------------------------------
+// A level-synchronous sweep pays for the DEEPEST branch at every level, and introsort on LiDAR leaf indices is deep and lopsided
+// (median-of-three on piecewise-monotone keys: 16 levels before the last range of a 115 k-point scan fell below 4,096 records, 23 more
+// inside it).  From kEsTaskMax records down, ranges are therefore TASKS: a workgroup pops a range from a global queue and
+//   * partitions it itself out of global memory (16 waves, each over a contiguous slice in coalesced rounds of 64 with ballot ranks:
+//     counts -> wave bases -> stop lists -> K* disjoint swaps) and pushes the two children, or
+//   * (range <= kEsLds) takes it into LDS, where its WAVES run the same partition on sub-ranges from a local queue -- no workgroup
+//     barrier per level, every branch advances at its own pace -- then ranks the records of every final <= 16 block (= the insertion
+//     sort) and writes the range back.
+// Hand-off between workgroups (possibly on different XCDs): the producer writes back its L2 (agent-scope release) before it publishes a
+// child, the consumer invalidates (agent-scope acquire) after it pops one.  Termination: a counter of open tasks.
+constexpr int kEsTaskThreads = 1024, kEsTaskWaves = kEsTaskThreads / 64;
+constexpr int kEsCoop = 1024;    // sub-ranges of an LDS range longer than this are partitioned by the whole workgroup, shorter ones by single waves
+constexpr int kEsStack = 64;     // pending workgroup-level sub-ranges (disjoint, each > kEsCoop records: at most kEsLds / kEsCoop)
+constexpr int kEsWaveStack = 48; // a wave's depth-first stack (smaller child first: <= log2(kEsCoop) + 1 pending ranges)
+constexpr int kEsLocalQ = 1024;  // sub-range tasks of one LDS range (<= 2 per partition, <= kEsLds / 17 partitions)
+struct EsQueue { unsigned head, tail, open, n_init; };
+
+__device__ __forceinline__ unsigned es_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// push a range (>= 2 records) onto the global queue; the caller has released its writes
+__device__ __forceinline__ void es_push(EsQueue* __restrict__ q, EsWork* __restrict__ tasks, unsigned* __restrict__ ready, const unsigned cap, EsState* __restrict__ st,
+                                        const unsigned f, const unsigned l, const int depth) {
+    if (l - f < 2u) return;
+    __hip_atomic_fetch_add(&q->open, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (no return value: does not wait)
+    const unsigned slot = atomicAdd(&q->tail, 1u);
+    if (slot >= cap) { atomicExch(&st->fail, 1u); atomicSub(&q->open, 1u); return; }
+    tasks[slot] = EsWork{f, l, depth, 0};  // (plain stores: the release below orders them, and the sorted records, before the flag)
+    __hip_atomic_store(&ready[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(kEsTaskThreads)
+es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* __restrict__ tasks, unsigned* __restrict__ ready, const unsigned cap,
+               EsQueue* __restrict__ q, unsigned* __restrict__ Lp, unsigned* __restrict__ Rl, EsState* __restrict__ st, EsMailbox* __restrict__ dbg,
+               const unsigned init_n /* != 0: the whole array [0, init_n) is workgroup 0's first task (no begin launch, no queue entry) */) {
+#define ES_MARK(k) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0 && dbg->mark[k] == 0u) dbg->mark[k] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
     __shared__ unsigned sk[kEsLds], sv[kEsLds];
-    __shared__ unsigned short lp[kEsLds], rl[kEsLds], pl[kEsLds + 1], pr[kEsLds + 1], sid[kEsLds];
-    __shared__ unsigned char bnd[kEsLds + 1];
-    __shared__ unsigned short sf[2][kEsMaxSub], sl[2][kEsMaxSub], sK[kEsMaxSub], ida[kEsMaxSub], idb[kEsMaxSub], scut[kEsMaxSub];
-    __shared__ short sd[2][kEsMaxSub];
-    __shared__ unsigned spiv[kEsMaxSub];
-    __shared__ unsigned wsum[kEsLdsThreads / 64][2];
-    __shared__ unsigned s_nact, s_nnext, s_fail;
-    const int t = threadIdx.x;
-    const unsigned n_work = st->n_work;
-    for (unsigned w = blockIdx.x; w < n_work; w += gridDim.x) {
-        const EsWork wk = work[w];
-        const unsigned m = wk.last - wk.first;
-        __syncthreads();  // (LDS of the previous range is free)
-        for (unsigned i = t; i < m; i += kEsLdsThreads) { sk[i] = key[wk.first + i]; sv[i] = val[wk.first + i]; sid[i] = m > (unsigned)kEsThreshold ? 0 : 0xffff; bnd[i] = 0; }
-        if (t == 0) {
-            bnd[0] = 1; bnd[m] = 1;
-            s_nact = m > (unsigned)kEsThreshold ? 1u : 0u;
+    __shared__ unsigned short lp[kEsLds], rl[kEsLds];
+    __shared__ unsigned bmask[kEsLds / 32 + 2];  // bit i: a partition cut (or the range's ends) lies in front of record i
+    __shared__ unsigned ws_t[kEsTaskWaves][kEsWaveStack];  // per-wave depth-first stacks of phase B
+    __shared__ signed char ws_d[kEsTaskWaves][kEsWaveStack];
+    __shared__ unsigned qt[kEsLocalQ];  // local task = first | last << 16, published with one release store (0 = not yet)
+    __shared__ signed char qd[kEsLocalQ];
+    __shared__ unsigned lq_head, lq_tail, lq_open, s_sp;
+    __shared__ unsigned short sa_f[kEsStack], sa_l[kEsStack];
+    __shared__ signed char sa_d[kEsStack];
+    __shared__ unsigned s_wl[kEsTaskWaves], s_wr[kEsTaskWaves], s_cnt[kEsTaskWaves];
+    __shared__ unsigned s_first, s_last, s_pivot, s_state, s_fail, s_K;
+    __shared__ int s_depth;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    bool take_init = init_n != 0u && blockIdx.x == 0;
+    for (;;) {
+        // ---- pop a task (thread 0), broadcast ----
+        if (t == 0 && take_init) {
+            int lg = 0;
+            while ((2u << lg) <= init_n) ++lg;  // floor(log2 n): introsort's depth limit is twice that
+            s_first = 0u; s_last = init_n; s_depth = 2 * lg;
+            s_state = 1u;
             s_fail = 0u;
-            sf[0][0] = 0; sl[0][0] = (unsigned short)m; sd[0][0] = (short)wk.depth;
+        } else if (t == 0) {
+            unsigned state = 0u;  // 1: got a task, 2: all done
+            for (unsigned spin = 0;; ++spin) {
+                if (es_ld(&st->fail)) { state = 2u; break; }
+                const unsigned h = es_ld(&q->head), tl = es_ld(&q->tail);
+                const unsigned lim = tl < cap ? tl : cap;
+                if (h < lim) {
+                    if (atomicCAS(&q->head, h, h + 1u) != h) continue;
+                    if (h >= q->n_init) {
+                        unsigned guard = 0u;
+                        while (__hip_atomic_load(&ready[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++guard < 4000000u) __builtin_amdgcn_s_sleep(1);
+                        if (guard >= 4000000u) { atomicExch(&st->fail, 3u); state = 2u; break; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    const EsWork wk = tasks[h];
+                    s_first = wk.first; s_last = wk.last; s_depth = wk.depth;
+                    state = 1u;
+                    break;
+                }
+                if (es_ld(&q->open) == 0u) { state = 2u; break; }
+                if (spin > 4000000u) { atomicExch(&st->fail, 2u); state = 2u; break; }  // watchdog (seconds): never hang the device
+                if (spin < 64u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(20);
+            }
+            s_state = state;
+            s_fail = 0u;
         }
+        take_init = false;
+        ES_MARK(0);
         __syncthreads();
-        int cur = 0;
-        while (s_nact != 0u && !s_fail) {
-            const unsigned nact = s_nact;
-            // A: median of three per active sub-range
-            for (unsigned s = t; s < nact; s += kEsLdsThreads) {
-                const unsigned f = sf[cur][s], l = sl[cur][s];
-                if (sd[cur][s] == 0) { s_fail = 1u; continue; }
-                const unsigned a = f + 1u, b = f + (l - f) / 2u, c = l - 1u;
-                const unsigned ka = sk[a], kb = sk[b], kc = sk[c];
-                unsigned med;
-                if (ka < kb) { if (kb < kc) med = b; else if (ka < kc) med = c; else med = a; }
-                else if (ka < kc) med = a;
-                else if (kb < kc) med = c;
-                else med = b;
-                const unsigned k0 = sk[f], v0 = sv[f];
-                sk[f] = sk[med]; sv[f] = sv[med]; sk[med] = k0; sv[med] = v0;
-                spiv[s] = sk[f];
-                sK[s] = 0;
-            }
-            if (t == 0) s_nnext = 0u;
-            __syncthreads();
-            if (s_fail) break;
-            // B: both predicates of every record of an active sub-range (not its pivot slot), ranked by one block-wide exclusive scan
-            unsigned fl[kEsLdsItems], fr[kEsLdsItems];
-            unsigned v[2] = {0u, 0u}, tot[2];
-#pragma unroll
-            for (int q = 0; q < kEsLdsItems; ++q) {
-                const unsigned i = (unsigned)t * kEsLdsItems + q;
-                fl[q] = fr[q] = 0u;
-                if (i < m) {
-                    const unsigned s = sid[i];
-                    if (s != 0xffffu && i != sf[cur][s]) { const unsigned k = sk[i], p = spiv[s]; fl[q] = k >= p ? 1u : 0u; fr[q] = k <= p ? 1u : 0u; }
-                }
-                v[0] += fl[q]; v[1] += fr[q];
-            }
-            block_excl_scan<2>(v, tot, wsum);
+        ES_MARK(1);
+        if (s_state == 2u) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the producer's records, not this CU's cached copies
+        ES_MARK(2);
+        unsigned first = s_first, last = s_last, m = last - first;
+        int depth = s_depth;
+        bool dead = false;  // the range hit the depth limit (sort failed) -- nothing left to do for this task
+        while (m > (unsigned)kEsLds) {
+            // ============ a workgroup partitions the range out of global memory, hands one child to the queue and keeps the other:
+            // no queue round trip (pop, acquire, ~10 atomics) on the critical path of a lopsided recursion ============
+            if (depth == 0) { if (t == 0) atomicExch(&st->fail, 1u); dead = true; break; }  // (introsort switches to heap sort here)
+            if (t == 0) atomicAdd(&st->pad[0], 1u);  // diagnostics: partitions done from global memory
             {
-                unsigned a = v[0], b = v[1];
+                if (t == 0) s_pivot = es_median_to_first(key, val, first, last);
+                __syncthreads();
+                const unsigned p = s_pivot;
+                // wave w owns a contiguous slice of [first + 1, last), a multiple of 64 positions long
+                const unsigned span = last - first - 1u, per = ((span + kEsTaskWaves - 1u) / kEsTaskWaves + 63u) & ~63u;
+                const unsigned w0 = first + 1u + (unsigned)w * per, w1 = w0 + per < last ? w0 + per : last;
+                // (every loop below keeps U independent loads in flight: a global round trip costs ~1 us on a freshly invalidated cache, and a
+                // 115 k-record range is 113 rounds of 64 per wave)
+                constexpr int U = 8;
+                unsigned cl = 0u, cr = 0u;
+                for (unsigned base = w0; base < w1; base += 64u * U) {
+                    unsigned kk[U];
 #pragma unroll
-                for (int q = 0; q < kEsLdsItems; ++q) {
-                    const unsigned i = (unsigned)t * kEsLdsItems + q;
-                    if (i < m) { pl[i] = (unsigned short)a; pr[i] = (unsigned short)b; }
-                    a += fl[q]; b += fr[q];
-                }
-                if (t == 0) { pl[m] = (unsigned short)tot[0]; pr[m] = (unsigned short)tot[1]; }
-            }
-            __syncthreads();
-            // C: stop lists of every sub-range at [first + rank]
+                    for (int u = 0; u < U; ++u) { const unsigned i = base + 64u * u + lane; kk[u] = i < w1 ? key[i] : 0u; }
 #pragma unroll
-            for (int q = 0; q < kEsLdsItems; ++q) {
-                const unsigned i = (unsigned)t * kEsLdsItems + q;
-                if (i < m && (fl[q] | fr[q])) {
-                    const unsigned f = sf[cur][sid[i]];
-                    if (fl[q]) lp[f + pl[i] - pl[f + 1u]] = (unsigned short)i;
-                    if (fr[q]) rl[f + pr[i] - pr[f + 1u]] = (unsigned short)i;
+                    for (int u = 0; u < U; ++u) {
+                        const unsigned i = base + 64u * u + lane;
+                        cl += (unsigned)__popcll(__ballot(i < w1 && kk[u] >= p));
+                        cr += (unsigned)__popcll(__ballot(i < w1 && kk[u] <= p));
+                    }
                 }
-            }
-            __syncthreads();
-            // D: swaps (position i of a sub-range plays k = i - first) and K*
-            for (unsigned i = t; i < m; i += kEsLdsThreads) {
-                const unsigned s = sid[i];
-                if (s == 0xffffu) continue;
-                const unsigned f = sf[cur][s], l = sl[cur][s], k = i - f;
-                if (k >= l - f - 1u) continue;
-                const unsigned nL = (unsigned)pl[l] - pl[f + 1u], nR = (unsigned)pr[l] - pr[f + 1u];
-                auto Rk = [&](const unsigned kq) { return kq < nR ? (unsigned)rl[f + nR - 1u - kq] : f; };
-                auto cond = [&](const unsigned kq) { return kq < nL && (unsigned)lp[f + kq] < Rk(kq); };
-                if (!cond(k)) continue;
-                const unsigned a = lp[f + k], b = Rk(k);
-                const unsigned ka = sk[a], va = sv[a];
-                sk[a] = sk[b]; sv[a] = sv[b]; sk[b] = ka; sv[b] = va;
-                if (!cond(k + 1u)) sK[s] = (unsigned short)(k + 1u);
-            }
-            __syncthreads();
-            // E: cuts, children, the next level's table
-            for (unsigned s = t; s < nact; s += kEsLdsThreads) {
-                const unsigned f = sf[cur][s], l = sl[cur][s], K = sK[s];
-                const unsigned nL = (unsigned)pl[l] - pl[f + 1u], nR = (unsigned)pr[l] - pr[f + 1u];
-                const unsigned INF = 0xFFFFFFFFu;
-                const unsigned a = K < nL ? (unsigned)lp[f + K] : INF;
-                const unsigned b = K >= 1u ? (K - 1u < nR ? (unsigned)rl[f + nR - K] : f) : INF;
-                const unsigned cut = a < b ? a : b;
-                scut[s] = (unsigned short)cut;
-                bnd[cut] = 1;
-                const short d = (short)(sd[cur][s] - 1);
-                unsigned short ia = 0xffff, ib = 0xffff;
-                if (cut - f > (unsigned)kEsThreshold) {
-                    const unsigned slot = atomicAdd(&s_nnext, 1u);
-                    if (slot < (unsigned)kEsMaxSub) { sf[cur ^ 1][slot] = (unsigned short)f; sl[cur ^ 1][slot] = (unsigned short)cut; sd[cur ^ 1][slot] = d; ia = (unsigned short)slot; }
-                    else s_fail = 1u;
+                if (lane == 0) { s_wl[w] = cl; s_wr[w] = cr; }
+                __syncthreads();
+                unsigned bl = 0u, br = 0u, nL = 0u, nR = 0u;
+                for (int x = 0; x < kEsTaskWaves; ++x) { const unsigned a = s_wl[x], b = s_wr[x]; if (x < w) { bl += a; br += b; } nL += a; nR += b; }
+                for (unsigned base = w0; base < w1; base += 64u * U) {
+                    unsigned kk[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { const unsigned i = base + 64u * u + lane; kk[u] = i < w1 ? key[i] : 0u; }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const unsigned i = base + 64u * u + lane;
+                        const bool fl = i < w1 && kk[u] >= p, fr = i < w1 && kk[u] <= p;
+                        const unsigned long long ml = __ballot(fl), mr = __ballot(fr);
+                        if (fl) Lp[first + bl + (unsigned)__popcll(ml & lt_mask)] = i;
+                        if (fr) Rl[first + br + (unsigned)__popcll(mr & lt_mask)] = i;
+                        bl += (unsigned)__popcll(ml); br += (unsigned)__popcll(mr);
+                    }
                 }
-                if (l - cut > (unsigned)kEsThreshold) {
-                    const unsigned slot = atomicAdd(&s_nnext, 1u);
-                    if (slot < (unsigned)kEsMaxSub) { sf[cur ^ 1][slot] = (unsigned short)cut; sl[cur ^ 1][slot] = (unsigned short)l; sd[cur ^ 1][slot] = d; ib = (unsigned short)slot; }
-                    else s_fail = 1u;
+                __syncthreads();
+                // the K* swaps (cond is monotone in k: K* = the number of k it holds for).  Pair k needs L_k and the k-th R-stop from the
+                // right; candidates beyond min(nL, nR + 1) cannot hold.  Conditions first (independent loads), then the records.
+                auto Rk = [&](const unsigned k) { return k < nR ? Rl[first + nR - 1u - k] : first; };
+                const unsigned kmax = nL < nR + 1u ? nL : nR + 1u;
+                unsigned mine = 0u;
+                for (unsigned k0 = (unsigned)t; k0 < kmax; k0 += (unsigned)kEsTaskThreads * 4u) {
+                    unsigned a[4], b[4];
+                    bool c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned k = k0 + (unsigned)u * (unsigned)kEsTaskThreads;
+                        a[u] = k < kmax ? Lp[first + k] : 0u;
+                        b[u] = k < kmax ? Rk(k) : 0u;
+                    }
+                    unsigned ka[4], kb[4], va[4], vb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned k = k0 + (unsigned)u * (unsigned)kEsTaskThreads;
+                        c[u] = k < kmax && a[u] < b[u];
+                        if (c[u]) { ka[u] = key[a[u]]; kb[u] = key[b[u]]; va[u] = val[a[u]]; vb[u] = val[b[u]]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (c[u]) { key[a[u]] = kb[u]; key[b[u]] = ka[u]; val[a[u]] = vb[u]; val[b[u]] = va[u]; ++mine; }
                 }
-                ida[s] = ia; idb[s] = ib;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+                if (lane == 0) s_cnt[w] = mine;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's swaps have left the CU
+                __syncthreads();
+                if (t == 0) {
+                    unsigned K = 0u;
+                    for (int x = 0; x < kEsTaskWaves; ++x) K += s_cnt[x];
+                    const unsigned INF = 0xFFFFFFFFu;
+                    const unsigned a = K < nL ? Lp[first + K] : INF;
+                    const unsigned b = K >= 1u ? Rk(K - 1u) : INF;
+                    const unsigned cut = a < b ? a : b;
+                    // keep the larger child, publish the other (its records: every wave's swaps reached the L2 before the barrier above; the
+                    // release of es_push writes them back for a consumer on another XCD)
+                    const bool keep_right = last - cut >= cut - first;
+                    if (keep_right) { es_push(q, tasks, ready, cap, st, first, cut, depth - 1); s_first = cut; s_last = last; }
+                    else { es_push(q, tasks, ready, cap, st, cut, last, depth - 1); s_first = first; s_last = cut; }
+                }
+                __syncthreads();
+                first = s_first; last = s_last; m = last - first; --depth;
             }
-            __syncthreads();
-            for (unsigned i = t; i < m; i += kEsLdsThreads) {
-                const unsigned s = sid[i];
-                if (s != 0xffffu) sid[i] = i < scut[s] ? ida[s] : idb[s];
-            }
-            if (t == 0) s_nact = s_nnext;
-            cur ^= 1;
-            __syncthreads();
         }
-        if (s_fail) { if (t == 0) st->fail = 1u; continue; }
-        // the insertion sort: every record moves to its stable rank inside its final block (blocks of <= 16 between cuts)
-        for (unsigned i = t; i < m; i += kEsLdsThreads) {
-            unsigned b0 = i, b1 = i + 1u;
-            while (!bnd[b0]) --b0;
-            while (!bnd[b1]) ++b1;
-            const unsigned k = sk[i];
-            unsigned r = 0u;
-            for (unsigned j = b0; j < b1; ++j) { const unsigned kj = sk[j]; r += (kj < k || (kj == k && j < i)) ? 1u : 0u; }
-            key[wk.first + b0 + r] = k;
-            val[wk.first + b0 + r] = sv[i];
+        ES_MARK(9);
+        if (!dead && m >= 2u) {
+            if (t == 0) { atomicAdd(&st->pad[1], 1u); atomicAdd(&st->pad[2], m); }  // diagnostics: ranges sorted in LDS, their records
+            // ============ the range lives in LDS; its waves partition sub-ranges from a local queue ============
+            for (unsigned i = t; i < m; i += kEsTaskThreads) { sk[i] = key[first + i]; sv[i] = val[first + i]; }
+            for (unsigned i = t; i < (unsigned)(kEsLds / 32 + 2); i += kEsTaskThreads) bmask[i] = 0u;
+            __syncthreads();
+            for (unsigned i = t; i < (unsigned)kEsLocalQ; i += kEsTaskThreads) qt[i] = 0u;
+            if (t == 0) {
+                atomicOr(&bmask[0], 1u);
+                atomicOr(&bmask[m >> 5], 1u << (m & 31u));
+                lq_head = 0u; lq_tail = 0u; lq_open = 0u;
+                s_sp = 0u;
+                if (m > (unsigned)kEsCoop) { sa_f[0] = 0; sa_l[0] = (unsigned short)m; sa_d[0] = (signed char)(depth > 127 ? 127 : depth); s_sp = 1u; }
+                else if (m > (unsigned)kEsThreshold) { qd[0] = (signed char)(depth > 127 ? 127 : depth); lq_tail = 1u; lq_open = 1u; }
+            }
+            __syncthreads();
+            if (t == 0 && m > (unsigned)kEsThreshold && m <= (unsigned)kEsCoop) qt[0] = m << 16;  // (first = 0)
+            __syncthreads();
+            ES_MARK(10);
+            // ---- phase A: sub-ranges longer than kEsCoop are partitioned by the WHOLE workgroup, one after the other (a stack): a
+            // lopsided recursion keeps one long sub-range alive for many levels, and a single wave needs m / 64 dependent rounds for it
+            while (s_sp != 0u && !s_fail) {
+                const unsigned sp = s_sp - 1u;
+                const unsigned f = sa_f[sp], l = sa_l[sp];
+                const int d = sa_d[sp];
+                __syncthreads();  // (everyone has read the top of the stack)
+                if (d == 0) { if (t == 0) { s_fail = 1u; s_sp = 0u; } __syncthreads(); break; }
+                if (t == 0) {
+                    const unsigned a = f + 1u, b = f + (l - f) / 2u, c = l - 1u;
+                    const unsigned ka = sk[a], kb = sk[b], kc = sk[c];
+                    unsigned med;
+                    if (ka < kb) { if (kb < kc) med = b; else if (ka < kc) med = c; else med = a; }
+                    else if (ka < kc) med = a;
+                    else if (kb < kc) med = c;
+                    else med = b;
+                    const unsigned k0 = sk[f], v0 = sv[f];
+                    sk[f] = sk[med]; sv[f] = sv[med]; sk[med] = k0; sv[med] = v0;
+                    s_pivot = sk[f];
+                }
+                __syncthreads();
+                const unsigned p = s_pivot;
+                const unsigned span = l - f - 1u, per = ((span + kEsTaskWaves - 1u) / kEsTaskWaves + 63u) & ~63u;
+                const unsigned w0 = f + 1u + (unsigned)w * per, w1 = w0 + per < l ? w0 + per : l;
+                unsigned cl = 0u, cr = 0u;
+                for (unsigned base = w0; base < w1; base += 64u) {
+                    const unsigned i = base + lane;
+                    const unsigned k = i < w1 ? sk[i] : 0u;
+                    cl += (unsigned)__popcll(__ballot(i < w1 && k >= p));
+                    cr += (unsigned)__popcll(__ballot(i < w1 && k <= p));
+                }
+                if (lane == 0) { s_wl[w] = cl; s_wr[w] = cr; }
+                __syncthreads();
+                unsigned bl = 0u, br = 0u, nL = 0u, nR = 0u;
+                for (int x = 0; x < kEsTaskWaves; ++x) { const unsigned a = s_wl[x], b = s_wr[x]; if (x < w) { bl += a; br += b; } nL += a; nR += b; }
+                for (unsigned base = w0; base < w1; base += 64u) {
+                    const unsigned i = base + lane;
+                    const unsigned k = i < w1 ? sk[i] : 0u;
+                    const bool fl = i < w1 && k >= p, fr = i < w1 && k <= p;
+                    const unsigned long long ml = __ballot(fl), mr = __ballot(fr);
+                    if (fl) lp[f + bl + (unsigned)__popcll(ml & lt_mask)] = (unsigned short)i;
+                    if (fr) rl[f + br + (unsigned)__popcll(mr & lt_mask)] = (unsigned short)i;
+                    bl += (unsigned)__popcll(ml); br += (unsigned)__popcll(mr);
+                }
+                __syncthreads();
+                const unsigned kmax = nL < nR + 1u ? nL : nR + 1u;
+                unsigned mine = 0u;
+                for (unsigned k = (unsigned)t; k < kmax; k += (unsigned)kEsTaskThreads) {
+                    const unsigned a = lp[f + k], b = k < nR ? (unsigned)rl[f + nR - 1u - k] : f;
+                    if (a < b) { const unsigned ka = sk[a], va = sv[a]; sk[a] = sk[b]; sv[a] = sv[b]; sk[b] = ka; sv[b] = va; ++mine; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+                if (lane == 0) s_cnt[w] = mine;
+                __syncthreads();
+                if (t == 0) {
+                    unsigned K = 0u;
+                    for (int x = 0; x < kEsTaskWaves; ++x) K += s_cnt[x];
+                    const unsigned INF = 0xFFFFFFFFu;
+                    const unsigned a = K < nL ? (unsigned)lp[f + K] : INF;
+                    const unsigned b = K >= 1u ? (K - 1u < nR ? (unsigned)rl[f + nR - K] : f) : INF;
+                    const unsigned cut = a < b ? a : b;
+                    atomicOr(&bmask[cut >> 5], 1u << (cut & 31u));
+                    unsigned top = sp;  // (the processed entry is replaced)
+                    const unsigned cf[2] = {f, cut}, cl2[2] = {cut, l};
+                    for (int x = 0; x < 2; ++x) {
+                        const unsigned cm = cl2[x] - cf[x];
+                        if (cm > (unsigned)kEsCoop) {
+                            if (top < (unsigned)kEsStack) { sa_f[top] = (unsigned short)cf[x]; sa_l[top] = (unsigned short)cl2[x]; sa_d[top] = (signed char)(d - 1); ++top; }
+                            else s_fail = 1u;
+                        } else if (cm > (unsigned)kEsThreshold) {
+                            const unsigned s2 = lq_tail;
+                            if (s2 < (unsigned)kEsLocalQ) { qd[s2] = (signed char)(d - 1); qt[s2] = cf[x] | (cl2[x] << 16); lq_tail = s2 + 1u; lq_open = lq_open + 1u; }
+                            else s_fail = 1u;
+                        }
+                    }
+                    s_sp = top;
+                }
+                __syncthreads();
+            }
+            ES_MARK(3);
+            // ---- phase B: every remaining sub-range (<= kEsCoop records, queued by phase A) belongs to ONE wave, which runs its whole
+            // subtree depth first from a private stack: no queue traffic, no waiting between partitions ----
+            for (;;) {
+                unsigned slot = 0u;
+                if (lane == 0) slot = atomicAdd(&lq_head, 1u);
+                slot = __shfl(slot, 0, 64);
+                if (slot >= lq_tail || slot >= (unsigned)kEsLocalQ) break;  // (lq_tail is final: phase A filled the queue)
+                int sp = 0;
+                if (lane == 0) { ws_t[w][0] = qt[slot]; ws_d[w][0] = qd[slot]; }
+                sp = 1;
+                while (sp > 0) {
+                    --sp;
+                    const unsigned task_word = ws_t[w][sp];
+                    const int d = ws_d[w][sp];
+                    const unsigned f = task_word & 0xffffu, l = task_word >> 16;
+                    if (d == 0) { if (lane == 0) __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); sp = 0; break; }
+                    unsigned p = 0u;
+                    if (lane == 0) {
+                        const unsigned a = f + 1u, b = f + (l - f) / 2u, c = l - 1u;
+                        const unsigned ka = sk[a], kb = sk[b], kc = sk[c];
+                        unsigned med;
+                        if (ka < kb) { if (kb < kc) med = b; else if (ka < kc) med = c; else med = a; }
+                        else if (ka < kc) med = a;
+                        else if (kb < kc) med = c;
+                        else med = b;
+                        const unsigned k0 = sk[f], v0 = sv[f];
+                        sk[f] = sk[med]; sv[f] = sv[med]; sk[med] = k0; sv[med] = v0;
+                        p = sk[f];
+                    }
+                    p = __shfl(p, 0, 64);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // one pass: both stop lists with left ranks (the running counts are the ranks); four rounds of reads in flight
+                    unsigned nL = 0u, nR = 0u;
+                    for (unsigned base = f + 1u; base < l; base += 64u * 4u) {
+                        unsigned kk[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const unsigned i = base + 64u * u + lane; kk[u] = i < l ? sk[i] : 0u; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const unsigned i = base + 64u * u + lane;
+                            const bool fl = i < l && kk[u] >= p, fr = i < l && kk[u] <= p;
+                            const unsigned long long ml = __ballot(fl), mr = __ballot(fr);
+                            if (fl) lp[f + nL + (unsigned)__popcll(ml & lt_mask)] = (unsigned short)i;
+                            if (fr) rl[f + nR + (unsigned)__popcll(mr & lt_mask)] = (unsigned short)i;
+                            nL += (unsigned)__popcll(ml); nR += (unsigned)__popcll(mr);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    unsigned K = 0u;
+                    for (unsigned k0 = 0u; k0 < nL; k0 += 64u) {
+                        const unsigned k = k0 + lane;
+                        bool c = false;
+                        unsigned a = 0u, b = 0u;
+                        if (k < nL) { a = lp[f + k]; b = k < nR ? (unsigned)rl[f + nR - 1u - k] : f; c = a < b; }
+                        if (c) { const unsigned ka = sk[a], va = sv[a]; sk[a] = sk[b]; sv[a] = sv[b]; sk[b] = ka; sv[b] = va; }
+                        const unsigned long long mc = __ballot(c);
+                        K += (unsigned)__popcll(mc);
+                        if (mc != ~0ull) break;  // (monotone: nothing beyond the first false)
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // cut + children (wave-uniform values: every lane computes them from the same LDS words)
+                    const unsigned INF = 0xFFFFFFFFu;
+                    const unsigned ca = K < nL ? (unsigned)lp[f + K] : INF;
+                    const unsigned cb = K >= 1u ? (K - 1u < nR ? (unsigned)rl[f + nR - K] : f) : INF;
+                    const unsigned cut = ca < cb ? ca : cb;
+                    if (lane == 0) atomicOr(&bmask[cut >> 5], 1u << (cut & 31u));
+                    // depth first, the SMALLER child next (the stack stays logarithmic)
+                    const unsigned m0 = cut - f, m1 = l - cut;
+                    const unsigned big_f = m0 >= m1 ? f : cut, big_l = m0 >= m1 ? cut : l, sm_f = m0 >= m1 ? cut : f, sm_l = m0 >= m1 ? l : cut;
+                    if (big_l - big_f > (unsigned)kEsThreshold) {
+                        if (sp < kEsWaveStack) { if (lane == 0) { ws_t[w][sp] = big_f | (big_l << 16); ws_d[w][sp] = (signed char)(d - 1); } ++sp; }
+                        else if (lane == 0) __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (sm_l - sm_f > (unsigned)kEsThreshold) {
+                        if (sp < kEsWaveStack) { if (lane == 0) { ws_t[w][sp] = sm_f | (sm_l << 16); ws_d[w][sp] = (signed char)(d - 1); } ++sp; }
+                        else if (lane == 0) __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+            ES_MARK(4);
+            __syncthreads();
+            ES_MARK(5);
+            if (s_fail) { if (t == 0) atomicExch(&st->fail, 1u); }
+            else {
+                // the insertion sort: every record moves to its stable rank inside its final block (blocks of <= 16 between cuts)
+                for (unsigned i = t; i < m; i += kEsTaskThreads) {
+                    // the record's final block [b0, b1): the nearest cut at or below i, the nearest above (blocks hold <= 16 records, so
+                    // both lie within two mask words)
+                    unsigned b0, b1;
+                    {
+                        const unsigned wi = i >> 5, bi = i & 31u;
+                        const unsigned lo = bmask[wi] & (0xFFFFFFFFu >> (31u - bi));  // bits 0 .. bi
+                        if (lo) b0 = (wi << 5) + (31u - (unsigned)__clz((int)lo));
+                        else { const unsigned pw = bmask[wi - 1u]; b0 = ((wi - 1u) << 5) + (31u - (unsigned)__clz((int)pw)); }
+                        const unsigned hi = bi == 31u ? 0u : (bmask[wi] & (0xFFFFFFFFu << (bi + 1u)));  // bits bi + 1 .. 31
+                        if (hi) b1 = (wi << 5) + (unsigned)__ffs((int)hi) - 1u;
+                        else { const unsigned nw = bmask[wi + 1u]; b1 = ((wi + 1u) << 5) + (unsigned)__ffs((int)nw) - 1u; }
+                    }
+                    const unsigned k = sk[i];
+                    unsigned r = 0u;
+                    for (unsigned j = b0; j < b1; ++j) { const unsigned kj = sk[j]; r += (kj < k || (kj == k && j < i)) ? 1u : 0u; }
+                    key[first + b0 + r] = k;
+                    val[first + b0 + r] = sv[i];
+                }
+            }
         }
+        ES_MARK(6);
+        __syncthreads();
+        if (t == 0) atomicSub(&q->open, 1u);  // (after the children were pushed)
+        ES_MARK(7);
     }
+    ES_MARK(8);
+#undef ES_MARK
 }
 
 }  // namespace fls

@@ -51,8 +51,19 @@ def test_structured_inputs():
     check(np.zeros(n, np.int64), "all equal")
     check(np.repeat(np.arange(n // 6), 6), "runs of six")
     check(np.tile(np.arange(300), n // 300), "sawtooth")
-    k = np.sort(base); k[::97] = rng.integers(0, 5000, k[::97].size)
+    k = np.sort(base); k[:: n // 7] += 3
     check(k, "nearly sorted")
+
+
+def test_heap_sort_case_is_declined():
+    """A sorted array with every 97th key replaced at random drives introsort to its depth limit (2 log2 n partitions deep on a 67-record
+    range: checked with the CPU model), where libstdc++ switches to heap sort -- not reproduced on the device: the sort reports
+    FLS_ERR_STATE and the VoxelGrid callers take the host filter."""
+    rng = np.random.default_rng(5)
+    n = 60000
+    k = np.sort(rng.integers(0, 5000, n)); k[::97] = rng.integers(0, 5000, k[::97].size)
+    (rh, kh, vh), (rd, kd, vd) = sort_both(k)
+    assert rh == 0 and rd == _lib.FLS_ERR_STATE, (rh, rd)
 
 
 def test_leaf_indices_of_a_real_scan():

@@ -1,12 +1,11 @@
-"""Device VoxelGrid (csrc/kernels_voxelgrid.hpp) against the oracle's pcl::VoxelGrid restatement
-(oracle/flo_cloud.h, itself pinned by the compiled reference's VoxelGridCloud in tests/test_ref_pin.py).
+"""Device VoxelGrid (csrc/kernels_voxelgrid.hpp + kernels_exactsort.hpp) against the oracle's pcl::VoxelGrid
+restatement (oracle/flo_cloud.h, itself pinned by the compiled reference's VoxelGridCloud in tests/test_ref_pin.py).
 
-Contract under test (the reason the device path is opt-in, FLS_DEVICE_VOXELGRID=1):
-  * number of leaves, their order, which points fall into which leaf: exactly the reference's;
-  * centroid of a leaf holding one or two points: bit-identical;
-  * centroid of a larger leaf: the reference sums in the order std::sort leaves equal keys in (unspecified), the device in
-    ascending point index -- the difference is bounded by count * 2^-23 * max|coordinate| per component (asserted), and is
-    a few ulp in practice (reported).
+Round 4: the device filter is the DEFAULT and BIT-IDENTICAL to the reference -- its sort reproduces std::sort's permutation
+(tests/test_gpu_exact_sort.py), so every leaf is summed in the reference's order.  `check` asserts bit equality of the whole output.
+FLS_DEVICE_VOXELGRID=2 keeps the round-2/3 form (stable radix sort, leaf sums in ascending point index) for A/B; its contract --
+leaves / order / integers exact, leaves of <= 2 points bit-identical, larger leaves within count * 2^-23 * max|coordinate| -- is what
+`check_index_order` asserts.  FLS_DEVICE_VOXELGRID=0 = the exact host filter (worker pool).
 """
 import ctypes as C
 
@@ -53,6 +52,20 @@ def leaf_counts(cloud, leaf):
 
 
 def check(cloud, leaf):
+    """default mode: the device output IS the reference's, bit for bit"""
+    ref = O.voxel_grid(cloud, leaf)
+    rc, out = device_voxel_grid(cloud, leaf)
+    assert rc == 0, rc
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    cnt, amax = leaf_counts(cloud, leaf)
+    assert len(cnt) == ref.shape[0]
+    same = (out.view(np.uint32) == ref.view(np.uint32)).all(1)
+    assert same.all(), (int((~same).sum()), int(len(same)), np.flatnonzero(~same)[:5], cnt[~same][:5])
+    return dict(leaves=int(len(cnt)), big=int((cnt > 2).sum()), max_leaf=int(cnt.max()), identical=1.0, max_ulp=0.0)
+
+
+def check_index_order(cloud, leaf):
+    """FLS_DEVICE_VOXELGRID=2 (set by the caller): the round-2/3 contract"""
     ref = O.voxel_grid(cloud, leaf)
     rc, out = device_voxel_grid(cloud, leaf)
     assert rc == 0, rc
@@ -69,6 +82,15 @@ def check(cloud, leaf):
                 max_ulp=float((d / ulp).max()))
 
 
+def test_index_order_mode_keeps_its_contract(monkeypatch):
+    monkeypatch.setenv("FLS_DEVICE_VOXELGRID", "2")
+    cfg = synth.make_config(2, with_map=False)
+    scan = np.concatenate([cfg["scan"][:, :3], np.linspace(0, 1, cfg["scan"].shape[0], dtype=np.float32)[:, None]], axis=1)
+    r = check_index_order(scan, 0.2)
+    print("index-order mode:", r)
+    assert r["leaves"] > 1000 and r["max_ulp"] <= 16 and r["identical"] < 1.0  # (it really is the other summation order)
+
+
 @pytest.mark.parametrize("cid,leaf", [(0, 0.4), (2, 0.2), (1, 0.5)])
 def test_scan_filters_of_the_benchmark_configs(cid, leaf):
     """the source filters Match runs: configs[0] (16x900 scan, 0.4 m), configs[2] (64x1800 scan, 0.2 m), and a coarse one"""
@@ -76,7 +98,7 @@ def test_scan_filters_of_the_benchmark_configs(cid, leaf):
     scan = np.concatenate([cfg["scan"][:, :3], np.linspace(0, 1, cfg["scan"].shape[0], dtype=np.float32)[:, None]], axis=1)
     r = check(scan, leaf)
     print(cid, leaf, r)
-    assert r["leaves"] > 1000 and r["max_ulp"] <= 16
+    assert r["leaves"] > 1000 and r["big"] > 100
 
 
 def test_random_clouds_edge_cases():
@@ -101,6 +123,10 @@ def test_random_clouds_edge_cases():
             continue
         box = np.prod(np.floor((fin.max(0) - fin.min(0)).astype(np.float64) / leaf) + 1)
         if box > 2 ** 31 - 1:  # "leaf size too small": declined (the host filter copies the input)
+            assert device_voxel_grid(a, leaf)[0] == _lib.FLS_ERR_STATE
+            declined += 1
+            continue
+        if len(fin) != len(a):  # the reference sorts the finite points only: a cloud with non-finite points is the host filter's
             assert device_voxel_grid(a, leaf)[0] == _lib.FLS_ERR_STATE
             declined += 1
             continue
@@ -136,9 +162,9 @@ def test_declined_inputs():
 
 @pytest.mark.parametrize("mode,y,cid,loc", [("IcpOptimized", reg.YAML_NCLT_ICP, 0, True), ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, False)])
 def test_match_with_device_source_filter(mode, y, cid, loc, monkeypatch):
-    """ICP / NDT Match with the opt-in device source filter: same number of filtered points, same iteration count and
-    effective points as the exact host filter, poses within the centroid-rounding noise (1e-6 m / rad); then a map update
-    from the device-resident filtered cloud (mapping-mode NDT)."""
+    """ICP / NDT Match with the device source filter (default) against the host filter (FLS_DEVICE_VOXELGRID=0): the filtered clouds
+    are bit-identical, so the two handles return IDENTICAL poses; then a map update from the device-resident filtered cloud
+    (mapping-mode NDT)."""
     cfg = synth.make_config(cid, scale=1.0 if cid == 0 else 0.2)
     res = {}
     for dev in (0, 1):
@@ -156,8 +182,7 @@ def test_match_with_device_source_filter(mode, y, cid, loc, monkeypatch):
     assert h[7] == 0 and h[8] == 2 and d[7] == 2 and d[8] == 0  # which filter ran
     assert h[0] == d[0] and h[4] == d[4] and h[2] == d[2] and h[3] == d[3]
     for a, b in ((h[1], d[1]), (h[5], d[5])):
-        dt, dr = synth.pose_error(a, b)
-        assert dt < 1e-6 and dr < 1e-6, (dt, dr)
+        assert np.array_equal(a, b), synth.pose_error(a, b)
     assert h[6] == d[6]  # map size after the updates
     if mode == "IncrementalNDT":  # with the device filter the whole update chain (transform, second VoxelGrid, UpdateVoxel) stays on the device
         assert h[9] == 0 and d[9] == 2, (h[9], d[9])
@@ -172,6 +197,6 @@ def test_voxel_grid_cloud_entry_point_device_mode():
     exact = reg.VoxelGridCloud(cloud, 0.5, on_device=False)
     rc, hook = device_voxel_grid(cloud, 0.5)
     assert rc == 0 and np.array_equal(dev.view(np.uint32), hook.view(np.uint32))
-    assert dev.shape == exact.shape and np.allclose(dev, exact, rtol=0, atol=2e-4)
+    assert dev.shape == exact.shape and np.array_equal(dev.view(np.uint32), exact.view(np.uint32))
     far = np.array([[0, 0, 0, 1], [1e6, 1e6, 1e6, 2]], np.float32)  # "leaf size too small": the device declines, the exact filter copies the input
     assert np.array_equal(reg.VoxelGridCloud(far, 0.1, on_device=True), far)

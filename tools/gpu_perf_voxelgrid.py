@@ -1,5 +1,5 @@
-"""What the source VoxelGrid costs inside fls_match for the ICP / NDT kinds, host (exact, default) vs device
-(FLS_DEVICE_VOXELGRID=1, contract in csrc/kernels_voxelgrid.hpp).  One process per setting (the switch is read at create).
+"""What the source VoxelGrid costs inside fls_match for the ICP / NDT kinds: host filter (0), device filter with std::sort's order
+(1, default since round 4: bit-identical), device filter with the stable radix sort (2, round-2/3 contract).  One process per setting.
 usage: python tools/gpu_perf_voxelgrid.py            (spawns the four runs)"""
 import json
 import os
@@ -27,7 +27,7 @@ def one(kind):
         return (time.perf_counter() - t0) / n * 1e3
     run(5)
     ms = run(40)
-    print(json.dumps({"kind": kind, "device_filter": os.environ.get("FLS_DEVICE_VOXELGRID", "0"), "n_raw": int(cfg["scan"].shape[0]),
+    print(json.dumps({"kind": kind, "FLS_DEVICE_VOXELGRID": os.environ.get("FLS_DEVICE_VOXELGRID", "1"), "n_raw": int(cfg["scan"].shape[0]),
                       "n_filtered": int(m.stats.n_source), "iterations": int(m.stats.iterations), "ms_per_match_host_buffers": round(ms, 3),
                       "device_runs": m.map_size(105), "host_runs": m.map_size(106)}))
 
@@ -37,5 +37,5 @@ if __name__ == "__main__":
         one(sys.argv[1])
     else:
         for kind in ("icp", "ndt"):
-            for dev in ("0", "1"):
+            for dev in ("0", "1", "2"):  # host filter | device, std::sort order (default) | device, index order
                 subprocess.run([sys.executable, __file__, kind], env=dict(os.environ, FLS_DEVICE_VOXELGRID=dev), check=False)
