@@ -593,12 +593,13 @@ __global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* _
     upd_commit(st, mb, seq, n_bricks_cap);
 }
 
-// ---- the short chain (round 4): six dependent launches instead of eleven --------------------------------------------------------
+// ---- the short chain (round 4): seven dependent launches instead of eleven --------------------------------------------------------
 // A dependent launch costs ~7 us on this path (2-5 us of work + ~4 us of dispatch latency), so the launches that only scanned a
 // few hundred block totals, flipped first -> last ranks or published the result are folded into their neighbours:
 //   ivox_add_decide_kernel (+ count)  ->  ivox_upd_seq_nb (every block sums the block totals before it: no scan1)  ->  ivox_upd_plan
 //   ->  ivox_upd_last_regions (every block sums the plan totals and evaluates the verdict itself: no scan2, no separate `last`)
-//   ->  ivox_upd_points  ->  ivox_upd_finish_commit (the last block to finish publishes: no commit launch).
+//   ->  ivox_upd_points  ->  ivox_upd_finish  ->  ivox_upd_commit   (ivox_upd_finish_commit, where the last block to finish publishes, is
+//   the FLS_IVOX_FUSED_COMMIT=1 variant: measured slower, 15-26 us against 4.6 + 4.1 us).
 // Same device functions, same arithmetic.  Batches that may evict keep the long chain (the selection needs grid-wide steps of its own).
 __global__ void __launch_bounds__(kUpdBlock)
 ivox_upd_seq_nb(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st, const int nblocks) {
