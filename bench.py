@@ -773,6 +773,9 @@ def main():
             "value": value, "unit": "scans/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "protocol": {"version": 3, "pre_warm_matches": PRE_WARM_MATCHES, "event_bracketed_steps": "mid-period, one step in 32",
+                         "note": "version 3 since round 3 (256 untimed pre-warm Matches, mid-period event brackets, call-k oracle comparison); rounds 1-2 "
+                                 "lines (protocol 1 / 2: no pre-warm, bracket on step 0 / every 8th step) are not directly comparable"},
             "config": {"workload": "BASELINE configs[1]: Velodyne-64 synthetic scan (64x1800 = 115,200 pts), point-to-plane "
                                    "(LoamPointToPlaneIVOX semantics, YAML config_nclt.yaml) into a 1e6-pt iVox map, 1 scan per GPU per step "
                                    "(the same scan on every GPU)",
