@@ -309,14 +309,19 @@ def bench_mapping_mode(reg, synth, cfg, n_scans=6):
         import ctypes as C
         from funny_lidar_slam_amd import _lib
 
+        declined = [0]
+
         def filt(c, leaf=0.5):
-            a = np.ascontiguousarray(np.concatenate([c[:, :3], np.zeros((c.shape[0], 1), np.float32)], axis=1), np.float32)
-            out = np.zeros_like(a)
+            # pcl::VoxelGrid of the preprocessing thread (preprocessing.cpp:236-237) on the device, bit-identical to the reference's (round 4);
+            # what the device declines (introsort's heap-sort case) takes the exact host filter -- counted
+            a = np.ascontiguousarray(c, np.float32)
+            out = np.zeros((a.shape[0], 4), np.float32)
             n_out = C.c_size_t(0)
             fp = C.POINTER(C.c_float)
-            rc = _lib.lib().fls_debug_voxel_grid(0, a.ctypes.data_as(fp), a.shape[0], 4, np.float32(leaf), out.ctypes.data_as(fp), out.shape[0], C.byref(n_out))
+            rc = _lib.lib().fls_voxel_grid_cloud(0, 1, a.ctypes.data_as(fp), a.shape[0], a.shape[1], np.float32(leaf), out.ctypes.data_as(fp), out.shape[0], C.byref(n_out))
             if rc != 0:
-                raise RuntimeError(f"fls_debug_voxel_grid: {rc}")
+                declined[0] += 1
+                return np.ascontiguousarray(reg.VoxelGridCloud(c, leaf, on_device=False)[:, :3])
             return np.ascontiguousarray(out[: n_out.value, :3])
 
         fscans = [filt(sc) for sc in scans]
@@ -330,7 +335,8 @@ def bench_mapping_mode(reg, synth, cfg, n_scans=6):
             guess = T
         res["filtered_planar_cloud_0p5m"] = {"scan_points": int(np.median([s.shape[0] for s in fscans])), "map_points_after": m.map_size(),
                                              "ms_per_scan_match_plus_update_from_host_buffers": 1e3 * float(np.median(tb[1:])),
-                                             "gn_iterations": its, "device_batches": m.map_size(103), "refused_batches": m.map_size(104)}
+                                             "gn_iterations": its, "device_batches": m.map_size(103), "refused_batches": m.map_size(104),
+                                             "preprocessing_filters_declined_by_the_device": declined[0], "preprocessing_filters": n_scans + 1}
         m.close()
     except Exception as e:
         res["filtered_planar_cloud_0p5m"] = {"error": repr(e)[:200]}

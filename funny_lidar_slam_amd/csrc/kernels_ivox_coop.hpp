@@ -617,7 +617,22 @@ ivox_add_decide_kernel(const float* __restrict__ sx, const float* __restrict__ s
                        const double fs /* filter_size_map_min */, unsigned char* __restrict__ code, float4* __restrict__ pw_out,
                        const unsigned* __restrict__ nn_ids /* may be null */, const float4* __restrict__ map_pts, const unsigned n_slots,
                        uint2* __restrict__ lx /* may be null: no counting */, uint2* __restrict__ bt, unsigned* __restrict__ st_status,
-                       unsigned* __restrict__ st_apply) {
+                       unsigned* __restrict__ st_apply, const GnState* __restrict__ gn /* non-null: SPECULATIVE launch, see below */, const int max_it) {
+    // SPECULATIVE form (round 4): the host queues the decision + update chain right behind the iterations it expects the Match to need,
+    // without waiting for the result (14 us of mailbox turnaround + launch latency in front of the map update).  The launch then decides
+    // ON THE DEVICE whether LoamPointToPlaneIVOX::Match would reach AddCloudToLocalMap here (:197-206): the Gauss-Newton loop has ended
+    // (stop rule or max_iterations) and n_valid >= 50.  If not, the whole chain marks itself skipped (kUpdSkipped = 16) and does nothing;
+    // the host queues another chain behind the iterations it adds.  The pose is the device's (GnState::T), not a launch argument.
+    Pose16 Tl = Tw;
+    if (gn != nullptr) {
+        const bool go = (gn->done != 0 || gn->iter >= max_it) && gn->n_valid >= 50;
+        if (!go) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) { *st_status = 16u; *st_apply = 0u; }
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Tl.m[q] = gn->T[q];
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     unsigned char c = 0;  // this point's code (0 also for the threads beyond n)
     if (i < n || (MATERIALIZE && i < nn_n)) {
@@ -646,9 +661,9 @@ ivox_add_decide_kernel(const float* __restrict__ sx, const float* __restrict__ s
         }
         if (i < n) {
             const double x = sx[i], y = sy[i], z = sz[i];
-            const float wx = (float)(((Tw.m[0] * x + Tw.m[4] * y) + Tw.m[8] * z) + Tw.m[12]);
-            const float wy = (float)(((Tw.m[1] * x + Tw.m[5] * y) + Tw.m[9] * z) + Tw.m[13]);
-            const float wz = (float)(((Tw.m[2] * x + Tw.m[6] * y) + Tw.m[10] * z) + Tw.m[14]);
+            const float wx = (float)(((Tl.m[0] * x + Tl.m[4] * y) + Tl.m[8] * z) + Tl.m[12]);
+            const float wy = (float)(((Tl.m[1] * x + Tl.m[5] * y) + Tl.m[9] * z) + Tl.m[13]);
+            const float wz = (float)(((Tl.m[2] * x + Tl.m[6] * y) + Tl.m[10] * z) + Tl.m[14]);
             pw_out[i] = make_float4(wx, wy, wz, 0.f);
             auto neighbour = [&](const int k) -> float4 {
                 if (MATERIALIZE) return nb[k];

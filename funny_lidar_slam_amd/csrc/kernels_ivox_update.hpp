@@ -39,7 +39,8 @@ constexpr unsigned kUpdNoRank = 0xFFFFFFFFu;
 constexpr int kUpdBlock = 256;
 constexpr int kUpdMaxBlocks = 1024;  // one-workgroup scan of the block totals: n <= 262,144 source points per batch
 
-enum : unsigned { kUpdOk = 0u, kUpdNeedHost = 1u, kUpdEvictConflict = 2u, kUpdArrayFull = 4u, kUpdOutside = 8u };  // any bit set: the batch is refused
+enum : unsigned { kUpdOk = 0u, kUpdNeedHost = 1u, kUpdEvictConflict = 2u, kUpdArrayFull = 4u, kUpdOutside = 8u,  // any bit set: the batch is refused
+                  kUpdSkipped = 16u };  // a speculative chain found that the Match does not update the map here: nothing ran (ivox_add_decide_kernel)
 
 // persistent device-side bookkeeping of the map image + the per-batch scratch words
 struct IvoxUpdState {
@@ -344,6 +345,7 @@ ivox_upd_seq(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restri
 __global__ void __launch_bounds__(kUpdBlock)
 ivox_upd_plan(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState* __restrict__ st) {
     __shared__ unsigned wsum[kUpdBlock / 64][4];
+    if (st->status & kUpdSkipped) return;
     const unsigned A = st->n1 + st->n2;
     const unsigned r = blockIdx.x * kUpdBlock + threadIdx.x;
     unsigned v[4] = {0u, 0u, 0u, 0u}, tot[4];
@@ -563,7 +565,7 @@ ivox_upd_finish(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState*
 }
 
 __device__ __forceinline__ void upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* __restrict__ mb, const unsigned seq, const unsigned n_bricks_cap) {
-    const unsigned A = st->n1 + st->n2;
+    const unsigned A = (st->status & kUpdSkipped) ? 0u : st->n1 + st->n2;
     if (st->n_bricks > n_bricks_cap) st->n_bricks = n_bricks_cap;  // (a refused batch overshot the pool)
     if (st->apply) {
         st->n_alive += st->creations;
@@ -604,6 +606,7 @@ __global__ void ivox_upd_commit(IvoxUpdState* __restrict__ st, IvoxUpdMailbox* _
 __global__ void __launch_bounds__(kUpdBlock)
 ivox_upd_seq_nb(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st, const int nblocks) {
     __shared__ unsigned wsum[kUpdBlock / 64][4];
+    if (st->status & kUpdSkipped) return;
     unsigned pre[2], all[2];
     block_prefix_total<2>(b.bt, nblocks, (int)blockIdx.x, pre, all, wsum);  // bt: raw block totals of the decision codes (ivox_add_decide_kernel)
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->n1 = all[0]; st->n2 = all[1]; }
@@ -618,6 +621,7 @@ ivox_upd_seq_nb(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __res
 __global__ void __launch_bounds__(kUpdBlock)
 ivox_upd_last_regions(const IvoxUpdBatch b, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st) {
     __shared__ unsigned wsum[kUpdBlock / 64][8];
+    if (st->status & kUpdSkipped) return;
     const unsigned A = st->n1 + st->n2;
     const int nblocks = (int)((A + kUpdBlock - 1) / kUpdBlock);
     if ((int)blockIdx.x >= nblocks && blockIdx.x != 0) return;  // (block 0 always runs: it records the verdict, also of an empty batch)

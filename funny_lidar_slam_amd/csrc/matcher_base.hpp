@@ -215,6 +215,11 @@ struct fls_matcher {
     int expect_iters = 4;
     template <class F>
     unsigned run_mailbox_loop(int iters, size_t points_per_iter, F&& launch) {
+        return run_mailbox_loop(iters, points_per_iter, launch, [](int) {});
+    }
+    // after_chunk(launched): called after every chunk of iterations has been queued, before the host waits (speculative work behind the chunk)
+    template <class F, class G>
+    unsigned run_mailbox_loop(int iters, size_t points_per_iter, F&& launch, G&& after_chunk) {
         match_id = (match_id + 1) & 0x7fffffu;
         if (profiling) ensure_events(iters);
         if (count_traffic) FLS_HIP(hipMemsetAsync(d_tc.p, 0, sizeof(fls::TrafficCounters), stream));
@@ -225,6 +230,7 @@ struct fls_matcher {
             const int end = std::min(iters, launched + chunk);
             for (int it = launched; it < end; ++it) launch(it, it == 0 ? 1 : 0);
             launched = end;
+            after_chunk(launched);
             FLS_HIP(hipGetLastError());
             word = wait_mailbox(launched);
             if (((word >> 8) & 1u) || launched >= iters) break;

@@ -39,6 +39,10 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     bool fused_update = false;     // FLS_IVOX_FUSED_UPDATE=1 (A/B): small batches as ONE launch of one workgroup
     bool short_chain_update = true;  // FLS_IVOX_SHORT_CHAIN=0 (A/B): the round-3 chain of eleven launches for every batch
     size_t n_fused_updates = 0, n_short_updates = 0;
+    // the decision + update chain queued behind the iterations the Match is expected to need, gated on the device (ivox_add_decide_kernel):
+    // removes the host's mailbox turnaround + first-launch latency (~14 us) in front of the map update.  FLS_IVOX_SPECULATIVE=0: wait first.
+    bool speculative_update = true, spec_pending = false, last_chain_skipped = false;
+    size_t n_speculative = 0, n_speculative_skipped = 0;
     bool fused_commit = false;     // FLS_IVOX_FUSED_COMMIT=1 (A/B): the last finishing block publishes instead of a commit launch (measured slower: 15-26 us against 4.6 + 4.1 us)
     int finish_blocks = kFinishBlocks;  // FLS_IVOX_FINISH_BLOCKS (A/B)
     bool device_evict = true;      // FLS_IVOX_DEVICE_EVICT=0: a batch that reaches the LRU capacity is refused (round-2 behaviour, with the margin rule)
@@ -113,6 +117,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (const char* e = std::getenv("FLS_IVOX_FUSED_UPDATE")) fused_update = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_SHORT_CHAIN")) short_chain_update = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_HOST_SRC")) host_src = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FLS_IVOX_SPECULATIVE")) speculative_update = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_FUSED_COMMIT")) fused_commit = std::atoi(e) != 0;
         if (const char* e = std::getenv("FLS_IVOX_FINISH_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) finish_blocks = v; }
         d_upd_state.reserve(1);
@@ -208,6 +213,11 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
 
     // One batch of the resident scan through the device-side AddPoints.  Returns true when the device applied it.
     bool device_add_points(const size_t n, const bool counted_by_decide) {
+        if (!enqueue_update_chain(n, counted_by_decide)) return false;
+        return await_update_chain(n);
+    }
+    // the launches of one device AddPoints batch (no waiting); false: the batch is too large for the device path
+    bool enqueue_update_chain(const size_t n, const bool counted_by_decide) {
         const int nb = int((n + kUpdBlock - 1) / kUpdBlock);
         if (nb > kUpdMaxBlocks) return false;
         d_lx.reserve(n); d_bt.reserve(size_t(nb)); d_seq_src.reserve(n); d_seq_cell.reserve(n); d_jj.reserve(n); d_tlist.reserve(n);
@@ -279,7 +289,11 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         hipLaunchKernelGGL(ivox_upd_commit, dim3(1), dim3(64), 0, stream, d_upd_state.p, upd_mb_dev, upd_seq, unsigned(image.n_bricks_cap));
         }
         FLS_HIP(hipGetLastError());
-        // the verdict of the batch (a few words in host-mapped memory; no copy, no stream synchronisation)
+        return true;
+    }
+    // the verdict of the batch queued last; true: applied.  (kUpdSkipped -- a speculative chain that found nothing to do -- reads as "not applied".)
+    bool await_update_chain(const size_t n) {
+        // (a few words in host-mapped memory; no copy, no stream synchronisation)
         for (unsigned long long spin = 1;; ++spin) {
             if (__atomic_load_n(&upd_mb_host->seq, __ATOMIC_ACQUIRE) == upd_seq) break;
             if ((spin & 0x3fffu) == 0) {
@@ -292,6 +306,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
 #endif
         }
         dev_n_bricks = std::min<size_t>(upd_mb_host->n_bricks, image.n_bricks_cap);  // (bricks are created whatever the verdict)
+        last_chain_skipped = (upd_mb_host->status & kUpdSkipped) != 0u;
+        if (last_chain_skipped) return false;
         if (upd_mb_host->status != kUpdOk) {
             if (upd_mb_host->status & kUpdEvictConflict) ++n_refused_conflict;
             if (upd_mb_host->status & kUpdArrayFull) { ++n_refused_full; rebuild_after_replay = true; }  // point array or brick pool: re-flatten with more room
@@ -343,7 +359,41 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         return add_cloud_impl(cloud);
     }
 
-    fls_status add_cloud_impl(const std::vector<PtI>& planar_cloud, const bool from_resident_scan = false) {
+    // the decision launch (ivox_add_decide_kernel): codes + world points of the resident scan; in device mode it also counts the codes and
+    // opens the batch.  speculative: gated on the device by the Gauss-Newton state, pose read from it.  Returns "counted".
+    bool launch_decide(const size_t n, const bool speculative) {
+        d_code.reserve(n);
+        d_pw.reserve(n);
+        Pose16 Tw;
+        std::memcpy(Tw.m, T_, sizeof(Tw.m));
+        const GnState* const gn = speculative ? (const GnState*)d_state.p : nullptr;
+        const int max_it = int(p.max_iterations);
+        // device mode: the decision launch also counts the insertion codes per block and opens the batch (ivox_upd_count's job)
+        const int nb = int((n + kUpdBlock - 1) / kUpdBlock);
+        const bool count_here = device_map && nb <= kUpdMaxBlocks;
+        if (count_here) { d_lx.reserve(n); d_bt.reserve(size_t(nb)); }
+        uint2* const lx_arg = count_here ? d_lx.p : nullptr;
+        uint2* const bt_arg = count_here ? d_bt.p : nullptr;
+        unsigned* const st_status = count_here ? &d_upd_state.p->status : nullptr;
+        unsigned* const st_apply = count_here ? &d_upd_state.p->apply : nullptr;
+        // (the update moves map slots: lists still in ids form become rows in the same launch)
+        if (nn_ids_mode && (speculative || !nn_rows_current) && nn_n > 0) {
+            const size_t m = std::max(n, nn_n);
+            hipLaunchKernelGGL(ivox_add_decide_kernel<true>, dim3(unsigned((m + 255) / 256)), dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p,
+                               int(n), Tw, d_nn.p, d_nn_cnt.p, int(nn_n), filter_size_map_min,
+                               d_code.p, d_pw.p, (const unsigned*)d_nn_ids.p, (const float4*)image.d_pts.p, unsigned(image.d_pts.cap), lx_arg, bt_arg, st_status, st_apply, gn, max_it);
+            if (!speculative) nn_rows_current = true;
+        } else {
+            hipLaunchKernelGGL(ivox_add_decide_kernel<false>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p,
+                               int(n), Tw, d_nn.p, d_nn_cnt.p, int(nn_n), filter_size_map_min,
+                               d_code.p, d_pw.p, (const unsigned*)(nn_ids_mode ? d_nn_ids.p : nullptr), (const float4*)image.d_pts.p, unsigned(image.d_pts.cap), lx_arg, bt_arg,
+                               st_status, st_apply, gn, max_it);
+        }
+        FLS_HIP(hipGetLastError());
+        return count_here;
+    }
+
+    fls_status add_cloud_impl(const std::vector<PtI>& planar_cloud, const bool from_resident_scan = false, const bool pre_enqueued = false) {
         if (p.is_localization_mode) { device_map = false; is_first = true; ivox.clear(); image_built = false; }
         fls_status rc = FLS_OK;
         if (!(from_resident_scan && !is_first)) { ensure_nn_rows(); sync_host_from_device(); }  // every other branch works on the host mirror
@@ -359,43 +409,30 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             const auto tm0 = std::chrono::steady_clock::now();
             bool counted = false;
             if (n) {
-                d_code.reserve(n);
-                d_pw.reserve(n);
-                Pose16 Tw;
-                std::memcpy(Tw.m, T_, sizeof(Tw.m));
-                // device mode: the decision launch also counts the insertion codes per block and opens the batch (ivox_upd_count's job)
-                const int nb = int((n + kUpdBlock - 1) / kUpdBlock);
-                const bool count_here = device_map && nb <= kUpdMaxBlocks;
-                if (count_here) { d_lx.reserve(n); d_bt.reserve(size_t(nb)); }
-                uint2* const lx_arg = count_here ? d_lx.p : nullptr;
-                uint2* const bt_arg = count_here ? d_bt.p : nullptr;
-                unsigned* const st_status = count_here ? &d_upd_state.p->status : nullptr;
-                unsigned* const st_apply = count_here ? &d_upd_state.p->apply : nullptr;
-                counted = count_here;
-                // (the update below moves map slots: lists still in ids form become rows in the same launch)
-                if (nn_ids_mode && !nn_rows_current && nn_n > 0) {
-                    const size_t m = std::max(n, nn_n);
-                    hipLaunchKernelGGL(ivox_add_decide_kernel<true>, dim3(unsigned((m + 255) / 256)), dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p,
-                                       int(n), Tw, d_nn.p, d_nn_cnt.p, int(nn_n), filter_size_map_min,
-                                       d_code.p, d_pw.p, (const unsigned*)d_nn_ids.p, (const float4*)image.d_pts.p, unsigned(image.d_pts.cap), lx_arg, bt_arg, st_status, st_apply);
-                    nn_rows_current = true;
+                if (!pre_enqueued) {
+                    counted = launch_decide(n, /*speculative=*/false);
+                    ensure_nn_rows();
+                    if (device_map && !enqueue_update_chain(n, counted)) { ++n_host_fallbacks; sync_host_from_device(); }
                 } else {
-                    hipLaunchKernelGGL(ivox_add_decide_kernel<false>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, scan.x.p, scan.y.p, scan.z.p,
-                                       int(n), Tw, d_nn.p, d_nn_cnt.p, int(nn_n), filter_size_map_min,
-                                       d_code.p, d_pw.p, (const unsigned*)(nn_ids_mode ? d_nn_ids.p : nullptr), (const float4*)image.d_pts.p, unsigned(image.d_pts.cap), lx_arg, bt_arg,
-                                       st_status, st_apply);
+                    counted = true;
                 }
-                FLS_HIP(hipGetLastError());
-                ensure_nn_rows();
                 if (device_map) {
-                    if (device_add_points(n, counted)) {
+                    if (await_update_chain(n)) {
                         if (host_timing)
                             std::fprintf(stderr, "[fls host] device AddPoints: %u points into %u voxels, %.3f ms\n", upd_mb_host->added, upd_mb_host->touched,
                                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count());
                         return FLS_OK;
                     }
-                    // refused (an eviction inside the batch, a point outside the voxel window, the point array full): nothing was
-                    // applied; the exact sequential path below replays the batch on the host mirror
+                    if (last_chain_skipped) {
+                        // a speculative chain that judged "no update here" although the host wants one (cannot happen while host and device
+                        // read the same words; kept as a safe path): decide + apply the ordinary way
+                        if (nn_ids_mode) nn_rows_current = false;  // (the skipped launch materialised nothing)
+                        counted = launch_decide(n, false);
+                        ensure_nn_rows();
+                        if (enqueue_update_chain(n, counted) && await_update_chain(n)) return FLS_OK;
+                    }
+                    // refused (an eviction-order conflict, the point array or brick pool full): nothing was applied; the exact sequential
+                    // path below replays the batch on the host mirror
                     ++n_host_fallbacks;
                     sync_host_from_device();
                 }
@@ -567,6 +604,17 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         const BrickDir win = use_dense ? im.bricks() : BrickDir{nullptr, 0u, nullptr, 0u};
         Pose16 T0;
         std::memcpy(T0.m, T, sizeof(T0.m));
+        // speculative map update (see speculative_update): only where the short chain applies and the call would update the map if it converges
+        const bool spec = speculative_update && update_map && !p.is_localization_mode && !borrowed && !is_first && device_map && short_chain_update && !fused_update &&
+                          dev_n_alive + n < ivox.capacity && int((n + kUpdBlock - 1) / kUpdBlock) <= kUpdMaxBlocks;
+        spec_pending = false;
+        auto after_chunk = [&](int) {
+            if (!spec) return;
+            if (spec_pending) ++n_speculative_skipped;  // (the chain behind the previous chunk found the Match unfinished)
+            const bool counted = launch_decide(n, /*speculative=*/true);
+            spec_pending = counted && enqueue_update_chain(n, counted);
+            ++n_speculative;
+        };
         const unsigned word = run_mailbox_loop(iters, n, [&](int it, int first) {
             hipEvent_t e0 = profiling ? ev[2 * it] : nullptr, e1 = profiling ? ev[2 * it + 1] : nullptr;
             hipEvent_t f0 = nullptr, f1 = nullptr;
@@ -589,7 +637,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             if (first) FLS_FIT(true); else FLS_FIT(false);
 #undef FLS_FIT_NT
 #undef FLS_FIT
-        });
+        }, after_chunk);
         scan_in_staging = false;  // (the first launch left the device copy)
         if (nn_ids_mode) nn_rows_current = false;  // the lists of every point with candidates are slots of the current image now
         const Mailbox& mb = *mb_host;
@@ -607,9 +655,13 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         stats.converged = has_converge ? 1 : 0;
         fls_status rc = has_converge ? FLS_OK : FLS_NOT_CONVERGED;
         if (has_converge && !p.is_localization_mode && update_map && !borrowed) {  // :205-206
-            const fls_status arc = add_cloud_impl(scan.host, /*from_resident_scan=*/true);
+            if (spec_pending && nn_ids_mode) nn_rows_current = true;  // (the speculative decision launch turned the lists into rows)
+            const fls_status arc = add_cloud_impl(scan.host, /*from_resident_scan=*/true, /*pre_enqueued=*/spec_pending);
             if (arc != FLS_OK) rc = arc; else stats.map_updated = 1;
+        } else if (spec_pending) {
+            ++n_speculative_skipped;  // not converged: the chain skipped itself on the device (n_valid < 50), nothing to collect
         }
+        spec_pending = false;
         if (out) *out = stats;
         return rc;
     }
@@ -737,6 +789,8 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (slot == 103) return n_device_updates;  //                ... by the device-side AddPoints
         if (slot == 104) return n_host_fallbacks;  //                batches the device refused (replayed on the host)
         if (slot == 122) return n_fused_updates;    //                ... of which in the one-launch form
+        if (slot == 124) return n_speculative;      //                chains queued speculatively behind the iterations
+        if (slot == 125) return n_speculative_skipped;  //            ... that the device skipped (the Match needed more iterations / did not converge)
         if (slot == 123) return n_short_updates;    //                ... of which in the short chain (five launches behind the decision)
         if (slot == 117) return n_device_evictions;  //              voxels evicted inside device batches
         if (slot == 119) return n_refused_conflict;  //              refusals by reason: eviction order conflict / point array full / point outside the window

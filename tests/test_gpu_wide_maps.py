@@ -220,3 +220,47 @@ def test_device_addpoints_large_and_small_batches_alternate(monkeypatch):
         guess = T_ref
     assert m.map_size(103) == 4 and m.map_size(122) == 2 and m.map_size(123) == 2 and m.map_size(104) == 0, (m.map_size(103), m.map_size(122), m.map_size(123), m.map_size(104))
     m.close(); o.close()
+
+
+@pytest.mark.parametrize("spec", ["1", "0"])
+def test_speculative_update_chain(spec, monkeypatch):
+    """The decision + update chain is queued behind the iterations the Match is expected to need and gates itself on the device
+    (Gauss-Newton loop ended and n_valid >= 50: what LoamPointToPlaneIVOX::Match checks before AddCloudToLocalMap, :197-206); a chain that
+    finds the Match unfinished skips itself and the host queues another one behind the added iterations.  FLS_IVOX_SPECULATIVE=0 waits for
+    the result first.  Same poses, ids, map sizes as the oracle either way (the 8-scan replay + the 24-scan multi-site run)."""
+    monkeypatch.setenv("FLS_IVOX_SPECULATIVE", spec)
+    m, o = _replay(8)
+    assert m.map_size(103) >= 7 and m.map_size(104) == 0
+    queued, skipped = m.map_size(124), m.map_size(125)
+    print(f"speculative = {spec}: {queued} chains queued, {skipped} skipped on the device, {m.map_size(103)} batches applied")
+    assert (queued >= 7 and queued - skipped == m.map_size(103)) if spec == "1" else (queued == 0 and skipped == 0), (queued, skipped, m.map_size(103))
+    m.close(); o.close()
+    m, o = multi_site_replay(3, 9)
+    assert m.map_size(104) == 0
+    m.close(); o.close()
+
+
+def test_speculative_chain_skips_itself_when_the_match_does_not_converge():
+    """A scan that sees nothing of the map: n_valid = 0 < 50, Match returns false, the reference does not touch the map -- the chain queued
+    behind the iterations must leave the image alone (status kUpdSkipped), and the next ordinary scan must still agree with the oracle."""
+    scene = synth.make_scene()
+    rng = synth.rng_for(1, 55)
+    mp = synth.sample_map(scene, 60000, synth.rng_for(1, 0, 5), radius=30.0)
+    y = reg.YAML_NCLT_IVOX
+    m = reg.make_matcher("PointToPlane_IVOX", y)
+    o = util.oracle_for("PointToPlane_IVOX", y)
+    m.AddCloudToLocalMap([mp]); o.AddCloudToLocalMap(mp)
+    lid = dict(synth.VELODYNE_64, n_az=60)
+    good = synth.cast_scan(scene, np.eye(4), rng=rng, max_range=38.0, **lid)
+    far = (good[:3000] + np.float32(4000.0)).astype(np.float32)
+    guess = np.eye(4)
+    for k, scan in enumerate((good, far, good)):
+        T = guess.copy()
+        ok = m.Match(reg.PointcloudCluster(planar_cloud_=scan), T, update_map=True)
+        ok_ref, T_ref = o.Match(scan, guess, update_map=True)
+        assert ok == ok_ref and m.stats.map_updated == o.stats.map_updated, (k, ok, ok_ref)
+        assert m.map_size() == o.map_size() and m.map_size(102) == o.map_voxels(), k
+        if ok_ref:
+            util.assert_same_registration(m, o, ok, T, ok_ref, T_ref, sets_only_tail=True, max_tie_rows=int(o.counters().tie_queries))
+    assert m.map_size(125) >= 1, "the far scan's chain must have skipped itself"
+    m.close(); o.close()
