@@ -21,8 +21,9 @@
 //             previous level, medians of this one; es_count / es_scatter: stop lists through per-tile counts; es_swap)
 //   regime 2  every range of <= kEsLds records: one workgroup takes it into LDS and runs ALL its remaining levels there
 //             (es_lds_kernel), then ranks the records of every final <= 16 block (= the insertion sort) and writes them back.
-// The heap-sort fallback of introsort (recursion deeper than 2 log2 n: adversarial inputs) is not reproduced: the sort reports
-// failure and the caller takes the host path.
+// The heap-sort fallback of introsort (recursion deeper than 2 log2 n) IS reproduced for ranges that fit into LDS (es_heap_sort: real scans
+// reach it routinely); only a range still longer than kEsLds records at depth 0 makes the sort report failure (the caller takes the host
+// path).
 #pragma once
 #include "device_common.hpp"
 
@@ -260,6 +261,40 @@ __device__ __forceinline__ void es_push(EsQueue* __restrict__ q, EsWork* __restr
     __hip_atomic_store(&ready[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// std::__partial_sort(first, last, last) = __make_heap + __sort_heap of libstdc++ (bits/stl_heap.h), what introsort falls back to when a
+// range exhausts the depth limit 2 log2 n.  NOT a corner case here: ring-major LiDAR leaf indices are piecewise monotone, median-of-three
+// splits them lopsidedly, and most 115 k-point scans end with a few ranges of 30-70 records at depth 0 (tools/es_decline_probe.py, the CPU
+// model) -- the reference's own std::sort heap-sorts them, so the device does too: ONE lane runs the restated routines on the range in LDS
+// (the order heap sort leaves equal keys in is as implementation-defined as introsort's; tests/host/exact_sort_model_test.cpp checks the
+// restatement against std::sort on 1,500 such ranges).  Keys compare with '<' only, values ride along.
+__device__ __forceinline__ void es_heap_adjust(unsigned* __restrict__ k, unsigned* __restrict__ v, int hole, const int len, const unsigned vk, const unsigned vv) {
+    const int top = hole;
+    int second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (k[second] < k[second - 1]) second--;
+        k[hole] = k[second]; v[hole] = v[second];
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        k[hole] = k[second - 1]; v[hole] = v[second - 1];
+        hole = second - 1;
+    }
+    int parent = (hole - 1) / 2;  // __push_heap
+    while (hole > top && k[parent] < vk) { k[hole] = k[parent]; v[hole] = v[parent]; hole = parent; parent = (hole - 1) / 2; }
+    k[hole] = vk; v[hole] = vv;
+}
+__device__ __forceinline__ void es_heap_sort(unsigned* __restrict__ k, unsigned* __restrict__ v, const int len) {  // k, v: the range's first record
+    if (len >= 2)
+        for (int parent = (len - 2) / 2;; --parent) { es_heap_adjust(k, v, parent, len, k[parent], v[parent]); if (parent == 0) break; }
+    for (int last = len - 1; last >= 1; --last) {
+        const unsigned vk = k[last], vv = v[last];
+        k[last] = k[0]; v[last] = v[0];
+        es_heap_adjust(k, v, 0, last, vk, vv);
+    }
+}
+
 __global__ void __launch_bounds__(kEsTaskThreads)
 es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* __restrict__ tasks, unsigned* __restrict__ ready, const unsigned cap,
                EsQueue* __restrict__ q, unsigned* __restrict__ Lp, unsigned* __restrict__ Rl, EsState* __restrict__ st, EsMailbox* __restrict__ dbg,
@@ -445,7 +480,14 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                 const unsigned f = sa_f[sp], l = sa_l[sp];
                 const int d = sa_d[sp];
                 __syncthreads();  // (everyone has read the top of the stack)
-                if (d == 0) { if (t == 0) { s_fail = 1u; s_sp = 0u; } __syncthreads(); break; }
+                if (d == 0) {  // depth limit: heap sort (one lane), every record of the range becomes a final block of its own, next entry
+                    if (t == 0) es_heap_sort(sk + f, sv + f, (int)(l - f));
+                    __syncthreads();
+                    for (unsigned i = f + 1u + (unsigned)t; i < l; i += (unsigned)kEsTaskThreads) atomicOr(&bmask[i >> 5], 1u << (i & 31u));
+                    if (t == 0) s_sp = sp;
+                    __syncthreads();
+                    continue;
+                }
                 if (t == 0) {
                     const unsigned a = f + 1u, b = f + (l - f) / 2u, c = l - 1u;
                     const unsigned ka = sk[a], kb = sk[b], kc = sk[c];
@@ -534,7 +576,14 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                     const unsigned task_word = ws_t[w][sp];
                     const int d = ws_d[w][sp];
                     const unsigned f = task_word & 0xffffu, l = task_word >> 16;
-                    if (d == 0) { if (lane == 0) __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); sp = 0; break; }
+                    if (d == 0) {  // depth limit: heap sort by one lane; the range is sorted, every record a final block of its own
+                        if (lane == 0) es_heap_sort(sk + f, sv + f, (int)(l - f));
+                        for (unsigned i = f + 1u + (unsigned)lane; i < l; i += 64u) atomicOr(&bmask[i >> 5], 1u << (i & 31u));
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        continue;
+                    }
                     unsigned p = 0u;
                     if (lane == 0) {
                         const unsigned a = f + 1u, b = f + (l - f) / 2u, c = l - 1u;

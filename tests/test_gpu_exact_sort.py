@@ -55,15 +55,26 @@ def test_structured_inputs():
     check(k, "nearly sorted")
 
 
-def test_heap_sort_case_is_declined():
+def test_depth_limit_ranges_are_heap_sorted_like_libstdcxx():
     """A sorted array with every 97th key replaced at random drives introsort to its depth limit (2 log2 n partitions deep on a 67-record
-    range: checked with the CPU model), where libstdc++ switches to heap sort -- not reproduced on the device: the sort reports
-    FLS_ERR_STATE and the VoxelGrid callers take the host filter."""
+    range: checked with the CPU model), where libstdc++ heap-sorts the range; ring-major scans at a 0.2 m leaf do the same on most frames.
+    The device restates the heap routines (es_heap_sort): record for record the host's result."""
     rng = np.random.default_rng(5)
     n = 60000
-    k = np.sort(rng.integers(0, 5000, n)); k[::97] = rng.integers(0, 5000, k[::97].size)
-    (rh, kh, vh), (rd, kd, vd) = sort_both(k)
-    assert rh == 0 and rd == _lib.FLS_ERR_STATE, (rh, rd)
+    for step in (97, 1501):
+        k = np.sort(rng.integers(0, 5000, n)); k[::step] = rng.integers(0, 5000, k[::step].size)
+        check(k, f"nearly sorted, every {step}th key random")
+    scene = synth.make_scene()
+    srng = synth.rng_for(1, 123)
+    Tgt = np.eye(4)
+    for f in range(4):
+        c = synth.cast_scan(scene, Tgt, rng=srng, **synth.VELODYNE_64).astype(np.float32)
+        Tgt = Tgt @ synth.random_pose(srng, 0.5, 0.5)
+        for leaf in (0.2, 0.5):
+            q = np.floor(c * (np.float32(1.0) / np.float32(leaf))).astype(np.int64)
+            q -= q.min(0)
+            d = q.max(0) + 1
+            check(q[:, 0] + q[:, 1] * d[0] + q[:, 2] * d[0] * d[1], f"frame {f} leaf {leaf}")
 
 
 def test_leaf_indices_of_a_real_scan():

@@ -192,7 +192,8 @@ def test_device_addpoints_three_forms(form, monkeypatch):
     m, o = _replay(8)
     assert m.map_size(103) >= 7 and m.map_size(104) == 0
     short, one = m.map_size(123), m.map_size(122)
-    assert (short, one) == ((m.map_size(103), 0) if form == "short" else (0, m.map_size(103)) if form == "one_workgroup" else (0, 0)), (form, short, one)
+    # (short-chain launches include the speculative ones the device skipped: map_size(125))
+    assert (short - m.map_size(125), one) == ((m.map_size(103), 0) if form == "short" else (0, m.map_size(103)) if form == "one_workgroup" else (0, 0)), (form, short, one)
     m.close(); o.close()
 
 
