@@ -45,6 +45,7 @@ fls_status guarded(F&& f) {
 extern "C" {
 
 int fls_abi_version(void) { return FLS_ABI_VERSION; }
+int fls_abi_revision(void) { return FLS_ABI_REVISION; }
 int fls_device_count(void) { return gfx950_device_count(); }
 
 const char* fls_status_string(int s) {

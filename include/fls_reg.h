@@ -35,6 +35,11 @@ extern "C" {
 #endif
 
 #define FLS_ABI_VERSION 1
+/* Additive revision of ABI version 1: entry points are only ever ADDED under one FLS_ABI_VERSION (existing signatures, struct layouts and
+ * status codes do not change), and this number counts the additions -- 1: fls_match_batch, map export / import; 2: fls_voxel_grid_cloud,
+ * fls_features_*; 3: fls_replicas_*, fls_loop_match; 4: fls_debug_exact_sort.  A caller built against revision r works with any library
+ * whose fls_abi_revision() >= r. */
+#define FLS_ABI_REVISION 4
 
 /* Which reference class the handle replaces (mode strings: include/common/constant_variable.h:21-25). */
 typedef enum fls_kind {
@@ -263,6 +268,7 @@ fls_status fls_debug_exact_sort(int device_id, uint32_t* key, uint32_t* val, siz
 
 const char* fls_status_string(int status);
 int fls_abi_version(void);
+int fls_abi_revision(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => every compute call fails with FLS_ERR_DEVICE) */
 int fls_device_count(void);
 

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(built):
     for s in syms:
         assert hasattr(L, s), f"libfls_reg.so does not export {s}"
     assert sorted(_lib.EXPORTED_SYMBOLS) == syms
-    assert L.fls_abi_version() == 1
+    assert L.fls_abi_version() == 1 and L.fls_abi_revision() >= 4  # (additive revisions: include/fls_reg.h)
 
 
 def test_struct_layouts_match_header(built):
