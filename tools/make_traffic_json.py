@@ -1,4 +1,4 @@
-"""profiles/traffic_ivox_knn.json from the raw rocprofv3 --pmc CSVs of tools/prof_round3.sh (one counter group per pass).
+"""profiles/traffic_ivox_knn.json from the raw rocprofv3 --pmc CSVs of tools/prof_round4.sh (one counter group per pass).
 usage: python tools/make_traffic_json.py <dir with pmc1..pmc5 counter_collection csv copies> <trace avg launch us> > profiles/traffic_ivox_knn.json
 Units as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE in KB per dispatch, FETCH_SIZE doubled on gfx950."""
 import collections, csv, glob, json, os, sys
@@ -23,7 +23,7 @@ def active_mean(name):
 
 
 fetch, write = active_mean("FETCH_SIZE"), active_mean("WRITE_SIZE")
-out = {"kernel": "ivox_knn_kernel<4,false,true,*,true>", "source": "rocprofv3 --kernel-trace --pmc <one group per pass>, python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-batch --no-extras (tools/prof_round3.sh, profiles/r03_*_pmc_summary.txt)",
+out = {"kernel": "ivox_knn_kernel<4,false,true,*,true>", "source": "rocprofv3 --kernel-trace --pmc <one group per pass>, python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-batch --no-extras (tools/prof_round4.sh, profiles/r04_d_pmc_summary.txt)",
        "fetch_size_kb_per_launch_raw": fetch, "write_size_kb_per_launch_raw": write, "fetch_correction": 2.0,
        "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 if fetch is not None and write is not None else None}
 rd = active_mean("TCP_TCC_READ_REQ_sum")
@@ -48,5 +48,6 @@ out["trace_avg_launch_us"] = launch_us
 out["note"] = ("mean over the active launches of the first-iteration and later-iteration instantiations; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, "
                "WRITE_SIZE uncorrected; l2_read_bytes assumes 128-B TCP->TCC read requests; instruction_floor = SQ_INSTS_VALU wave-instructions x 4 cycles / 1024 SIMDs at "
                "the nominal 2.4 GHz; valu_busy = instruction_floor / the trace's launch duration; wave_* as fractions of SQ_WAVE_CYCLES.  Round 3: the neighbour lists leave "
-               "the kernel as 20-byte id rows (32-byte stride), not as 80-byte gathered rows")
+               "the kernel as 20-byte id rows (32-byte stride), not as 80-byte gathered rows.  Round 4: the voxel look-up goes through the two-level brick image "
+               "(one directory load per query + slab offsets) instead of the bounding-box window: same traffic, same instruction count")
 print(json.dumps(out, indent=1))
