@@ -516,6 +516,25 @@ def bench_c5_native(m, reg, scans, n_gpus, share, table_torch, lanes=8):
     if table_torch is not None and table_torch.shape == rows.shape:
         out["table_equals_torch_form_bitwise"] = bool(np.array_equal(rows, table_torch))
     rs.close()
+    # what replicating the map costs, measured where one GPU is enough: a second handle on device 0 filled by the
+    # device-to-device image copy (default) and by the round-3 export blob + import (FLS_REPLICAS_VIA_BLOB=1); both must answer alike
+    try:
+        sub = clusters[:32]
+        rep = {}
+        for label, env in (("device_image_copy", "0"), ("export_blob_plus_import_round3", "1")):
+            os.environ["FLS_REPLICAS_VIA_BLOB"] = env
+            t0 = time.perf_counter()
+            r2 = m.Replicas([0, 0])
+            t_all = time.perf_counter() - t0
+            oks2, T2, s2 = r2.MatchBatch(sub, T0s[:len(sub)], lanes=lanes)
+            same = all(np.array_equal(T2[k], Tb[k]) and s2[k].n_valid == sb[k].n_valid for k in range(len(sub)))
+            rep[label] = {"set_create_ms": 1e3 * t_all, "replica_fill_ms": float(r2.import_ms()[1]), "first_32_jobs_equal_the_owner_table": bool(same)}
+            r2.close()
+        out["map_replication_one_more_handle_on_this_gpu"] = rep
+    except Exception as e:  # noqa: BLE001 -- an extra, never the reason a bench line is lost
+        out["map_replication_one_more_handle_on_this_gpu"] = {"error": repr(e)}
+    finally:
+        os.environ.pop("FLS_REPLICAS_VIA_BLOB", None)
     return out
 
 

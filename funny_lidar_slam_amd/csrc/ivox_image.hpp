@@ -222,6 +222,40 @@ struct IvoxImage {
         scatter_cell_records(s, stage);
         FLS_HIP(hipStreamSynchronize(s));
     }
+    // ---- read-only replica (fls_replicas_*): the kNN side of another handle's image, device to device ----
+    // points, directory and slabs (or the per-voxel table) and nothing of the AddPoints side: the handle that owns this copy serves
+    // fls_match_batch only (P2PlaneIvoxMatcher::replicate_from).  `used_slots` / `n_bricks_live` are the SOURCE's current counts (its device
+    // state while the device maintains the map); the source's stream must be idle.
+    void clone_for_reading(const IvoxImage& src, size_t used_slots, size_t n_bricks_live, int src_device, int dst_device, hipStream_t s) {
+        auto copy = [&](void* d, const void* q, size_t bytes) {
+            if (!bytes) return;
+            if (src_device == dst_device) FLS_HIP(hipMemcpyAsync(d, q, bytes, hipMemcpyDeviceToDevice, s));
+            else FLS_HIP(hipMemcpyPeerAsync(d, dst_device, q, src_device, bytes, s));
+        };
+        want_hash = src.want_hash;
+        have_bricks = src.have_bricks;
+        used = used_slots; garbage = 0; n_pts_live = src.n_pts_live;
+        table.clear(); brick_index.clear(); brick_keys.clear(); dir.clear(); dir_dirty = false; meta_cells = 0;
+        cell_upd.clear(); pt_upd.clear();
+        d_pts.reserve(std::max<size_t>(used_slots, 1));
+        copy(d_pts.p, src.d_pts.p, used_slots * sizeof(float4));
+        mask = src.mask;
+        if (want_hash) {
+            d_table.reserve(size_t(mask) + 1);
+            copy(d_table.p, src.d_table.p, (size_t(mask) + 1) * sizeof(HashEntry));
+        }
+        dir_mask = src.dir_mask;
+        n_bricks_cap = src.n_bricks_cap;
+        if (have_bricks) {
+            d_dir.reserve(size_t(dir_mask) + 1);
+            copy(d_dir.p, src.d_dir.p, (size_t(dir_mask) + 1) * sizeof(HashEntry));
+            d_cells.reserve(std::max<size_t>(n_bricks_live, 1) * kBrickStride);
+            if (n_bricks_live == 0) FLS_HIP(hipMemsetAsync(d_cells.p, 0, kBrickStride * sizeof(uint2), s));
+            copy(d_cells.p, src.d_cells.p, n_bricks_live * kBrickStride * sizeof(uint2));
+        }
+        FLS_HIP(hipStreamSynchronize(s));
+    }
+
     // cell_upd (and pt_upd) -> the device image
     void scatter_cell_records(hipStream_t s, PinnedBuf<char>& stage) {
         const size_t np = pt_upd.size(), nc = cell_upd.size();

@@ -311,7 +311,7 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
     __shared__ unsigned short sa_f[kEsStack], sa_l[kEsStack];
     __shared__ signed char sa_d[kEsStack];
     __shared__ unsigned s_wl[kEsTaskWaves], s_wr[kEsTaskWaves], s_cnt[kEsTaskWaves];
-    __shared__ unsigned s_first, s_last, s_pivot, s_state, s_fail, s_K;
+    __shared__ unsigned s_first, s_last, s_pivot, s_state, s_fail;
     __shared__ int s_depth;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;

@@ -16,8 +16,10 @@
 // on the device: the host never synchronises inside a Match, it polls the result mailbox.
 //
 // This header holds what every LOAM-family kind shares: the point-to-plane residual, the wave reduction of
-// the rank-1 normal-equation terms (DPP row shifts: no LDS, no atomics -> bit-reproducible) and the
-// Gauss-Newton tail.  No MFMA: there is no dense contraction in this path (21+6+2 scalars per point).
+// the rank-1 normal-equation terms and the Gauss-Newton tail.  The 29 sums of a wave are entries of sum_p v_p v_p^T with
+// v_p = (J0..J5, r, 1): they run as eight v_mfma_f64_16x16x4_f64 issues over a per-wave LDS tile (reduce_rank1_mfma_and_store, fixed
+// issue order -> bit-reproducible; a measured departure from north_star's "no MFMA" wording, DESIGN.md section 4: fit launch
+// 17.4 -> 15.9 us); -DFLS_FIT_MFMA=0 builds the DPP row-shift tree they replaced.  Nothing else in this path is a dense contraction.
 #pragma once
 #include "host_math.hpp"
 #include "device_common.hpp"

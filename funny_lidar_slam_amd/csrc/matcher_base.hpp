@@ -67,6 +67,10 @@ struct fls_matcher {
     virtual size_t map_size(int slot) const = 0;
     virtual size_t map_export(void*, size_t) { return 0; }                       // 0: this kind has no exportable image
     virtual fls_status map_import(const void*, size_t) { return FLS_ERR_STATE; }
+    // fls_replicas_*: this handle becomes a READ-ONLY copy of `owner`'s device map image (device to device, no host mirror): it serves
+    // fls_match_batch and nothing else until a map_import / a cleared map makes it an ordinary handle again
+    virtual bool can_replicate() const { return false; }
+    virtual fls_status replicate_from(fls_matcher&) { return FLS_ERR_STATE; }
     // state a FRESH reference matcher would not have (e.g. nearest_points_ of an earlier Match): cleared per batch job
     virtual void reset_job_state() {}
     // Batch of independent registrations against the CURRENT map (BASELINE configs[4]): every job is what a

@@ -29,6 +29,9 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     size_t n_incremental = 0, n_full_rebuilds = 0;
     // a batch lane (fls_match_batch) reads its owner's resident map image
     const IvoxImage* borrowed = nullptr;
+    // a member of a replica set (fls_replicas_*): `image` is a device-to-device copy of the owner's (kNN side only), the host mirror is
+    // empty -- the handle serves fls_match_batch; everything that needs the mirror answers FLS_ERR_STATE
+    bool replica_only = false;
     bool host_timing = false;  // FLS_HOST_TIMING=1: print the host-side cost of every map update
     // ---- device-side AddPoints (kernels_ivox_update.hpp): while `device_map` is set the DEVICE image is the authoritative map
     // (points, voxel table, LRU stamps, counters) and the host mirror `ivox` is stale; sync_host_from_device() brings it back.
@@ -394,6 +397,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     }
 
     fls_status add_cloud_impl(const std::vector<PtI>& planar_cloud, const bool from_resident_scan = false, const bool pre_enqueued = false) {
+        if (replica_only) return FLS_ERR_STATE;
         if (p.is_localization_mode) { device_map = false; is_first = true; ivox.clear(); image_built = false; }
         fls_status rc = FLS_OK;
         if (!(from_resident_scan && !is_first)) { ensure_nn_rows(); sync_host_from_device(); }  // every other branch works on the host mirror
@@ -571,6 +575,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     }
 
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
+        if (replica_only && update_map) return FLS_ERR_STATE;  // (a replica's image has no AddPoints side and no mirror)
         const size_t n = scan.n;
         number_planar_point = n;
         stats = fls_stats{};
@@ -680,7 +685,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     };
     struct BlobVoxel { unsigned long long key; unsigned count, pad; };
     size_t map_export(void* blob, size_t cap) override {
-        if (borrowed) return 0;
+        if (borrowed || replica_only) return 0;
         const bool was_device = device_map;
         sync_host_from_device();
         const size_t need = sizeof(BlobHeader) + ivox.n_alive * sizeof(BlobVoxel) + ivox.n_points * sizeof(Pt4);
@@ -734,6 +739,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             if (std::adjacent_find(keys.begin(), keys.end()) != keys.end()) return FLS_ERR_INVALID;  // a voxel listed twice
         }
         device_map = false;
+        replica_only = false;
         const size_t capacity = ivox.capacity;
         ivox.rebuild_from_image(vox, bp, size_t(hd.n_points), int(hd.next_id));
         ivox.resolution = hd.resolution; ivox.inv_resolution = 1.0f / hd.resolution; ivox.capacity = capacity;
@@ -742,6 +748,41 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         image_built = false;  // the slot layout is rebuilt from the mirror (window order), like the first build of the exporter
         image_dirty = true;
         refresh_image();
+        return FLS_OK;
+    }
+
+    // ---- replica sets: the owner's device image copied device to device (hipMemcpyPeer over xGMI between GPUs; no export blob, no host
+    // mirror rebuild, no re-flatten -- SURVEY 8e's replicated read-only map).  Both devices' streams are idle when this returns.
+    bool can_replicate() const override { return !borrowed; }
+    size_t live_counts(size_t& n_bricks_live) {  // slots in use + bricks, from the device's own state while it maintains the map
+        if (!device_map) { n_bricks_live = image.n_bricks(); return image.used; }
+        IvoxUpdState st{};
+        FLS_HIP(hipMemcpyAsync(&st, d_upd_state.p, sizeof(st), hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipStreamSynchronize(stream));
+        n_bricks_live = std::min<size_t>(st.n_bricks, image.n_bricks_cap);
+        return size_t(st.used);
+    }
+    fls_status replicate_from(fls_matcher& o) override {
+        if (borrowed || o.kind != kind) return FLS_ERR_INVALID;
+        auto& src = static_cast<P2PlaneIvoxMatcher&>(o);
+        if (src.borrowed || src.replica_only || src.ivox.resolution != ivox.resolution) return FLS_ERR_STATE;
+        FLS_HIP(hipSetDevice(src.device));
+        const fls_status prc = src.prepare_batch();  // image current, the owner's stream idle
+        if (prc != FLS_OK) return prc;
+        size_t nb = 0;
+        const size_t used_now = src.live_counts(nb);
+        FLS_HIP(hipSetDevice(device));
+        FLS_HIP(hipStreamSynchronize(stream));
+        device_map = false;
+        replica_only = false;
+        ivox.clear();
+        image_built = false; image_dirty = true;  // (a copy that fails half-way leaves an empty map that rebuilds its image)
+        use_dense = src.use_dense;
+        image.clone_for_reading(src.image, used_now, nb, src.device, device, stream);
+        is_first = src.is_first;
+        replica_only = true;
+        image_built = true; image_dirty = false; rebuild_after_replay = false;
+        nn_n = 0; have_final = false; nn_rows_current = true; spec_pending = false;
         return FLS_OK;
     }
 
