@@ -159,8 +159,10 @@ size_t fls_map_export(fls_handle h, void* blob, size_t cap_bytes);
 fls_status fls_map_import(fls_handle h, const void* blob, size_t n_bytes);
 
 /* ---- one process, several GPUs ("one process + N host threads"; BASELINE configs[4]) ---------------------------
- * A replica set = one handle per entry of device_ids, each holding a copy of the owner's map image (fls_map_export once,
- * fls_map_import per device on that device's own host thread); the owner itself serves the first entry that names its own
+ * A replica set = one handle per entry of device_ids, each holding a READ-ONLY copy of the owner's device map image, copied device
+ * to device (hipMemcpyPeer; no host blob, no host mirror per replica -- FLS_REPLICAS_VIA_BLOB=1 restores round 3's fls_map_export once +
+ * fls_map_import per device, which is also what the library falls back to, loudly, where a peer copy is refused); the owner itself
+ * serves the first entry that names its own
  * device, so {owner's device} alone is valid and {d, d} gives two handles on one GPU (what the tests use on a one-GPU box).
  * fls_replicas_match_batch = fls_match_batch with the jobs block-partitioned over the entries (job j of the caller's arrays
  * lands on entry floor-partition(j); results are written straight into the caller's arrays: one address space, no gather),
