@@ -55,7 +55,7 @@ struct IvoxUpdState {
     unsigned evict_ready, n_list;  // the host queued the eviction selection; entries of the stamp-sorted list of alive cells
     unsigned long long evicted_points, evicted_slots;  // totals of the evicted voxels (ivox_evict_apply)
     unsigned n_bricks;        // bricks in the directory (device-side creation: ivox_upd_seq); may overshoot the pool inside a refused batch, clamped at commit
-    unsigned pad_;
+    unsigned recreated;       // voxels this batch evicts AND re-creates (touched after their turn in the eviction order: ivox_evict_select)
 };
 // what the host reads back (host-mapped pinned memory, written by ivox_upd_commit)
 struct IvoxUpdMailbox {
@@ -64,6 +64,7 @@ struct IvoxUpdMailbox {
     int next_id;
     unsigned seq;
     unsigned evicted, n_bricks;
+    unsigned recreated, pad_;
 };
 
 struct IvoxUpdArrays {
@@ -253,15 +254,22 @@ __device__ __forceinline__ void upd_seq_rank(const IvoxUpdBatch& b, const IvoxUp
     b.jj[r] = atomicAdd(&a.pend[cell], 1u);
     atomicMin(&a.rank_mm[cell], r);
 }
+// top bit of a cell's `pend` word between ivox_evict_select and ivox_evict_apply (long chain only): the batch evicts this voxel BEFORE its
+// first point arrives, i.e. the reference re-creates it from the batch's points alone (ivox_map.cpp:126-136) -- the second plan pass
+// counts it as a creation with nothing to keep
+constexpr unsigned kUpdRecreate = 0x80000000u;
 // what the batch does to the voxel whose first point has rank r: {new region slots, creation, touched, capacity left behind}
 template <bool COH = false>
 __device__ __forceinline__ bool upd_plan_rank(const IvoxUpdBatch& b, const IvoxUpdArrays& a, const unsigned r, unsigned (&v)[4]) {
     v[0] = v[1] = v[2] = v[3] = 0u;
     const unsigned cell = b.seq_cell[r];
     if (cell == kUpdInvalidCell || upd_ld<COH>(&a.rank_mm[cell]) != r) return false;
-    const uint2 old = upd_ld_cell<COH>(&a.cells[cell]);
-    const unsigned total = old.y + upd_ld<COH>(&a.pend[cell]);
-    const unsigned cl = a.cap_log2[cell];
+    uint2 old = upd_ld_cell<COH>(&a.cells[cell]);
+    const unsigned pe = upd_ld<COH>(&a.pend[cell]);
+    const bool recreate = (pe & kUpdRecreate) != 0u;
+    if (recreate) old = make_uint2(0u, 0u);  // (its old points and region are accounted for by the eviction)
+    const unsigned total = old.y + (pe & ~kUpdRecreate);
+    const unsigned cl = recreate ? 0u : a.cap_log2[cell];
     const unsigned cap = cl ? (1u << cl) : 0u;
     const bool grow = total > cap;
     v[0] = grow ? upd_cap_for(total) : 0u;
@@ -297,6 +305,7 @@ __device__ __forceinline__ void upd_decide_totals(IvoxUpdState* __restrict__ st,
     st->evict = e;
     st->evicted_points = 0ull;
     st->evicted_slots = 0ull;
+    st->recreated = 0u;
     st->status = status;
     if (!evict_ready) st->apply = status == kUpdOk ? 1u : 0u;  // no eviction selection follows: this is the verdict (ivox_upd_decide otherwise)
 }
@@ -421,46 +430,116 @@ ivox_upd_cranks(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState*
     if (a.cells[cell].y != 0u) return;  // an existing voxel: no creation
     crank[b.bt2[blockIdx.x].y + b.px[r].y] = r;
 }
-// Which voxels the batch evicts.  The candidates are the alive cells in LRU order (oldest first).  An UNTOUCHED candidate is the
-// next eviction.  A candidate the batch touches has moved to the list's front by the time the eviction pointer reaches it iff its
-// first touch (rank_mm = first rank, after ivox_upd_seq) precedes that eviction's creation: then the reference skips it -- exactly
-// what is done here; if the eviction comes first the reference evicts the voxel and the later touch re-creates it (one more creation,
-// one more eviction, different ids ...): that batch is refused and replayed by the sequential host code.  One workgroup, chunks of
-// 1024 candidates, a running count of untouched candidates = the eviction index a candidate maps to.
+// Which voxels the batch evicts.  The candidates are the alive cells in LRU order (oldest first); eviction number idx happens right
+// after creation number base_c + idx of the batch (ivox_map.cpp:133-136: the creation that brings the count to the capacity evicts
+// the list's back).  An UNTOUCHED candidate is the next eviction.  A candidate the batch touches has moved to the list's front by
+// the time the eviction pointer reaches it iff its first touch (rank_mm = first rank, after ivox_upd_seq) precedes that eviction's
+// creation: the reference skips it, and so does this walk.  If the eviction comes first the reference evicts the voxel and the later
+// touch RE-CREATES it from the batch's points alone: one more creation -- its rank joins the creation sequence -- and therefore one
+// more eviction.  Round 4 resolves that here (it used to refuse the batch): the candidate is evicted, marked kUpdRecreate for the
+// second plan pass, its first rank is inserted into the sorted list S, and the walk continues with creation ranks read from the
+// MERGED sequence crank U S.  A marked voxel's turn is found one at a time (everything decided in parallel behind an undiscovered one
+// would use the wrong sequence): the chunk is re-evaluated from the position behind it -- conflicts are rare, a pass is 1024 candidates.
+// The walk is checked against the sequential loop on random maps in tests/host/evict_conflict_model_test.cpp.  What still goes to the
+// host: a selection that runs out of untouched-or-late candidates (it would reach voxels this batch itself touched or created:
+// kUpdNeedHost) and more than kEvMaxRecreate re-created voxels in one batch.  One workgroup.
+constexpr int kEvMaxRecreate = 1024;
+// k-th (0-based) smallest of crank[0, C) U S[0, nS) (both ascending, all ranks distinct); k < C + nS
+__device__ __forceinline__ unsigned evict_merged_rank(const unsigned* __restrict__ crank, const unsigned C, const unsigned* S, const unsigned nS, const unsigned k) {
+    unsigned j = 0;
+    while (j < nS && j <= k && S[j] < (k - j < C ? crank[k - j] : 0xFFFFFFFFu)) ++j;  // S[j] is smaller than a creation rank inside the first k + 1: it is inside too
+    unsigned v = 0u;
+    if (j <= k && k - j < C) v = crank[k - j];
+    if (j > 0u && S[j - 1] > v) v = S[j - 1];
+    return v;
+}
 __global__ void __launch_bounds__(kEvBlock)
 ivox_evict_select(const unsigned* __restrict__ order, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st, const unsigned* __restrict__ crank,
                   unsigned* __restrict__ evict_list) {
     __shared__ unsigned wsum[kEvBlock / 64];
-    __shared__ unsigned s_found;
+    __shared__ unsigned s_found, s_nS, s_conflict, s_overflow;
+    __shared__ unsigned s_S[kEvMaxRecreate];
     const unsigned E = st->evict;
     if (E == 0u || st->status != kUpdOk) return;
-    const unsigned n_list = st->n_list;
+    const unsigned n_list = st->n_list, C = st->creations;
     const unsigned base_c = st->lru_capacity - 1u > st->n_alive ? st->lru_capacity - 1u - st->n_alive : 0u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_found = 0u;
+    if (threadIdx.x == 0) { s_found = 0u; s_nS = 0u; s_conflict = 0xFFFFFFFFu; s_overflow = 0u; }
     __syncthreads();
     for (unsigned j0 = 0; j0 < n_list; j0 += kEvBlock) {
-        const unsigned found = s_found;
-        if (found >= E) break;
+        if (s_found >= E + s_nS) break;
         const unsigned j = j0 + threadIdx.x;
         const bool valid = j < n_list;
         const unsigned cell = valid ? order[j] : 0u;
         const bool un = valid && a.pend[cell] == 0u;
-        const unsigned long long m = __ballot(un);
-        if (lane == 0) wsum[w] = (unsigned)__popcll(m);
-        __syncthreads();
-        unsigned before = 0u, total = 0u;
-        for (int q = 0; q < kEvBlock / 64; ++q) { const unsigned t = wsum[q]; if (q < w) before += t; total += t; }
-        const unsigned idx = found + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));  // evictions decided before this candidate
-        if (valid && idx < E) {
-            if (un) evict_list[idx] = cell;
-            else if (!(a.rank_mm[cell] < crank[base_c + idx])) atomicOr(&st->status, kUpdEvictConflict);  // evicted first, re-created later: host
+        const unsigned rv = (valid && !un) ? a.rank_mm[cell] : 0u;  // first rank of a touched candidate
+        unsigned start = j0;  // positions of this chunk in front of `start` are decided
+        for (;;) {
+            const unsigned found = s_found, nS = s_nS, Etot = E + nS;  // (uniform: written before the last barrier)
+            if (found >= Etot) break;
+            const bool in = valid && j >= start;
+            const unsigned long long m = __ballot(in && un);
+            if (lane == 0) wsum[w] = (unsigned)__popcll(m);
+            __syncthreads();
+            unsigned before = 0u, total = 0u;
+            for (int q = 0; q < kEvBlock / 64; ++q) { const unsigned t = wsum[q]; if (q < w) before += t; total += t; }
+            const unsigned idx = found + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));  // evictions decided before this candidate
+            // evicted first, re-created later?  (only the FIRST such position of the pass is trusted)
+            if (in && !un && idx < Etot && !(rv < evict_merged_rank(crank, C, s_S, nS, base_c + idx))) atomicMin(&s_conflict, j);
+            __syncthreads();
+            const unsigned fc = s_conflict;
+            if (in && un && j < fc && idx < Etot) evict_list[idx] = cell;
+            __syncthreads();  // (every thread has read s_conflict / s_found / s_nS / wsum)
+            if (fc == 0xFFFFFFFFu) {
+                if (threadIdx.x == 0) s_found = found + total;
+                __syncthreads();
+                break;
+            }
+            if (j == fc) {  // this candidate: evicted as number idx, re-created by its first point
+                evict_list[idx] = cell;
+                if (nS >= (unsigned)kEvMaxRecreate) {
+                    s_overflow = 1u;
+                } else {
+                    a.pend[cell] |= kUpdRecreate;
+                    unsigned q = nS;
+                    while (q > 0u && s_S[q - 1] > rv) { s_S[q] = s_S[q - 1]; --q; }
+                    s_S[q] = rv;
+                    s_nS = nS + 1u;
+                }
+                s_found = idx + 1u;
+                s_conflict = 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            if (s_overflow) break;
+            start = fc + 1u;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) s_found = found + total;
-        __syncthreads();
+        if (s_overflow) break;
     }
-    if (threadIdx.x == 0 && s_found < E) atomicOr(&st->status, kUpdNeedHost);
+    if (threadIdx.x == 0) {
+        if (s_overflow) atomicOr(&st->status, kUpdEvictConflict);  // (more re-created voxels than the list holds: the sequential host code)
+        else if (s_found < E + s_nS) atomicOr(&st->status, kUpdNeedHost);
+        else { st->evict = E + s_nS; st->recreated = s_nS; }
+    }
+}
+// second plan pass of a batch with an eviction selection (after ivox_upd_plan has run again, now seeing the kUpdRecreate marks): the
+// block offsets and totals as the regions will be laid out, the point-array check with them, and the cross-check that plan and selection
+// agree on the number of evictions.  Without marked voxels everything comes out as in the first pass.
+__global__ void __launch_bounds__(kUpdMaxBlocks)
+ivox_upd_scan2_again(const IvoxUpdBatch b, IvoxUpdState* __restrict__ st) {
+    __shared__ unsigned wsum[kUpdMaxBlocks / 64][4];
+    const unsigned A = st->n1 + st->n2;
+    const int nblocks = (int)((A + kUpdBlock - 1) / kUpdBlock);
+    const uint4 t = (int)threadIdx.x < nblocks ? b.bt2[threadIdx.x] : make_uint4(0u, 0u, 0u, 0u);
+    unsigned v[4] = {t.x, t.y, t.z, t.w}, tot[4];
+    block_excl_scan<4>(v, tot, wsum);
+    if ((int)threadIdx.x < nblocks) b.bt2[threadIdx.x] = make_uint4(v[0], v[1], v[2], v[3]);
+    if (threadIdx.x == 0) {
+        unsigned e;
+        unsigned status = upd_verdict(st, tot, st->evict_ready, st->n_list, st->status, e);
+        if (status == kUpdOk && e != st->evict) status |= kUpdNeedHost;  // (never expected: the selection counted E + re-created)
+        st->alloc = tot[0]; st->creations = tot[1]; st->touched = tot[2]; st->relocated_garbage = tot[3];
+        st->status = status;
+    }
 }
 __global__ void ivox_upd_decide(IvoxUpdState* __restrict__ st) {
     if (threadIdx.x == 0 && blockIdx.x == 0) st->apply = st->status == kUpdOk ? 1u : 0u;
@@ -478,6 +557,7 @@ ivox_evict_apply(const unsigned* __restrict__ evict_list, const IvoxUpdArrays a,
     brick_write_mirrors(a, cell, make_uint2(0u, 0u));
     a.cap_log2[cell] = 0;
     a.stamp[cell] = 0ull;
+    a.pend[cell] &= ~kUpdRecreate;  // (a re-created voxel is an empty cell with pending points from here on: regions / points / finish treat it as new)
 }
 
 // the scratch word of every touched cell turns from the FIRST into the LAST rank of the batch (max >= min: one atomicMax);
@@ -587,6 +667,7 @@ __device__ __forceinline__ void upd_commit(IvoxUpdState* __restrict__ st, IvoxUp
     __hip_atomic_store(&mb->touched, st->touched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&mb->next_id, st->next_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&mb->evicted, st->apply ? st->evict : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mb->recreated, st->apply ? st->recreated : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -38,7 +38,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
     bool device_map = false;
     bool allow_device_map = true;  // FLS_IVOX_DEVICE_UPDATE=0: always the host path (A/B)
     size_t device_margin = 4096;   // voxels of head-room below the LRU capacity required to (re-)enter device mode (FLS_IVOX_DEVICE_MARGIN: test hook)
-    size_t n_device_updates = 0, n_host_fallbacks = 0, n_device_evictions = 0, n_refused_conflict = 0, n_refused_full = 0, n_refused_outside = 0;
+    size_t n_device_updates = 0, n_host_fallbacks = 0, n_device_evictions = 0, n_device_recreated = 0, n_refused_conflict = 0, n_refused_full = 0, n_refused_outside = 0;
     bool fused_update = false;     // FLS_IVOX_FUSED_UPDATE=1 (A/B): small batches as ONE launch of one workgroup
     bool short_chain_update = true;  // FLS_IVOX_SHORT_CHAIN=0 (A/B): the round-3 chain of eleven launches for every batch
     size_t n_fused_updates = 0, n_short_updates = 0;
@@ -282,6 +282,10 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             d_evict_list.reserve(n);
             hipLaunchKernelGGL(ivox_upd_cranks, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p, d_crank.p);
             hipLaunchKernelGGL(ivox_evict_select, dim3(1), dim3(kEvBlock), 0, stream, (const unsigned*)ev_sort.v0, a, d_upd_state.p, (const unsigned*)d_crank.p, d_evict_list.p);
+            // voxels the selection evicts BEFORE their first point of this batch arrives are re-created by it (round 4; such a batch used to
+            // be refused): the plan runs again seeing them as creations, and the totals / block offsets / point-array check with it
+            hipLaunchKernelGGL(ivox_upd_plan, g, t, 0, stream, b, a, (const IvoxUpdState*)d_upd_state.p);
+            hipLaunchKernelGGL(ivox_upd_scan2_again, dim3(1), dim3(kUpdMaxBlocks), 0, stream, b, d_upd_state.p);
         }
         if (may_evict) hipLaunchKernelGGL(ivox_upd_decide, dim3(1), dim3(64), 0, stream, d_upd_state.p);  // (the selection may still refuse the batch)
         if (may_evict) hipLaunchKernelGGL(ivox_evict_apply, g, t, 0, stream, (const unsigned*)d_evict_list.p, a, d_upd_state.p);
@@ -321,6 +325,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         dev_n_alive = size_t(upd_mb_host->n_alive);
         stamp_bound += n;
         n_device_evictions += upd_mb_host->evicted;
+        n_device_recreated += upd_mb_host->recreated;
         ++n_device_updates;
         return true;
     }
@@ -834,6 +839,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (slot == 125) return n_speculative_skipped;  //            ... that the device skipped (the Match needed more iterations / did not converge)
         if (slot == 123) return n_short_updates;    //                ... of which in the short chain (five launches behind the decision)
         if (slot == 117) return n_device_evictions;  //              voxels evicted inside device batches
+        if (slot == 126) return n_device_recreated;  //              ... of which re-created by a later point of the same batch (eviction-order conflicts resolved on the device)
         if (slot == 119) return n_refused_conflict;  //              refusals by reason: eviction order conflict / point array full / point outside the window
         if (slot == 120) return n_refused_full;
         if (slot == 121) return n_refused_outside;

@@ -128,7 +128,7 @@ def test_multi_site_mapping_run_2km_extent():
 
 def test_multi_site_mapping_run_with_evictions(monkeypatch):
     """The same run with the LRU capacity just above the prior map: sites visited least recently lose voxels while the current one grows;
-    evictions run inside the device batches wherever the reference's order allows it (true eviction-order conflicts replay on the host)."""
+    evictions run inside the device batches, including voxels evicted and re-created by one batch (eviction-order conflicts; round 3 replayed those on the host)."""
     probe = util.oracle_for("PointToPlane_IVOX", reg.YAML_NCLT_IVOX)
     scene = synth.make_scene()
     patch = synth.sample_map(scene, 40000, synth.rng_for(1, 0, 7), radius=26.0)
@@ -139,7 +139,8 @@ def test_multi_site_mapping_run_with_evictions(monkeypatch):
     applied, refused, evicted = m.map_size(103), m.map_size(104), m.map_size(117)
     print(f"multi-site run at capacity {cap}: {applied} device batches, {refused} refused (conflict {m.map_size(119)}, full {m.map_size(120)}, outside {m.map_size(121)}), {evicted} evicted on the device")
     assert o.map_voxels() == cap - 1
-    assert refused == m.map_size(119) and m.map_size(120) == 0 and m.map_size(121) == 0, "only true eviction-order conflicts may leave the device"
+    print(f"voxels evicted and re-created inside one device batch: {m.map_size(126)}")
+    assert refused == 0 and m.map_size(119) == 0 and m.map_size(120) == 0 and m.map_size(121) == 0, "nothing leaves the device: eviction-order conflicts are resolved there"
     assert applied >= 10 and evicted > 200, (applied, evicted)
     m.close(); o.close()
 

@@ -22,3 +22,12 @@ def test_exact_sort_closed_form_model(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "host", "exact_sort_model_test.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_eviction_selection_with_recreated_voxels_model(tmp_path):
+    """The batch form of 'evict inside the insert loop' (ivox_map.cpp:133-136) incl. voxels evicted and re-created by one batch -- the walk
+    ivox_evict_select performs -- equals the sequential loop on random maps (tests/host/evict_conflict_model_test.cpp)."""
+    exe = os.path.join(str(tmp_path), "evict_conflict_model_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "host", "evict_conflict_model_test.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
