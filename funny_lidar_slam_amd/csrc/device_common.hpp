@@ -246,4 +246,16 @@ __host__ __device__ __forceinline__ unsigned hash_key(unsigned long long k) {
     return (unsigned)k;
 }
 
+// ---- LRU evictions inside a batch (ivox_evict_select, ndt_evict_select): creation ranks of a batch merged with the first ranks of the
+// voxels it evicts and re-creates ----
+// k-th (0-based) smallest of crank[0, C) U S[0, nS) (both ascending, all ranks distinct); k < C + nS
+__device__ __forceinline__ unsigned evict_merged_rank(const unsigned* __restrict__ crank, const unsigned C, const unsigned* S, const unsigned nS, const unsigned k) {
+    unsigned j = 0;
+    while (j < nS && j <= k && S[j] < (k - j < C ? crank[k - j] : 0xFFFFFFFFu)) ++j;  // S[j] is smaller than a creation rank inside the first k + 1: it is inside too
+    unsigned v = 0u;
+    if (j <= k && k - j < C) v = crank[k - j];
+    if (j > 0u && S[j - 1] > v) v = S[j - 1];
+    return v;
+}
+
 }  // namespace fls

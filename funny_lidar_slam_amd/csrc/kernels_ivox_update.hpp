@@ -444,15 +444,6 @@ ivox_upd_cranks(const IvoxUpdBatch b, const IvoxUpdArrays a, const IvoxUpdState*
 // host: a selection that runs out of untouched-or-late candidates (it would reach voxels this batch itself touched or created:
 // kUpdNeedHost) and more than kEvMaxRecreate re-created voxels in one batch.  One workgroup.
 constexpr int kEvMaxRecreate = 1024;
-// k-th (0-based) smallest of crank[0, C) U S[0, nS) (both ascending, all ranks distinct); k < C + nS
-__device__ __forceinline__ unsigned evict_merged_rank(const unsigned* __restrict__ crank, const unsigned C, const unsigned* S, const unsigned nS, const unsigned k) {
-    unsigned j = 0;
-    while (j < nS && j <= k && S[j] < (k - j < C ? crank[k - j] : 0xFFFFFFFFu)) ++j;  // S[j] is smaller than a creation rank inside the first k + 1: it is inside too
-    unsigned v = 0u;
-    if (j <= k && k - j < C) v = crank[k - j];
-    if (j > 0u && S[j - 1] > v) v = S[j - 1];
-    return v;
-}
 __global__ void __launch_bounds__(kEvBlock)
 ivox_evict_select(const unsigned* __restrict__ order, const IvoxUpdArrays a, IvoxUpdState* __restrict__ st, const unsigned* __restrict__ crank,
                   unsigned* __restrict__ evict_list) {

@@ -42,7 +42,7 @@ struct NdtRows {
     double* info;              // [row][9]   (read by ndt_kernel)
     int* vid;                  // [row]      (read by ndt_kernel)
     unsigned long long* stamp; // LRU: larger = touched later
-    unsigned* touch;           // sequence number of the last batch that touched the row (eviction conflict test)
+    unsigned long long* touch; // {sequence number of the last batch that touched the row : 2^31 - 1 - cloud index of that batch's first point in it} (eviction selection)
 };
 
 struct NdtUpdState {
@@ -53,12 +53,22 @@ struct NdtUpdState {
     unsigned capacity, row_cap;
     unsigned n_new, status, apply, touched;
     unsigned evict, seq, evict_ready, dead_hi;  // voxels this batch evicts; batch sequence number; the host queued the selection; hi word given to dead rows' sort key
+    unsigned recreated, pad1;                   // voxels this batch evicts AND re-creates (touched after their turn in the eviction order: ndt_evict_select)
 };
+constexpr unsigned kNdtRecreateBit = 0x80000000u;  // evict_list entry: the row is retired but its table entry lives on (the re-created voxel's row takes it over)
+constexpr int kNdtEvBlock = 1024, kNdtMaxRecreate = 1024;
+__device__ __forceinline__ unsigned long long ndt_touch_word(const unsigned seq, const unsigned i) { return ((unsigned long long)seq << 32) | (unsigned long long)(0x7fffffffu - i); }
+// number of entries of the ascending list v[0, n) that are smaller than x
+__device__ __forceinline__ unsigned ndt_lower_bound(const unsigned* __restrict__ v, const unsigned n, const unsigned x) {
+    unsigned lo = 0u, hi = n;
+    while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (v[mid] < x) lo = mid + 1u; else hi = mid; }
+    return lo;
+}
 
 // per point: voxel key, find or claim its table entry; for a claimed (new) entry remember the smallest cloud index
 __global__ void __launch_bounds__(256)
 ndt_upd_locate(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int n, const double inv_voxel,
-               HashEntry* __restrict__ table, const unsigned mask, unsigned* __restrict__ slot_h, NdtUpdState* __restrict__ st, unsigned* __restrict__ touch,
+               HashEntry* __restrict__ table, const unsigned mask, unsigned* __restrict__ slot_h, NdtUpdState* __restrict__ st, unsigned long long* __restrict__ touch,
                const unsigned seq) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -82,7 +92,7 @@ ndt_upd_locate(const float* __restrict__ x, const float* __restrict__ y, const f
     slot_h[i] = h;
     const unsigned b = __hip_atomic_load(&table[h].begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (b >= kNdtNewBit) atomicMax(&table[h].begin, kNdtNewBit | (0x7fffffffu - (unsigned)i));
-    else touch[b] = seq;  // an existing voxel this batch appends to (every toucher stores the same word)
+    else atomicMax(&touch[b], ndt_touch_word(seq, (unsigned)i));  // an existing voxel this batch appends to: a newer batch beats an older one, the smallest index wins inside one
 }
 
 // creators (first point of a new voxel): block-local exclusive rank + block totals
@@ -109,12 +119,15 @@ ndt_upd_creators(const int n, const HashEntry* __restrict__ table, const unsigne
 }
 
 // LRU evictions inside a batch (incremental_ndt.h:202-206: a creation that brings the count to the capacity pops the list's back).
-// With n alive voxels and k creations the batch evicts E = max(0, n + k - (capacity - 1)) voxels: the tail at each eviction.  As long
-// as the E least recently touched voxels (smallest stamps over ALL alive rows) are not touched by this batch, the tails are exactly
-// those E voxels whatever the timing -- touched voxels only move to the front, new voxels are born there.  Anything else (one of
-// them is touched: the reference would skip it or evict it and re-create it, depending on the order inside the batch) is refused
-// and replayed by the exact sequential host code.  The host sorts the rows by stamp (two stable 32-bit radix rounds: low word,
-// then high word; dead rows get the largest key) before this kernel whenever the batch COULD reach the capacity.
+// With n alive voxels and k creations the batch evicts E = max(0, n + k - (capacity - 1)) voxels: the tail at each eviction; eviction
+// number idx happens right after creation number (capacity - 1 - n) + idx.  The candidates are the rows in LRU order (the host sorts
+// them by stamp -- two stable 32-bit radix rounds, dead rows last -- whenever the batch COULD reach the capacity).  An untouched
+// candidate is the next eviction; one the batch touches BEFORE that eviction's creation has moved to the front and is skipped; one it
+// touches AFTER it is evicted and RE-CREATED by its first point (one more creation -- its index joins the creation sequence -- one more
+// eviction, a new voxel id, statistics from the batch's points alone).  Round 3 refused every batch that touched one of the E oldest
+// rows; round 4 walks the list exactly like the iVox kind does (ndt_evict_select below = ivox_evict_select, kernels_ivox_update.hpp;
+// the walk is checked against the sequential loop in tests/host/evict_conflict_model_test.cpp).  What still goes to the host: a
+// selection that would reach voxels this batch itself created or moved to the front (kNdtNeedHost).
 __global__ void ndt_upd_predecide(NdtUpdState* __restrict__ st) {
     unsigned status = st->status;
     const unsigned long long total = (unsigned long long)st->n_alive + st->n_new;
@@ -139,27 +152,96 @@ ndt_evict_keys(const NdtRows r, const unsigned n_rows, const unsigned dead_hi, c
     key[i] = round == 0 ? (dead ? 0xffffffffu : (unsigned)s) : (dead ? dead_hi : (unsigned)(s >> 32));
     if (round == 0) val[i] = row;
 }
-// the E oldest rows must be alive and untouched by this batch
+// cloud index of every creator, in creation (= cloud) order
 __global__ void __launch_bounds__(256)
-ndt_evict_check(const NdtRows r, const unsigned* __restrict__ order, const unsigned n_rows, NdtUpdState* __restrict__ st) {
-    const unsigned j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= st->evict) return;
-    bool bad = j >= n_rows;
-    if (!bad) {
-        const unsigned row = order[j];
-        bad = r.key[row] == kNdtDeadKey || r.touch[row] == st->seq;
+ndt_upd_cranks(const int n, const unsigned* __restrict__ lx, const unsigned* __restrict__ bt /* scanned */, unsigned* __restrict__ crank) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned l = lx[i];
+    if (l != 0xffffffffu) crank[bt[i / kVgScanBlock] + l] = (unsigned)i;
+}
+// the eviction walk (one workgroup): evict_list[0, E + nS) = rows in eviction order (kNdtRecreateBit: re-created), s_idx / s_row = first
+// cloud index (ascending) and old row of the re-created voxels; state: evict, recreated, n_new grow by nS
+__global__ void __launch_bounds__(kNdtEvBlock)
+ndt_evict_select(const NdtRows r, const unsigned* __restrict__ order, const unsigned n_rows, NdtUpdState* __restrict__ st, const unsigned* __restrict__ crank,
+                 unsigned* __restrict__ evict_list, unsigned* __restrict__ s_idx_out, unsigned* __restrict__ s_row_out) {
+    __shared__ unsigned wsum[kNdtEvBlock / 64];
+    __shared__ unsigned s_found, s_nS, s_conflict, s_overflow;
+    __shared__ unsigned s_S[kNdtMaxRecreate], s_R[kNdtMaxRecreate];
+    const unsigned E = st->evict;
+    if (E == 0u || st->status != kNdtOk) return;
+    const unsigned C = st->n_new, seq = st->seq;
+    const unsigned base_c = st->capacity - 1u > st->n_alive ? st->capacity - 1u - st->n_alive : 0u;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_found = 0u; s_nS = 0u; s_conflict = 0xFFFFFFFFu; s_overflow = 0u; }
+    __syncthreads();
+    for (unsigned j0 = 0; j0 < n_rows; j0 += kNdtEvBlock) {
+        if (s_found >= E + s_nS) break;
+        const unsigned j = j0 + threadIdx.x;
+        unsigned row = 0u;
+        bool valid = j < n_rows;
+        if (valid) { row = order[j]; valid = r.key[row] != kNdtDeadKey; }  // (dead rows sort last: nothing behind the first one is a candidate)
+        const unsigned long long tw = valid ? r.touch[row] : 0ull;
+        const bool un = valid && (unsigned)(tw >> 32) != seq;
+        const unsigned rv = 0x7fffffffu - (unsigned)(tw & 0x7fffffffull);  // first cloud index of a touched candidate
+        unsigned start = j0;
+        for (;;) {
+            const unsigned found = s_found, nS = s_nS, Etot = E + nS;
+            if (found >= Etot) break;
+            const bool in = valid && j >= start;
+            const unsigned long long m = __ballot(in && un);
+            if (lane == 0) wsum[w] = (unsigned)__popcll(m);
+            __syncthreads();
+            unsigned before = 0u, total = 0u;
+            for (int q = 0; q < kNdtEvBlock / 64; ++q) { const unsigned t = wsum[q]; if (q < w) before += t; total += t; }
+            const unsigned idx = found + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (in && !un && idx < Etot && !(rv < evict_merged_rank(crank, C, s_S, nS, base_c + idx))) atomicMin(&s_conflict, j);
+            __syncthreads();
+            const unsigned fc = s_conflict;
+            if (in && un && j < fc && idx < Etot) evict_list[idx] = row;
+            __syncthreads();
+            if (fc == 0xFFFFFFFFu) {
+                if (threadIdx.x == 0) s_found = found + total;
+                __syncthreads();
+                break;
+            }
+            if (j == fc) {
+                evict_list[idx] = row | kNdtRecreateBit;
+                if (nS >= (unsigned)kNdtMaxRecreate) {
+                    s_overflow = 1u;
+                } else {
+                    unsigned q = nS;
+                    while (q > 0u && s_S[q - 1] > rv) { s_S[q] = s_S[q - 1]; s_R[q] = s_R[q - 1]; --q; }
+                    s_S[q] = rv; s_R[q] = row;
+                    s_nS = nS + 1u;
+                }
+                s_found = idx + 1u;
+                s_conflict = 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            if (s_overflow) break;
+            start = fc + 1u;
+        }
+        if (s_overflow) break;
     }
-    if (bad) atomicOr(&st->status, kNdtNeedHost);
+    __syncthreads();
+    const unsigned nS = s_nS;
+    if (s_overflow || s_found < E + nS) {
+        if (threadIdx.x == 0) atomicOr(&st->status, kNdtNeedHost);
+        return;
+    }
+    for (unsigned q = threadIdx.x; q < nS; q += kNdtEvBlock) { s_idx_out[q] = s_S[q]; s_row_out[q] = s_R[q]; }
+    if (threadIdx.x == 0) { st->evict = E + nS; st->recreated = nS; st->n_new = C + nS; }
 }
 __global__ void ndt_upd_decide(NdtUpdState* __restrict__ st) { st->apply = st->status == kNdtOk ? 1u : 0u; }
 // evict: tombstone the table entry, retire the row
 __global__ void __launch_bounds__(256)
-ndt_evict_apply(const NdtRows r, const unsigned* __restrict__ order, HashEntry* __restrict__ table, const NdtUpdState* __restrict__ st) {
+ndt_evict_apply(const NdtRows r, const unsigned* __restrict__ evict_list, HashEntry* __restrict__ table, const NdtUpdState* __restrict__ st) {
     const unsigned j = blockIdx.x * 256 + threadIdx.x;
     if (!st->apply || j >= st->evict) return;
-    const unsigned row = order[j];
+    const unsigned ent = evict_list[j], row = ent & ~kNdtRecreateBit;
     const unsigned h = r.hslot[row];
-    table[h].key = kNdtTombKey;
+    if (!(ent & kNdtRecreateBit)) table[h].key = kNdtTombKey;  // (a re-created voxel keeps its entry: ndt_upd_create points it at the new row)
     table[h].count = 0u;
     r.key[row] = kNdtDeadKey;
     r.estimated[row] = 0;
@@ -170,17 +252,23 @@ ndt_evict_apply(const NdtRows r, const unsigned* __restrict__ order, HashEntry* 
 __global__ void __launch_bounds__(256)
 ndt_upd_create(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int n, const double inv_voxel,
                HashEntry* __restrict__ table, const unsigned* __restrict__ slot_h, const unsigned* __restrict__ lx, const unsigned* __restrict__ bt,
-               const NdtRows r, const NdtUpdState* __restrict__ st) {
+               const NdtRows r, const NdtUpdState* __restrict__ st, const unsigned* __restrict__ crank, const unsigned* __restrict__ s_idx) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned l = lx[i];
-    if (l == 0xffffffffu) return;
+    // voxels the batch evicted before this point arrived are re-created by it (ndt_evict_select): their first points are creators too, and
+    // every creation after one of them moves up by one (voxel ids and rows follow the MERGED creation order)
+    const unsigned nS = st->apply ? st->recreated : 0u;
+    unsigned sk = 0u;
+    bool again = false;
+    if (nS) { sk = ndt_lower_bound(s_idx, nS, (unsigned)i); again = sk < nS && s_idx[sk] == (unsigned)i; }
+    if (l == 0xffffffffu && !again) return;
     const unsigned h = slot_h[i];
     if (!st->apply) {
         table[h] = HashEntry{kEmptyKey, kNdtNewBit, 0u};
         return;
     }
-    const unsigned rank = bt[i / kVgScanBlock] + l;
+    const unsigned rank = again ? ndt_lower_bound(crank, st->n_new - nS, (unsigned)i) + sk : bt[i / kVgScanBlock] + l + sk;
     const unsigned row = st->n_rows + rank;
     const double f0 = (double)x[i] * inv_voxel, f1 = (double)y[i] * inv_voxel, f2 = (double)z[i] * inv_voxel;
     r.key[row] = pack_key((int)f0, (int)f1, (int)f2);
@@ -190,7 +278,7 @@ ndt_upd_create(const float* __restrict__ x, const float* __restrict__ y, const f
     r.carry_cnt[row] = 0;
     r.vid[row] = st->next_vid + (int)rank;
     r.stamp[row] = 0ull;
-    r.touch[row] = st->seq;
+    r.touch[row] = ndt_touch_word(st->seq, (unsigned)i);
     table[h].begin = row;
     table[h].count = 0u;  // not estimated yet: ndt_kernel skips it
 }

@@ -273,7 +273,10 @@ struct NdtMatcher final : fls_matcher {
     size_t dev_entries = 0;           // table entries in use (alive voxels + tombstones since the last re-hash)
     unsigned long long device_evictions = 0, device_compactions = 0;
     DevBuf<unsigned long long> r_key, r_stamp;
-    DevBuf<unsigned> r_hslot, r_touch;
+    DevBuf<unsigned> r_hslot;
+    DevBuf<unsigned long long> r_touch;
+    DevBuf<unsigned> u_crank, u_evict, u_sidx, u_srow;  // eviction selection: creation indices, rows in eviction order, the re-created voxels
+    unsigned long long device_recreated = 0;            // voxels evicted and re-created inside one device batch
     DevicePairSort ev_sort;
     DevBuf<int> r_np;
     DevBuf<unsigned char> r_est, r_cc;
@@ -340,7 +343,7 @@ struct NdtMatcher final : fls_matcher {
         up(d_vid.p, vid.data(), na * 4); up(r_est.p, est.data(), na); up(r_cc.p, cc.data(), na); up(r_carry.p, carry.data(), carry.size() * 8);
         up(d_mu.p, mu.data(), mu.size() * 8); up(d_sigma.p, sg.data(), sg.size() * 8); up(d_info.p, inf.data(), inf.size() * 8);
         FLS_HIP(hipStreamSynchronize(stream));
-        FLS_HIP(hipMemsetAsync(r_touch.p, 0, r_touch.cap * sizeof(unsigned), stream));
+        FLS_HIP(hipMemsetAsync(r_touch.p, 0, r_touch.cap * sizeof(unsigned long long), stream));
         dev_rows = dev_alive = dev_entries = na;
         device_left = false;
         dev_table = ts;
@@ -385,7 +388,11 @@ struct NdtMatcher final : fls_matcher {
         if (n > size_t(kVgMaxBlocks) * kVgTile) return false;
         if ((dev_entries + n) * 2 + 2 > dev_table) grow_table_device(dev_alive + n);
         if (dev_rows + n > row_cap) { reserve_rows(device_slack ? dev_rows + dev_rows / 2 + 2 * n : dev_rows + n, true); ++row_growths; }
-        upd_seq = upd_seq + 1u ? upd_seq + 1u : 1u;
+        upd_seq = upd_seq + 1u;
+        if (upd_seq == 0u) {  // the touch words order batches by their sequence number: start over after 2^32 of them
+            upd_seq = 1u;
+            FLS_HIP(hipMemsetAsync(r_touch.p, 0, r_touch.cap * sizeof(unsigned long long), stream));
+        }
         const bool may_evict = device_evict && dev_alive + n >= size_t(p.ndt_capacity);  // every point a new voxel: the worst case
         NdtUpdState& hs = h_upd.p[0];
         hs = NdtUpdState{};
@@ -408,13 +415,17 @@ struct NdtMatcher final : fls_matcher {
             ev_sort.run(4, stream);
             hipLaunchKernelGGL(ndt_evict_keys, dim3(nbr), dim3(256), 0, stream, R, nr, hs.dead_hi, 1, (const unsigned*)ev_sort.v0, ev_sort.k0, ev_sort.v0);
             ev_sort.run(DevicePairSort::passes_for((unsigned long long)hs.dead_hi), stream);
-            hipLaunchKernelGGL(ndt_evict_check, dim3(unsigned(nb1)), dim3(256), 0, stream, R, (const unsigned*)ev_sort.v0, nr, d_upd.p);
+            // the walk over the LRU order (ndt_evict_select): skips what the batch touched in time, re-creates what it touched too late
+            u_crank.reserve(n); u_evict.reserve(std::max<size_t>(dev_rows, n)); u_sidx.reserve(size_t(kNdtMaxRecreate)); u_srow.reserve(size_t(kNdtMaxRecreate));
+            hipLaunchKernelGGL(ndt_upd_cranks, dim3(unsigned(nb1)), dim3(256), 0, stream, ni, (const unsigned*)u_lx.p, (const unsigned*)(u_bt.p + nb2), u_crank.p);
+            hipLaunchKernelGGL(ndt_evict_select, dim3(1), dim3(kNdtEvBlock), 0, stream, R, (const unsigned*)ev_sort.v0, nr, d_upd.p, (const unsigned*)u_crank.p, u_evict.p,
+                               u_sidx.p, u_srow.p);
         }
         hipLaunchKernelGGL(ndt_upd_decide, dim3(1), dim3(1), 0, stream, d_upd.p);
         if (may_evict && dev_rows > 0)
-            hipLaunchKernelGGL(ndt_evict_apply, dim3(unsigned(nb1)), dim3(256), 0, stream, R, (const unsigned*)ev_sort.v0, d_table.p, (const NdtUpdState*)d_upd.p);
+            hipLaunchKernelGGL(ndt_evict_apply, dim3(unsigned(nb1)), dim3(256), 0, stream, R, (const unsigned*)u_evict.p, d_table.p, (const NdtUpdState*)d_upd.p);
         hipLaunchKernelGGL(ndt_upd_create, dim3(unsigned(nb1)), dim3(256), 0, stream, x, y, z, ni, inv_voxel, d_table.p, (const unsigned*)u_slot.p,
-                           (const unsigned*)u_lx.p, (const unsigned*)(u_bt.p + nb2), R, (const NdtUpdState*)d_upd.p);
+                           (const unsigned*)u_lx.p, (const unsigned*)(u_bt.p + nb2), R, (const NdtUpdState*)d_upd.p, (const unsigned*)u_crank.p, (const unsigned*)u_sidx.p);
         u_sort.prepare(n);
         hipLaunchKernelGGL(ndt_upd_rowkeys, dim3(unsigned(nb1)), dim3(256), 0, stream, ni, (const HashEntry*)d_table.p, (const unsigned*)u_slot.p, u_sort.k0, u_sort.v0,
                            (const NdtUpdState*)d_upd.p);
@@ -427,10 +438,11 @@ struct NdtMatcher final : fls_matcher {
         FLS_HIP(hipGetLastError());
         const NdtUpdState& o = h_upd.p[1];
         if (!o.apply) { ++refused_batches; return false; }
-        dev_entries += size_t(o.n_rows) - dev_rows;  // one table entry per created voxel (an evicted voxel's entry stays as a tombstone)
+        dev_entries += size_t(o.n_rows) - dev_rows - o.recreated;  // one table entry per created voxel (an evicted voxel's entry stays as a tombstone, a re-created voxel reuses its own)
         dev_rows = o.n_rows; dev_alive = o.n_alive; dev_next_vid = o.next_vid; dev_epoch = o.epoch;
         last_touched = o.touched;
         device_evictions += o.evict;
+        device_recreated += o.recreated;
         ++device_batches;
         // retired rows pile up at the capacity (hundreds per scan): drop them through the host mirror now and then
         if (dev_rows - dev_alive > std::max<size_t>(2 * dev_alive, 262144)) compact_device_rows(n);
@@ -725,6 +737,7 @@ struct NdtMatcher final : fls_matcher {
         if (slot == 111) return size_t(resident_updates);  // map updates fed by the device-resident filtered scan
         if (slot == 112) return size_t(table_growths);     // device-side table rebuilds / row-array growths
         if (slot == 113) return size_t(row_growths);
+        if (slot == 126) return size_t(device_recreated);    // ... of which re-created by a later point of the same batch
         if (slot == 117) return size_t(device_evictions);    // voxels evicted by device batches / row compactions through the host mirror
         if (slot == 118) return size_t(device_compactions);
         return alive();
