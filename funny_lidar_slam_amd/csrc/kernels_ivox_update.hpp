@@ -13,8 +13,10 @@
 //     -- is the one the host path builds)
 // so the batch is applied with prefix sums over the sequence and per-voxel atomics whose arbitrary arrival order is erased again
 // (min / max / count are order free; the slots a voxel's new points land in are sorted by id afterwards).  Deterministic.
-// Anything this path cannot do exactly -- an eviction inside the batch (voxel count reaching the capacity), a point outside
-// the dense voxel window, the point array running out of room -- is detected BEFORE any map state is touched; the batch is
+// LRU evictions inside the batch (voxel count reaching the capacity) are selected by a walk over the alive cells in stamp order
+// (ivox_evict_select below), including voxels that are evicted and re-created by a later point of the same batch.
+// Anything this path cannot do exactly -- evictions that would reach voxels the batch itself created or touched, a key beyond
+// +-2^20, the point array or the brick pool running out of room -- is detected BEFORE any map state is touched; the batch is
 // then not applied, the status word says so and the host takes the exact sequential path (matcher_p2plane_ivox.hpp).
 //
 // Launch sequence (one stream, no host round trip; n = source points, A = points to insert):

@@ -2,8 +2,8 @@
 //
 // Reference: incremental_ndt.h:182-227 (per point: key = cast<int>(p * inv_voxel_size); new voxel -> push_front + capacity
 // check, known voxel -> append + splice to the front; then UpdateVoxel of every touched voxel, :130-179).  This file covers the
-// mapping-mode steady state: flag_first_scan == false and no eviction inside the batch (alive + created < capacity).  Anything
-// else (first scan, localization mode, a batch that would evict, a key out of range) is refused without side effects and runs
+// mapping-mode steady state: flag_first_scan == false, with the LRU evictions a batch causes (ndt_evict_select).  Anything
+// else (first scan, localization mode, evictions that would reach voxels of the batch itself, a key out of range) is refused without side effects and runs
 // through the exact sequential host code (matcher_ndt.hpp), which first downloads the device state.
 //
 // How the sequential semantics are recovered from a parallel pass:
