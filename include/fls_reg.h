@@ -235,6 +235,10 @@ int fls_get_iteration_log(fls_handle h, double* T_iters /* cap x 16, col-major *
 /* neighbours held for each source point after the last Match: ids are map insertion ids (iVox), map cloud
  * indices (kd-tree kinds), voxel creation ids (NDT); K = 5 (1 for ICP, 7 for NDT).  slot 1 = corner set. */
 int fls_get_correspondences(fls_handle h, int slot, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap_points);
+/* fls_map_size: slot 0 = map points (voxels for NDT), 1 = corner map (LoamFull), 102 = occupied voxels (iVox); slots >= 100 are
+ * introspection counters of the device-side map update that the tests and bench.py read (device batches applied 103 / 109, refused
+ * 104 / 110, voxels evicted inside device batches 117, of which re-created by a later point of the same batch 126, refusals by
+ * reason 119-121, ...): see map_size() of the matcher in csrc/matcher_p2plane_ivox.hpp / matcher_ndt.hpp.  Not part of the drop-in. */
 size_t fls_map_size(fls_handle h, int slot);
 
 /* ---- measurement hooks ----------------------------------------------------------------------------
