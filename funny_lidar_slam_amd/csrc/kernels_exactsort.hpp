@@ -242,6 +242,10 @@ es_swap_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsSeg* __
 //     sort) and writes the range back.
 // Hand-off between workgroups (possibly on different XCDs): the producer writes back its L2 (agent-scope release) before it publishes a
 // child, the consumer invalidates (agent-scope acquire) after it pops one.  Termination: a counter of open tasks.
+#ifndef FLS_ES_UNROLL
+#define FLS_ES_UNROLL 8  // independent key loads a lane keeps in flight in the passes of a partition out of global memory (A/B at the end of round 4,
+                         // NDT fls_match from host buffers: 8 -> 0.682 ms, 16 -> 0.676, 24 -> 0.691, 40 -> 0.934 (spills): not what bounds the stage)
+#endif
 constexpr int kEsTaskThreads = 1024, kEsTaskWaves = kEsTaskThreads / 64;
 constexpr int kEsCoop = 1024;    // sub-ranges of an LDS range longer than this are partitioned by the whole workgroup, shorter ones by single waves
 constexpr int kEsStack = 64;     // pending workgroup-level sub-ranges (disjoint, each > kEsCoop records: at most kEsLds / kEsCoop)
@@ -374,7 +378,7 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                 const unsigned w0 = first + 1u + (unsigned)w * per, w1 = w0 + per < last ? w0 + per : last;
                 // (every loop below keeps U independent loads in flight: a global round trip costs ~1 us on a freshly invalidated cache, and a
                 // 115 k-record range is 113 rounds of 64 per wave)
-                constexpr int U = 8;
+                constexpr int U = FLS_ES_UNROLL;  // (8 until the end of round 4: the passes are latency bound, the workgroup is alone on its CU and has registers to spare)
                 unsigned cl = 0u, cr = 0u;
                 for (unsigned base = w0; base < w1; base += 64u * U) {
                     unsigned kk[U];
