@@ -93,3 +93,21 @@ def test_small_functions_against_compiled_reference():
     xy = rng.normal(size=(2000, 2)).astype(np.float32) * 30
     for x, y in xy:
         assert L.ref_fast_atan2f(float(y), float(x)) == O.lib().flo_fast_atan2f(float(y), float(x))
+
+
+@need_ref
+def test_ivox_eviction_and_recreation_inside_one_batch_against_compiled_reference():
+    """IVoxMap::AddPoints evicts inside its insert loop (ivox_map.cpp:133-136): one 3,000-point batch at capacity 60 with 722 evictions, 641 of them of
+    voxels a later point of the same batch re-creates -- the corner the device-side eviction walk resolves (kernels_ivox_update.hpp).  The reference's own
+    code (fresh process), a sequential Python model and the oracle agree on the LRU order, every voxel's points and the surviving points (tests/evict_pin.py)."""
+    from tests import evict_pin as E
+    n_evict, n_recreate = E.check(E.run_ref_subprocess(), E.run_oracle())
+    assert (n_evict, n_recreate) == (722, 641)
+
+
+def test_ivox_eviction_and_recreation_inside_one_batch_against_reference_golden():
+    """the same check against the committed output of the compiled reference (tests/golden/ref_ivox_recreate.npz, written by `python -m tests.evict_pin --golden`)"""
+    from tests import evict_pin as E
+    with np.load(E.GOLDEN) as z:
+        ref = {k: z[k] for k in z.files}
+    E.check(ref, E.run_oracle())
