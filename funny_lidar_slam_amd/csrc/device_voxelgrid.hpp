@@ -6,6 +6,7 @@
 #pragma once
 #include "kernels_voxelgrid.hpp"
 #include "kernels_exactsort.hpp"
+#include "kernels_voxelgrid_plan.hpp"
 #include "kernels_gridbuild.hpp"
 #include "matcher_base.hpp"
 #include <cstdlib>
@@ -85,20 +86,16 @@ struct DeviceExactSort {
 #endif
         }
     }
-    // queues the whole sort on `s`; false: refused before anything ran (sizes).  The verdict of the sort itself (introsort's heap-sort
-    // case) is only known once the stream has drained: failed_after_sync().
-    bool run(unsigned* key, unsigned* val, const size_t n, hipStream_t s) {
-        if (n > (size_t(1) << 22)) return false;
-        if (n < 2) return true;
+    unsigned work_cap = 0, tile_cap = 0;
+    void allocate(const size_t n) {
         if (!mb_host) {
             FLS_HIP(hipHostMalloc((void**)&mb_host, sizeof(EsMailbox), hipHostMallocMapped));
             std::memset(mb_host, 0, sizeof(EsMailbox));
             FLS_HIP(hipHostGetDevicePointer((void**)&mb_dev, mb_host, 0));
         }
         es_debug_mailbox() = mb_host;
-        ++runs;
-        const unsigned work_cap = unsigned(64 * (n / kEsLds + 1) + 1024);
-        const unsigned tile_cap = unsigned(n / kEsTile + n / kEsTaskMax + 2);
+        work_cap = unsigned(64 * (n / kEsLds + 1) + 1024);
+        tile_cap = unsigned(n / kEsTile + n / kEsTaskMax + 2);
         seg_a.reserve(kEsMaxSeg); seg_b.reserve(kEsMaxSeg);
         work.reserve(work_cap);
         ready.reserve(work_cap);
@@ -108,6 +105,30 @@ struct DeviceExactSort {
         queue.reserve(1);
         h_st.reserve(1);
         h_queue.reserve(1);
+    }
+    // The one-launch form for clouds up to kEsTaskMax records whose queue a preceding kernel initialises (vg_minmax_plan, EsInitArgs):
+    // fused_prepare() before that kernel is queued, fused_launch() behind the kernel that writes the records.  `skip`: device word, non-zero
+    // = nothing to sort.  The verdict (EsState::fail) stays on the device: the caller's last kernel forwards it.
+    bool fused_ok(const size_t n) const { return n >= 2 && n <= size_t(kEsTaskMax); }
+    EsInitArgs fused_prepare(const size_t n) {
+        allocate(n);
+        return EsInitArgs{st.p, queue.p, ready.p, work_cap};
+    }
+    void fused_launch(unsigned* key, unsigned* val, const size_t n, const unsigned* skip, hipStream_t s) {
+        ++runs;
+        const unsigned grid = unsigned(std::min<size_t>(256, std::max<size_t>(8, n / kEsLds + 4)));
+        static const bool dbg_marks = std::getenv("FLS_ES_DEBUG") != nullptr;
+        if (dbg_marks) std::memset(mb_host->mark, 0, sizeof(mb_host->mark));
+        hipLaunchKernelGGL(es_task_kernel, dim3(grid), dim3(kEsTaskThreads), 0, s, key, val, work.p, ready.p, work_cap, queue.p, Lp.p, Rl.p, st.p,
+                           dbg_marks ? mb_dev : (EsMailbox*)nullptr, unsigned(n), skip);
+    }
+    // queues the whole sort on `s`; false: refused before anything ran (sizes).  The verdict of the sort itself (introsort's heap-sort
+    // case) is only known once the stream has drained: failed_after_sync().
+    bool run(unsigned* key, unsigned* val, const size_t n, hipStream_t s) {
+        if (n > (size_t(1) << 22)) return false;
+        if (n < 2) return true;
+        allocate(n);
+        ++runs;
         FLS_HIP(hipMemsetAsync(ready.p, 0, work_cap * sizeof(unsigned), s));
         if (n <= size_t(kEsTaskMax)) {
             // every source scan: no begin launch, no host wait -- the array itself is workgroup 0's first task (open = 1 stands for it)
@@ -118,7 +139,7 @@ struct DeviceExactSort {
             static const bool dbg_marks = std::getenv("FLS_ES_DEBUG") != nullptr;
             if (dbg_marks) std::memset(mb_host->mark, 0, sizeof(mb_host->mark));
             hipLaunchKernelGGL(es_task_kernel, dim3(grid), dim3(kEsTaskThreads), 0, s, key, val, work.p, ready.p, work_cap, queue.p, Lp.p, Rl.p, st.p,
-                               dbg_marks ? mb_dev : (EsMailbox*)nullptr, unsigned(n));
+                               dbg_marks ? mb_dev : (EsMailbox*)nullptr, unsigned(n), (const unsigned*)nullptr);
             FLS_HIP(hipMemcpyAsync(h_st.p, st.p, sizeof(EsState), hipMemcpyDeviceToHost, s));
             FLS_HIP(hipGetLastError());
             return true;
@@ -159,12 +180,23 @@ struct DeviceExactSort {
             const unsigned grid = unsigned(std::min<size_t>(256, std::max<size_t>(8, n / kEsLds + 4)));
             static const bool skip = std::getenv("FLS_ES_SKIP_TASKS") != nullptr;  // (bisecting aid)
             if (!skip) hipLaunchKernelGGL(es_task_kernel, dim3(grid), dim3(kEsTaskThreads), 0, s, key, val, work.p, ready.p, work_cap, queue.p, Lp.p, Rl.p, st.p,
-                                          std::getenv("FLS_ES_DEBUG") ? mb_dev : (EsMailbox*)nullptr, 0u);
+                                          std::getenv("FLS_ES_DEBUG") ? mb_dev : (EsMailbox*)nullptr, 0u, (const unsigned*)nullptr);
             FLS_HIP(hipMemcpyAsync(h_queue.p, queue.p, sizeof(EsQueue), hipMemcpyDeviceToHost, s));
         }
         FLS_HIP(hipMemcpyAsync(h_st.p, st.p, sizeof(EsState), hipMemcpyDeviceToHost, s));
         FLS_HIP(hipGetLastError());
         return true;
+    }
+    // FLS_ES_DEBUG: stage stamps of the last sort (the fused form never copies EsState back)
+    bool failed_after_sync_debug_only() {
+        static const bool dbg = std::getenv("FLS_ES_DEBUG") && std::atoi(std::getenv("FLS_ES_DEBUG")) != 0;
+        if (dbg && mb_host) {
+            const unsigned* mk = mb_host->mark;
+            auto us = [&](int a, int b) { return mk[a] && mk[b] ? 0.01 * double(int(mk[b] - mk[a])) : -1.0; };
+            std::fprintf(stderr, "[fls exact sort] workgroup 0, first task [us]: pop->start %.1f, global partitions %.1f, LDS load %.1f, phase A (workgroup partitions) %.1f, phase B (wave tasks) %.1f, "
+                         "ranks + write-back %.1f\n", us(0, 2), us(2, 9), us(9, 10), us(10, 3), us(3, 4), us(5, 6));
+        }
+        return false;
     }
     // after the caller's stream synchronisation: did a range hit introsort's depth limit inside es_lds_kernel?
     bool failed_after_sync() {
@@ -201,8 +233,21 @@ struct DeviceVoxelGrid {
     DevBuf<float> out;            // x | y | z | i, capacity n each
     DevBuf<VgHeader> d_hdr;
     PinnedBuf<VgHeader> h_hdr;    // [0] = init template, [1] = read-back
+    // the uninterrupted form (kernels_voxelgrid_plan.hpp): plan + accumulators on the device, the verdict in a host-mapped mailbox
+    DevBuf<VgPlan> d_plan;
+    DevBuf<VgAccum> d_acc;
+    VgMailbox* vmb_host = nullptr;
+    VgMailbox* vmb_dev = nullptr;
+    unsigned vseq = 0;
+    bool fused = true;            // FLS_VG_FUSED=0: the round-4 sequence (two stream synchronisations), A/B
+    unsigned last_status = 0;
+    unsigned long long fused_runs = 0;
     size_t n_in = 0, n_out = 0;
     int last_passes = 0;
+    ~DeviceVoxelGrid() { if (vmb_host) (void)hipHostFree(vmb_host); }
+    DeviceVoxelGrid() { if (const char* e = std::getenv("FLS_VG_FUSED")) fused = std::atoi(e) != 0; }
+    DeviceVoxelGrid(const DeviceVoxelGrid&) = delete;
+    DeviceVoxelGrid& operator=(const DeviceVoxelGrid&) = delete;
     const float* ox() const { return out.p; }
     const float* oy() const { return out.p + n_in; }
     const float* oz() const { return out.p + 2 * n_in; }
@@ -213,6 +258,7 @@ struct DeviceVoxelGrid {
         n_in = n;
         n_out = 0;
         if (n == 0 || n > size_t(kVgMaxBlocks) * kVgTile) return false;
+        if (fused && exact_order && exact.fused_ok(n)) return run_fused(x, y, z, in, n, leaf, s);
         h_hdr.reserve(2);
         d_hdr.reserve(1);
         for (int a = 0; a < 3; ++a) { h_hdr.p[0].mn[a] = 0xffffffffu; h_hdr.p[0].mx[a] = 0u; }
@@ -271,6 +317,69 @@ struct DeviceVoxelGrid {
         FLS_HIP(hipGetLastError());
         if (exact_order && exact.failed_after_sync()) { ++exact_declined; return false; }  // (introsort's heap-sort case: the host path sorts)
         n_out = h_hdr.p[1].n_out;
+        return true;
+    }
+
+    // One uninterrupted stream of launches (kernels_voxelgrid_plan.hpp): bounds + plan + sort-queue initialisation, leaf indices, the exact
+    // sort, run heads, offsets + verdict to the mailbox, centroids.  The host waits ONCE, on a host-mapped word the offsets kernel writes --
+    // before the centroid kernel has finished; whatever the caller queues next on `s` is ordered behind it.
+    bool run_fused(const float* x, const float* y, const float* z, const float* in, size_t n, float leaf, hipStream_t s) {
+        if (!vmb_host) {
+            FLS_HIP(hipHostMalloc((void**)&vmb_host, sizeof(VgMailbox), hipHostMallocMapped));
+            std::memset(vmb_host, 0, sizeof(VgMailbox));
+            FLS_HIP(hipHostGetDevicePointer((void**)&vmb_dev, vmb_host, 0));
+        }
+        if (!d_acc.p) {  // armed once; the last block of every vg_minmax_plan re-arms it
+            d_acc.reserve(1);
+            d_plan.reserve(1);
+            const VgAccum init{{0xffffffffu, 0xffffffffu, 0xffffffffu}, {0u, 0u, 0u}, 0u, 0u};
+            FLS_HIP(hipMemcpyAsync(d_acc.p, &init, sizeof(VgAccum), hipMemcpyHostToDevice, s));
+            FLS_HIP(hipStreamSynchronize(s));
+        }
+        const int ni = int(n);
+        const int nb1 = (ni + kVgBlock - 1) / kVgBlock, nb2 = (ni + kVgScanBlock - 1) / kVgScanBlock;
+        sort.prepare(n);
+        lx.reserve(n);
+        bt.reserve(size_t(2 * nb2));
+        sorted.reserve(n);
+        out.reserve(4 * n);
+        const EsInitArgs es = exact.fused_prepare(n);
+        vseq = (vseq + 1u) & 0x7fffffffu;
+        if (!vseq) vseq = 1u;
+        const float inv = 1.0f / leaf;
+        // (the reference sorts the FINITE points only: a cloud with a non-finite point is the host's, refuse_bad = 1)
+        hipLaunchKernelGGL(vg_minmax_plan, dim3(unsigned(std::min(nb1, 48))), dim3(kVgBlock), 0, s, x, y, z, ni, inv, 1, d_acc.p, d_plan.p, es);
+        hipLaunchKernelGGL(vg_index_plan, dim3(unsigned(nb1)), dim3(kVgBlock), 0, s, x, y, z, ni, (const VgPlan*)d_plan.p, sort.k0, sort.v0);
+        exact.fused_launch(sort.k0, sort.v0, n, &d_plan.p->status, s);
+        hipLaunchKernelGGL(vg_heads_plan, dim3(unsigned(nb2)), dim3(kVgScanBlock), 0, s, (const unsigned*)sort.k0, (const unsigned*)sort.v0, ni, (const VgPlan*)d_plan.p,
+                           (const EsState*)exact.st.p, x, y, z, in, sorted.p, lx.p, bt.p);
+        hipLaunchKernelGGL(vg_scan_publish, dim3(1), dim3(kVgScanBlock), 0, s, (const unsigned*)bt.p, bt.p + nb2, nb2, (const VgPlan*)d_plan.p, (const EsState*)exact.st.p,
+                           vmb_dev, vseq);
+        hipLaunchKernelGGL(vg_centroid_plan, dim3(unsigned(nb1)), dim3(kVgBlock), 0, s, (const unsigned*)sort.k0, (const float4*)sorted.p, ni, (const VgPlan*)d_plan.p,
+                           (const EsState*)exact.st.p, (const unsigned*)lx.p, (const unsigned*)(bt.p + nb2), out.p, out.p + n, out.p + 2 * n, out.p + 3 * n);
+        FLS_HIP(hipGetLastError());
+        for (unsigned long long spin = 1;; ++spin) {
+            if (__atomic_load_n(&vmb_host->seq, __ATOMIC_ACQUIRE) == vseq) break;
+            if ((spin & 0x3fffu) == 0) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) { if (__atomic_load_n(&vmb_host->seq, __ATOMIC_ACQUIRE) == vseq) break; FLS_HIP(hipErrorUnknown); }
+                if (q != hipErrorNotReady) FLS_HIP(q);
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        ++fused_runs;
+        last_status = vmb_host->status;
+        if (exact.failed_after_sync_debug_only()) {}
+        if (vmb_host->status != kVgOk || vmb_host->sort_fail != 0u) {
+            if (vmb_host->sort_fail != 0u) ++exact.failures;
+            ++exact_declined;
+            FLS_HIP(hipStreamSynchronize(s));  // (the staging the caller reuses; the refused call is rare)
+            return false;
+        }
+        ++exact_runs;
+        n_out = vmb_host->n_out;
         return true;
     }
 
@@ -480,6 +589,7 @@ struct SourceFilter {
     }
     void filter(const float* s0, size_t n0, int stride, float leaf, hipStream_t s, DevScan& scan, std::vector<PtI>& source) {
         resident = false;
+        raw_pending = false;
         if (on_device && n0 != 0) {
             raw.upload_raw(s0, n0, stride, s, true);
             if (vg.run(raw.x.p, raw.y.p, raw.z.p, raw.xyz.p + 3 * n0, n0, leaf, s)) {
@@ -495,6 +605,40 @@ struct SourceFilter {
             }
         }
         source = voxel_grid_strided(s0, n0, stride, leaf);
+        scan.upload(source, s);
+        ++host_runs;
+    }
+    // fls_scan_upload_raw: the RAW scan stays resident (x | y | z | intensity of raw_n points) and every fls_match_resident runs the source
+    // filter itself, like the reference's Match does (icp_optimized.h:57, incremental_ndt.h:231-232) -- what bench.py times for configs[0] / [2]
+    bool raw_pending = false;
+    size_t raw_n = 0;
+    float raw_leaf = 0.f;
+    std::vector<float> raw_host;  // packed xyzi rows of the raw scan: only what the device declines goes back to the host filter
+    void upload_raw_only(const float* s0, size_t n0, int stride, float leaf, hipStream_t s) {
+        raw_pending = true;
+        raw_n = n0;
+        raw_leaf = leaf;
+        raw_host.resize(4 * n0);
+        for (size_t i = 0; i < n0; ++i) {
+            const float* q = s0 + i * size_t(stride);
+            raw_host[4 * i] = q[0]; raw_host[4 * i + 1] = q[1]; raw_host[4 * i + 2] = q[2]; raw_host[4 * i + 3] = intensity_of(q, stride);
+        }
+        if (n0) { raw.upload_raw(s0, n0, stride, s, true); FLS_HIP(hipStreamSynchronize(s)); }
+    }
+    void refilter(hipStream_t s, DevScan& scan, std::vector<PtI>& source) {
+        resident = false;
+        if (on_device && raw_n != 0 && vg.run(raw.x.p, raw.y.p, raw.z.p, raw.xyz.p + 3 * raw_n, raw_n, raw_leaf, s)) {
+            scan.n = vg.n_out;
+            scan.host.clear();
+            scan.x.p = const_cast<float*>(vg.ox());
+            scan.y.p = const_cast<float*>(vg.oy());
+            scan.z.p = const_cast<float*>(vg.oz());
+            source.clear();
+            resident = true;
+            ++device_runs;
+            return;
+        }
+        source = voxel_grid_strided(raw_host.data(), raw_n, 4, raw_leaf);
         scan.upload(source, s);
         ++host_runs;
     }

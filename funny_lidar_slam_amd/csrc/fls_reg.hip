@@ -118,6 +118,16 @@ fls_status fls_scan_upload(fls_handle h, const float* s0, size_t n0, const float
     });
 }
 
+fls_status fls_scan_upload_raw(fls_handle h, const float* s0, size_t n0, const float* s1, size_t n1, int stride) {
+    if (!h || (!s0 && n0) || stride < 3) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(h->device));
+        const fls_status rc = h->scan_upload_raw(s0, n0, s1, n1, stride);
+        FLS_HIP(hipStreamSynchronize(h->stream));
+        return rc;
+    });
+}
+
 fls_status fls_match_resident(fls_handle h, double T[16], int update_map, fls_stats* stats) {
     if (!h || !T) return FLS_ERR_INVALID;
     return guarded([&]() -> fls_status {

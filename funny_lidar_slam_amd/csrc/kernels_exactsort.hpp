@@ -302,7 +302,9 @@ __device__ __forceinline__ void es_heap_sort(unsigned* __restrict__ k, unsigned*
 __global__ void __launch_bounds__(kEsTaskThreads)
 es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* __restrict__ tasks, unsigned* __restrict__ ready, const unsigned cap,
                EsQueue* __restrict__ q, unsigned* __restrict__ Lp, unsigned* __restrict__ Rl, EsState* __restrict__ st, EsMailbox* __restrict__ dbg,
-               const unsigned init_n /* != 0: the whole array [0, init_n) is workgroup 0's first task (no begin launch, no queue entry) */) {
+               const unsigned init_n /* != 0: the whole array [0, init_n) is workgroup 0's first task (no begin launch, no queue entry) */,
+               const unsigned* __restrict__ skip /* nullable; *skip != 0: the caller's plan was refused on the device, nothing to sort */) {
+    if (skip != nullptr && *skip != 0u) return;
 #define ES_MARK(k) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0 && dbg->mark[k] == 0u) dbg->mark[k] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
     __shared__ unsigned sk[kEsLds], sv[kEsLds];
     __shared__ unsigned short lp[kEsLds], rl[kEsLds];

@@ -92,9 +92,8 @@ struct VgGrid {
     unsigned total;  // number of leaves of the box = the sentinel key of a non-finite point
 };
 
-__global__ void __launch_bounds__(kVgBlock)
-vg_index(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int n, const VgGrid g,
-         unsigned* __restrict__ key, unsigned* __restrict__ val) {
+__device__ __forceinline__ void vg_index_body(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int n, const VgGrid& g,
+                                              unsigned* __restrict__ key, unsigned* __restrict__ val) {
     const int i = blockIdx.x * kVgBlock + threadIdx.x;
     if (i >= n) return;
     const float px = x[i], py = y[i], pz = z[i];
@@ -108,6 +107,11 @@ vg_index(const float* __restrict__ x, const float* __restrict__ y, const float* 
     }
     key[i] = k;
     val[i] = (unsigned)i;
+}
+__global__ void __launch_bounds__(kVgBlock)
+vg_index(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int n, const VgGrid g,
+         unsigned* __restrict__ key, unsigned* __restrict__ val) {
+    vg_index_body(x, y, z, n, g, key, val);
 }
 
 // per-tile digit counts, digit-major: hist[d * nb + b]
@@ -165,8 +169,7 @@ vg_scan_rows(const unsigned* __restrict__ hist, unsigned* __restrict__ out, cons
 // one workgroup: exclusive scan of `m` counters, in -> out, in coalesced tiles of 1024 with a carried running total.  The
 // loads of 32 tiles are issued together (one ~1 us memory round trip per 32 tiles instead of one per tile); a contiguous
 // chunk per thread made every wave load touch 64 cache lines: 27-35 us on the one CU that runs this.
-__global__ void __launch_bounds__(kVgScanBlock)
-vg_scan(const unsigned* __restrict__ in, unsigned* __restrict__ out, const int m, unsigned* __restrict__ total_out) {
+__device__ __forceinline__ unsigned vg_scan_body(const unsigned* __restrict__ in, unsigned* __restrict__ out, const int m) {
     __shared__ unsigned wsum[2][kVgScanBlock / 64];
     constexpr int B = 32;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -196,6 +199,11 @@ vg_scan(const unsigned* __restrict__ in, unsigned* __restrict__ out, const int m
             }
         }
     }
+    return carry;
+}
+__global__ void __launch_bounds__(kVgScanBlock)
+vg_scan(const unsigned* __restrict__ in, unsigned* __restrict__ out, const int m, unsigned* __restrict__ total_out) {
+    const unsigned carry = vg_scan_body(in, out, m);
     if (total_out != nullptr && threadIdx.x == 0) *total_out = carry;
 }
 
@@ -249,10 +257,9 @@ vg_scatter(const unsigned* __restrict__ kin, const unsigned* __restrict__ vin, u
 }
 
 // run heads of the sorted keys: block-local exclusive rank + block totals
-__global__ void __launch_bounds__(kVgScanBlock)
-vg_heads(const unsigned* __restrict__ key, const unsigned* __restrict__ val, const int n, const unsigned total, const float* __restrict__ x,
-         const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ in, float4* __restrict__ sorted,
-         unsigned* __restrict__ lx, unsigned* __restrict__ bt) {
+__device__ __forceinline__ void vg_heads_body(const unsigned* __restrict__ key, const unsigned* __restrict__ val, const int n, const unsigned total, const float* __restrict__ x,
+                                              const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ in, float4* __restrict__ sorted,
+                                              unsigned* __restrict__ lx, unsigned* __restrict__ bt) {
     __shared__ unsigned wsum[kVgScanBlock / 64];
     const int e = blockIdx.x * kVgScanBlock + threadIdx.x;
     unsigned head = 0u;
@@ -273,11 +280,16 @@ vg_heads(const unsigned* __restrict__ key, const unsigned* __restrict__ val, con
     if (e < n) lx[e] = head ? (base + inc - 1u) : 0xffffffffu;
     if (threadIdx.x == 0) bt[blockIdx.x] = tot;
 }
+__global__ void __launch_bounds__(kVgScanBlock)
+vg_heads(const unsigned* __restrict__ key, const unsigned* __restrict__ val, const int n, const unsigned total, const float* __restrict__ x,
+         const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ in, float4* __restrict__ sorted,
+         unsigned* __restrict__ lx, unsigned* __restrict__ bt) {
+    vg_heads_body(key, val, n, total, x, y, z, in, sorted, lx, bt);
+}
 
 // one thread per run head: float sums in sorted (= ascending point index) order, centroid = sum / count
-__global__ void __launch_bounds__(kVgBlock)
-vg_centroid(const unsigned* __restrict__ key, const float4* __restrict__ sorted, const int n, const unsigned* __restrict__ lx,
-            const unsigned* __restrict__ bt, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, float* __restrict__ oi) {
+__device__ __forceinline__ void vg_centroid_body(const unsigned* __restrict__ key, const float4* __restrict__ sorted, const int n, const unsigned* __restrict__ lx,
+                                                 const unsigned* __restrict__ bt, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, float* __restrict__ oi) {
     const int e = blockIdx.x * kVgBlock + threadIdx.x;
     if (e >= n) return;
     const unsigned l = lx[e];
@@ -309,6 +321,11 @@ vg_centroid(const unsigned* __restrict__ key, const float4* __restrict__ sorted,
     oy[o] = __fdiv_rn(sy, cf);
     oz[o] = __fdiv_rn(sz, cf);
     oi[o] = __fdiv_rn(si, cf);
+}
+__global__ void __launch_bounds__(kVgBlock)
+vg_centroid(const unsigned* __restrict__ key, const float4* __restrict__ sorted, const int n, const unsigned* __restrict__ lx,
+            const unsigned* __restrict__ bt, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, float* __restrict__ oi) {
+    vg_centroid_body(key, sorted, n, lx, bt, ox, oy, oz, oi);
 }
 
 }  // namespace fls

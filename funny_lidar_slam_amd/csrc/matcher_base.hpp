@@ -61,6 +61,8 @@ struct fls_matcher {
     // fls_match's upload: the Match follows at once, so a kind may leave the scan in its pinned staging buffer and let the first
     // iteration's kernels read it from there (default: the ordinary upload)
     virtual fls_status scan_upload_for_match(const float* s0, size_t n0, const float* s1, size_t n1, int stride) { return scan_upload(s0, n0, s1, n1, stride); }
+    // fls_scan_upload_raw: kinds whose Match filters its source (ICP, NDT) keep the RAW scan resident and filter inside match_resident
+    virtual fls_status scan_upload_raw(const float* s0, size_t n0, const float* s1, size_t n1, int stride) { return scan_upload(s0, n0, s1, n1, stride); }
     virtual fls_status match_resident(double* T, int update_map, fls_stats* out) = 0;
     virtual fls_status fitness(float max_range, float* score) = 0;
     virtual int correspondences(int slot, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) = 0;

@@ -625,9 +625,14 @@ struct NdtMatcher final : fls_matcher {
         src_filter.filter(s0, n0, stride, p.source_cloud_filter_size, stream, scan, source);  // :232
         return FLS_OK;
     }
+    fls_status scan_upload_raw(const float* s0, size_t n0, const float*, size_t, int stride) override {
+        src_filter.upload_raw_only(s0, n0, stride, p.source_cloud_filter_size, stream);
+        return FLS_OK;
+    }
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
         const NdtMatcher& M = owner ? *owner : *this;  // a batch lane reads its owner's voxel tables
         if (M.alive() == 0 || !M.have_map) return FLS_ERR_STATE;  // CHECK(!grids_.empty()) :230
+        if (src_filter.raw_pending) src_filter.refilter(stream, scan, source);  // :231-232, on the resident raw scan
         const size_t n = scan.n;
         const int nblk = int((n + 63) / 64);
         stats = fls_stats{};

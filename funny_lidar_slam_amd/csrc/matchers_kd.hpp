@@ -100,8 +100,14 @@ struct IcpMatcher final : fls_matcher {
         src_filter.filter(s0, n0, stride, p.source_cloud_filter_size, stream, scan, source);  // :57
         return FLS_OK;
     }
+    fls_status scan_upload_raw(const float* s0, size_t n0, const float*, size_t, int stride) override {
+        raw_n = n0;
+        src_filter.upload_raw_only(s0, n0, stride, p.source_cloud_filter_size, stream);
+        return FLS_OK;
+    }
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
         if (raw_n <= 10) return FLS_ERR_INVALID;  // CHECK_GT(ordered_cloud_.size(), 10u) :55
+        if (src_filter.raw_pending) src_filter.refilter(stream, scan, source);  // :57, on the resident raw scan
         if (!(owner ? owner->have_map : have_map)) return FLS_ERR_STATE;
         const size_t n = scan.n;
         const int nwg = int((n + 255) / 256);

@@ -149,6 +149,15 @@ class RegistrationInterface:
         if rc != _lib.FLS_OK:
             raise FlsError(rc, "fls_scan_upload")
 
+    def UploadScanRaw(self, cluster: PointcloudCluster) -> None:
+        """fls_scan_upload_raw: the raw cloud stays resident; every MatchResident runs the source VoxelGrid itself (ICP / NDT)."""
+        s0, s1 = self._sources(cluster)
+        a0, p0, n0, st0 = _cloud(s0)
+        a1, p1, n1, st1 = _cloud(s1)
+        rc = _lib.lib().fls_scan_upload_raw(self._h, p0, n0, p1, n1, st0)
+        if rc != _lib.FLS_OK:
+            raise FlsError(rc, "fls_scan_upload_raw")
+
     def MatchResident(self, T: np.ndarray, update_map: bool = False) -> bool:
         # hot in bench.py: one preallocated column-major pose buffer, no per-call ctypes object construction
         buf = getattr(self, "_Tbuf", None)

@@ -37,9 +37,9 @@ extern "C" {
 #define FLS_ABI_VERSION 1
 /* Additive revision of ABI version 1: entry points are only ever ADDED under one FLS_ABI_VERSION (existing signatures, struct layouts and
  * status codes do not change), and this number counts the additions -- 1: fls_match_batch, map export / import; 2: fls_voxel_grid_cloud,
- * fls_features_*; 3: fls_replicas_*, fls_loop_match; 4: fls_debug_exact_sort.  A caller built against revision r works with any library
+ * fls_features_*; 3: fls_replicas_*, fls_loop_match; 4: fls_debug_exact_sort; 5: fls_scan_upload_raw.  A caller built against revision r works with any library
  * whose fls_abi_revision() >= r. */
-#define FLS_ABI_REVISION 4
+#define FLS_ABI_REVISION 5
 
 /* Which reference class the handle replaces (mode strings: include/common/constant_variable.h:21-25). */
 typedef enum fls_kind {
@@ -227,6 +227,11 @@ fls_status fls_get_fitness_score(fls_handle h, float max_range, float* score);
  * keyframe gate's last_T either.                                                                          */
 fls_status fls_scan_upload(fls_handle h, const float* src0, size_t n0, const float* src1, size_t n1, int stride_floats);
 fls_status fls_match_resident(fls_handle h, double T_colmajor[16], int update_map, fls_stats* stats);
+/* fls_scan_upload_raw (revision 5): like fls_scan_upload, but for the kinds whose Match filters its source cloud first (IcpOptimized
+ * icp_optimized.h:57, IncrementalNDT incremental_ndt.h:231-232) the RAW cloud stays resident and EVERY fls_match_resident that follows runs
+ * that pcl::VoxelGrid itself before the iterations -- the whole of the reference's Match with its input already in device memory (what
+ * bench.py reports for BASELINE configs[0] / [2]).  The other kinds: identical to fls_scan_upload. */
+fls_status fls_scan_upload_raw(fls_handle h, const float* src0, size_t n0, const float* src1, size_t n1, int stride_floats);
 
 /* ---- introspection (parity tests, DLOG-equivalent) ---------------------------------------------- */
 /* pose / n_valid / sum_res after every executed iteration; returns the number of iterations logged. */

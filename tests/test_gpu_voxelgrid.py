@@ -200,3 +200,48 @@ def test_voxel_grid_cloud_entry_point_device_mode():
     assert dev.shape == exact.shape and np.array_equal(dev.view(np.uint32), exact.view(np.uint32))
     far = np.array([[0, 0, 0, 1], [1e6, 1e6, 1e6, 2]], np.float32)  # "leaf size too small": the device declines, the exact filter copies the input
     assert np.array_equal(reg.VoxelGridCloud(far, 0.1, on_device=True), far)
+
+
+@pytest.mark.parametrize("mode,y,cid,loc", [("IcpOptimized", reg.YAML_NCLT_ICP, 0, True), ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, False)])
+def test_scan_upload_raw_filters_inside_every_resident_match(mode, y, cid, loc):
+    """fls_scan_upload_raw (round 5): the raw cloud is resident and EVERY fls_match_resident runs the source VoxelGrid first, like the
+    reference's Match (icp_optimized.h:57, incremental_ndt.h:231-232) -- identical to fls_match from host buffers, call after call,
+    and to the filtered-at-upload form.  This is the call bench.py times for configs[0] / [2]."""
+    cfg = synth.make_config(cid, scale=1.0 if cid == 0 else 0.2)
+    cl = util.cluster_for(mode, cfg["scan"])
+    a = reg.make_matcher(mode, y, is_localization_mode=loc)
+    b = reg.make_matcher(mode, y, is_localization_mode=loc)
+    for m in (a, b):
+        m.AddCloudToLocalMap([cfg["map"]])
+    b.UploadScanRaw(cl)
+    for call in range(3):
+        Ta, Tb = np.eye(4), np.eye(4)
+        oka = a.Match(cl, Ta, update_map=False)
+        okb = b.MatchResident(Tb, update_map=False)
+        assert oka == okb and a.stats.iterations == b.stats.iterations and a.stats.n_source == b.stats.n_source
+        assert np.array_equal(Ta, Tb), (call, synth.pose_error(Ta, Tb))
+    assert b.map_size(105) == 3 and b.map_size(106) == 0  # three device filters, none on the host
+    a.UploadScan(cl)
+    Tc = np.eye(4)
+    a.MatchResident(Tc, update_map=False)
+    assert np.array_equal(Tc, Tb)
+    a.close(); b.close()
+
+
+def test_fused_launch_sequence_equals_the_round4_sequence(monkeypatch):
+    """FLS_VG_FUSED=0 restores the round-4 host-steered sequence (bounds read back, queue initialised by the runtime, two stream
+    synchronisations); the default derives the plan on the device and publishes the verdict to a mailbox.  Same bits either way,
+    including what both decline."""
+    cfg = synth.make_config(2, scale=0.3)
+    cloud = np.concatenate([cfg["scan"], np.linspace(0, 1, len(cfg["scan"]), dtype=np.float32)[:, None]], axis=1)
+    bad = cloud.copy(); bad[5, 1] = np.nan
+    far = np.array([[0, 0, 0, 1], [1e6, 1e6, 1e6, 2]], np.float32)
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("FLS_VG_FUSED", fused)
+        res[fused] = [device_voxel_grid(c, leaf) for c, leaf in ((cloud, 0.2), (cloud[:1], 0.2), (cloud[:700], 1.0), (bad, 0.2), (far, 0.1))]
+    for (rc1, o1), (rc0, o0) in zip(res["1"], res["0"]):
+        assert rc1 == rc0 and np.array_equal(o1.view(np.uint32), o0.view(np.uint32))
+    assert [r[0] for r in res["1"]] == [0, 0, 0, _lib.FLS_ERR_STATE, _lib.FLS_ERR_STATE]
+    ref = O.voxel_grid(cloud, 0.2)
+    assert np.array_equal(res["1"][0][1].view(np.uint32), ref.view(np.uint32))
