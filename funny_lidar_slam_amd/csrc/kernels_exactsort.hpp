@@ -247,7 +247,14 @@ es_swap_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsSeg* __
                          // NDT fls_match from host buffers: 8 -> 0.682 ms, 16 -> 0.676, 24 -> 0.691, 40 -> 0.934 (spills): not what bounds the stage)
 #endif
 constexpr int kEsTaskThreads = 1024, kEsTaskWaves = kEsTaskThreads / 64;
-constexpr int kEsCoop = 1024;    // sub-ranges of an LDS range longer than this are partitioned by the whole workgroup, shorter ones by single waves
+#ifndef FLS_ES_COOP
+#define FLS_ES_COOP 4096  // (A/B r05: 1024 / 2048 / 4096 / 8192 -> ICP call 0.466 / 0.449 / 0.444 / 0.478 ms)
+#endif
+#ifndef FLS_ES_SHARE
+#define FLS_ES_SHARE 64    // (A/B r05: 384 / 192 / 96 / 64 / 48 / 32 -> 0.497 / 0.451 / 0.444 / 0.445 / 0.445 / 0.475 ms)
+#endif
+constexpr int kEsCoop = FLS_ES_COOP;    // sub-ranges of an LDS range longer than this are partitioned by the whole workgroup, shorter ones by single waves
+constexpr int kEsShare = FLS_ES_SHARE;  // a wave hands children longer than this to the workgroup's queue (another wave takes them), shorter ones stay on its own stack
 constexpr int kEsStack = 64;     // pending workgroup-level sub-ranges (disjoint, each > kEsCoop records: at most kEsLds / kEsCoop)
 constexpr int kEsWaveStack = 48; // a wave's depth-first stack (smaller child first: <= log2(kEsCoop) + 1 pending ranges)
 constexpr int kEsLocalQ = 1024;  // sub-range tasks of one LDS range (<= 2 per partition, <= kEsLds / 17 partitions)
@@ -271,31 +278,206 @@ __device__ __forceinline__ void es_push(EsQueue* __restrict__ q, EsWork* __restr
 // model) -- the reference's own std::sort heap-sorts them, so the device does too: ONE lane runs the restated routines on the range in LDS
 // (the order heap sort leaves equal keys in is as implementation-defined as introsort's; tests/host/exact_sort_model_test.cpp checks the
 // restatement against std::sort on 1,500 such ranges).  Keys compare with '<' only, values ride along.
-__device__ __forceinline__ void es_heap_adjust(unsigned* __restrict__ k, unsigned* __restrict__ v, int hole, const int len, const unsigned vk, const unsigned vv) {
+// `St` = how a record is stored: es_store_plain (one lane runs the routine) or es_store_lane0 (every lane of a wave runs it in lock-step on the
+// same words -- wave-uniform control flow -- and only lane 0's stores land on the data, es_phase_b)
+struct es_store_plain { __device__ __forceinline__ void operator()(unsigned* p, const unsigned x) const { *p = x; } };
+template <class St>
+__device__ __forceinline__ void es_heap_adjust(unsigned* __restrict__ k, unsigned* __restrict__ v, int hole, const int len, const unsigned vk, const unsigned vv, const St st) {
     const int top = hole;
     int second = hole;
     while (second < (len - 1) / 2) {
         second = 2 * (second + 1);
         if (k[second] < k[second - 1]) second--;
-        k[hole] = k[second]; v[hole] = v[second];
+        const unsigned a = k[second], b = v[second];
+        st(&k[hole], a); st(&v[hole], b);
         hole = second;
     }
     if ((len & 1) == 0 && second == (len - 2) / 2) {
         second = 2 * (second + 1);
-        k[hole] = k[second - 1]; v[hole] = v[second - 1];
+        const unsigned a = k[second - 1], b = v[second - 1];
+        st(&k[hole], a); st(&v[hole], b);
         hole = second - 1;
     }
     int parent = (hole - 1) / 2;  // __push_heap
-    while (hole > top && k[parent] < vk) { k[hole] = k[parent]; v[hole] = v[parent]; hole = parent; parent = (hole - 1) / 2; }
-    k[hole] = vk; v[hole] = vv;
+    while (hole > top && k[parent] < vk) { const unsigned a = k[parent], b = v[parent]; st(&k[hole], a); st(&v[hole], b); hole = parent; parent = (hole - 1) / 2; }
+    st(&k[hole], vk); st(&v[hole], vv);
 }
-__device__ __forceinline__ void es_heap_sort(unsigned* __restrict__ k, unsigned* __restrict__ v, const int len) {  // k, v: the range's first record
+template <class St>
+__device__ __forceinline__ void es_heap_sort(unsigned* __restrict__ k, unsigned* __restrict__ v, const int len, const St st) {  // k, v: the range's first record
     if (len >= 2)
-        for (int parent = (len - 2) / 2;; --parent) { es_heap_adjust(k, v, parent, len, k[parent], v[parent]); if (parent == 0) break; }
+        for (int parent = (len - 2) / 2;; --parent) { es_heap_adjust(k, v, parent, len, k[parent], v[parent], st); if (parent == 0) break; }
     for (int last = len - 1; last >= 1; --last) {
         const unsigned vk = k[last], vv = v[last];
-        k[last] = k[0]; v[last] = v[0];
-        es_heap_adjust(k, v, 0, last, vk, vv);
+        const unsigned a = k[0], b = v[0];
+        st(&k[last], a); st(&v[last], b);
+        es_heap_adjust(k, v, 0, last, vk, vv, st);
+    }
+}
+__device__ __forceinline__ void es_heap_sort(unsigned* __restrict__ k, unsigned* __restrict__ v, const int len) { es_heap_sort(k, v, len, es_store_plain{}); }
+
+// LDS of es_task_kernel at namespace scope: the wave-task phase is a function of its own (es_phase_b) that names these arrays directly
+namespace es_lds {
+__shared__ unsigned sk[kEsLds], sv[kEsLds];
+__shared__ unsigned short lp[kEsLds], rl[kEsLds];
+__shared__ unsigned bmask[kEsLds / 32 + 2];  // bit i: a partition cut (or the range's ends) lies in front of record i
+__shared__ unsigned ws_t[kEsTaskWaves][kEsWaveStack];  // per-wave depth-first stacks of phase B
+__shared__ signed char ws_d[kEsTaskWaves][kEsWaveStack];
+__shared__ unsigned qt[kEsLocalQ];  // local task = first | last << 16, published with one release store (0 = not yet)
+__shared__ signed char qd[kEsLocalQ];
+__shared__ unsigned lq_head, lq_tail, lq_open, s_sp;
+__shared__ unsigned short sa_f[kEsStack], sa_l[kEsStack];
+__shared__ signed char sa_d[kEsStack];
+__shared__ unsigned s_wl[kEsTaskWaves], s_wr[kEsTaskWaves], s_cnt[kEsTaskWaves];
+__shared__ unsigned s_first, s_last, s_pivot, s_state, s_fail;
+__shared__ int s_depth;
+// per-lane scratch words: what lanes 1..63 write where only lane 0's store counts (es_phase_b: wave-uniform control flow WITHOUT sixty-four
+// stores to one address, which the LDS would serialise)
+__shared__ unsigned dmy_u[64];
+__shared__ unsigned short dmy_h[64];
+__shared__ signed char dmy_c[64];
+}  // namespace es_lds
+struct es_store_lane0 {
+    int lane;
+    __device__ __forceinline__ void operator()(unsigned* p, const unsigned x) const { *(lane == 0 ? p : &es_lds::dmy_u[lane]) = x; }
+};
+
+// phase B of an LDS range (see es_task_kernel): the remaining sub-ranges (<= kEsCoop records) are tasks of a TICKET QUEUE in LDS (round 5).
+// A wave takes a ticket, waits until that slot is published (or until no task is open any more: nothing will ever be published), partitions
+// the range and keeps the SMALLER child on its private stack; a larger child longer than kEsShare records goes back to the queue, where an idle
+// wave picks it up.  (Round 4 gave every queued range with its whole subtree to one wave: <= 8 tasks for 16 waves, 40-80 us on the slowest
+// wave -- profiles/r05_a_vg_*_before_exact_sort_stamps.log.)  lq_open = queue tasks not yet finished, subtrees included.
+//
+// CONTROL FLOW IS WAVE-UNIFORM ON PURPOSE.  A divergent `if (lane == 0) { atomic ... }` region that ends at a loop's back edge was compiled
+// (ROCm 7.2, gfx950) into a loop whose lane 0 and lanes 1..63 take the back edge SEPARATELY; the convergent operation at the loop's top
+// (readfirstlane / a __shfl of the ticket) then ran once per group, lanes 1..63 re-read ticket 0 and processed that task again -- partitions
+// with a partial exec mask (nL == 0 on a 76-record range) or an endless loop.  tools/experiments/lds_ticket_queue_test.hip reproduces it in
+// forty lines.  So: every lane executes every atomic (only lane 0 adds a non-zero value), every lane stores the wave's scalars (same value,
+// same address), scalars read back from LDS go through readfirstlane, and the median / heap-sort steps are executed by all lanes in
+// lock-step on the same words (reads of an instruction precede its writes: identical results).  A function of its own, not inlined: the
+// task kernel around it is 5,000 instructions deep in live scalars.
+__device__ __attribute__((noinline)) void es_phase_b(const unsigned m) {
+    using namespace es_lds;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // lane 0's address, a private scratch word for every other lane (one LDS pass instead of sixty-four serialised stores / atomics)
+    auto u0 = [&](unsigned* q) { return lane == 0 ? q : &dmy_u[lane]; };
+    auto c0 = [&](signed char* q) { return lane == 0 ? q : &dmy_c[lane]; };
+    const es_store_lane0 st0{lane};
+    auto rfl = [](const unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (;;) {
+        const unsigned ticket = rfl(atomicAdd(u0(&lq_head), 1u));
+        unsigned word = 0u;
+        if (ticket < (unsigned)kEsLocalQ) {
+            for (unsigned spin = 0;; ++spin) {
+                word = rfl(__hip_atomic_load(&qt[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (word != 0u) break;
+                if (rfl(__hip_atomic_load(&lq_open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) break;
+                if (rfl(__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) break;
+                if (spin > 400000u) { __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }  // watchdog (tens of ms): never hang
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (word == 0u) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        *u0(&ws_t[w][0]) = word;
+        *c0(&ws_d[w][0]) = qd[ticket];
+        int sp = 1;
+        while (sp > 0) {
+            --sp;
+            wave_sync();
+            const unsigned task_word = rfl(ws_t[w][sp]);
+            const int d = (int)rfl((unsigned)(unsigned char)ws_d[w][sp]);  // (depths are 0 .. 127)
+            const unsigned f = task_word & 0xffffu, l = task_word >> 16;
+            if (f >= l || l > m) { __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }  // (never: a corrupted word must not become wild LDS indices)
+            if (d == 0) {  // depth limit: heap sort (every lane runs it in lock-step on the same words); the range is sorted, every record a final block of its own
+                es_heap_sort(sk + f, sv + f, (int)(l - f), st0);
+                wave_sync();
+                for (unsigned i = f + 1u + (unsigned)lane; i < l; i += 64u) atomicOr(&bmask[i >> 5], 1u << (i & 31u));
+                continue;
+            }
+            unsigned p;
+            {   // std::__move_median_to_first(first, first + 1, mid, last - 1): loads first, then the four stores
+                const unsigned a = f + 1u, b = f + (l - f) / 2u, c = l - 1u;
+                const unsigned ka = sk[a], kb = sk[b], kc = sk[c];
+                unsigned med;
+                if (ka < kb) { if (kb < kc) med = b; else if (ka < kc) med = c; else med = a; }
+                else if (ka < kc) med = a;
+                else if (kb < kc) med = c;
+                else med = b;
+                med = rfl(med);
+                const unsigned k0 = sk[f], v0 = sv[f], km = sk[med], vm = sv[med];
+                wave_sync();
+                st0(&sk[f], km); st0(&sv[f], vm); st0(&sk[med], k0); st0(&sv[med], v0);
+                p = rfl(km);
+            }
+            wave_sync();
+            // one pass: both stop lists with left ranks (the running counts are the ranks); four rounds of reads in flight
+            unsigned nL = 0u, nR = 0u;
+            for (unsigned base = f + 1u; base < l; base += 64u * 4u) {
+                unsigned kk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const unsigned i = base + 64u * u + lane; kk[u] = i < l ? sk[i] : 0u; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned i = base + 64u * u + lane;
+                    const bool fl = i < l && kk[u] >= p, fr = i < l && kk[u] <= p;
+                    const unsigned long long ml = __ballot(fl), mr = __ballot(fr);
+                    if (fl) lp[f + nL + (unsigned)__popcll(ml & lt_mask)] = (unsigned short)i;
+                    if (fr) rl[f + nR + (unsigned)__popcll(mr & lt_mask)] = (unsigned short)i;
+                    nL += (unsigned)__popcll(ml); nR += (unsigned)__popcll(mr);
+                }
+            }
+            wave_sync();
+            unsigned K = 0u;
+            for (unsigned k0 = 0u; k0 < nL; k0 += 64u) {
+                const unsigned k = k0 + lane;
+                bool c = false;
+                unsigned a = 0u, b = 0u;
+                if (k < nL) { a = lp[f + k]; b = k < nR ? (unsigned)rl[f + nR - 1u - k] : f; c = a < b; }
+                if (c) { const unsigned ka = sk[a], va = sv[a]; sk[a] = sk[b]; sv[a] = sv[b]; sk[b] = ka; sv[b] = va; }
+                const unsigned long long mc = __ballot(c);
+                K += (unsigned)__popcll(mc);
+                if (mc != ~0ull) break;  // (monotone: nothing beyond the first false)
+            }
+            wave_sync();
+            // cut + children (scalars)
+            const unsigned INF = 0xFFFFFFFFu;
+            const unsigned ca = K < nL ? (unsigned)lp[f + K] : INF;
+            const unsigned cb = K >= 1u ? (K - 1u < nR ? (unsigned)rl[f + nR - K] : f) : INF;
+            const unsigned cut = rfl(ca < cb ? ca : cb);
+            if (cut <= f || cut >= l) { __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }  // (never)
+            atomicOr(u0(&bmask[cut >> 5]), 1u << (cut & 31u));
+            // the SMALLER child next on this wave (the stack stays logarithmic); the larger one to the queue when it is worth another wave's while
+            const unsigned m0 = cut - f, m1 = l - cut;
+            const unsigned big_f = m0 >= m1 ? f : cut, big_l = m0 >= m1 ? cut : l, sm_f = m0 >= m1 ? cut : f, sm_l = m0 >= m1 ? l : cut;
+            if (big_l - big_f > (unsigned)kEsThreshold) {
+                bool shared = false;
+                if (big_l - big_f > (unsigned)kEsShare) {
+                    atomicAdd(u0(&lq_open), 1u);
+                    const unsigned s2 = rfl(atomicAdd(u0(&lq_tail), 1u));
+                    if (s2 < (unsigned)kEsLocalQ) {
+                        *c0(&qd[s2]) = (signed char)(d - 1);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's records and the depth before the word
+                        __hip_atomic_store(u0(&qt[s2]), big_f | (big_l << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        shared = true;
+                    } else atomicSub(u0(&lq_open), 1u);  // (queue full: the range stays on this wave's stack)
+                }
+                if (!shared) {
+                    if (sp < kEsWaveStack) { *u0(&ws_t[w][sp]) = big_f | (big_l << 16); *c0(&ws_d[w][sp]) = (signed char)(d - 1); ++sp; }
+                    else __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            if (sm_l - sm_f > (unsigned)kEsThreshold) {
+                if (sp < kEsWaveStack) { *u0(&ws_t[w][sp]) = sm_f | (sm_l << 16); *c0(&ws_d[w][sp]) = (signed char)(d - 1); ++sp; }
+                else __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        atomicSub(u0(&lq_open), 1u);  // this queue task and its private subtree are done
     }
 }
 
@@ -306,19 +488,7 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                const unsigned* __restrict__ skip /* nullable; *skip != 0: the caller's plan was refused on the device, nothing to sort */) {
     if (skip != nullptr && *skip != 0u) return;
 #define ES_MARK(k) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0 && dbg->mark[k] == 0u) dbg->mark[k] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
-    __shared__ unsigned sk[kEsLds], sv[kEsLds];
-    __shared__ unsigned short lp[kEsLds], rl[kEsLds];
-    __shared__ unsigned bmask[kEsLds / 32 + 2];  // bit i: a partition cut (or the range's ends) lies in front of record i
-    __shared__ unsigned ws_t[kEsTaskWaves][kEsWaveStack];  // per-wave depth-first stacks of phase B
-    __shared__ signed char ws_d[kEsTaskWaves][kEsWaveStack];
-    __shared__ unsigned qt[kEsLocalQ];  // local task = first | last << 16, published with one release store (0 = not yet)
-    __shared__ signed char qd[kEsLocalQ];
-    __shared__ unsigned lq_head, lq_tail, lq_open, s_sp;
-    __shared__ unsigned short sa_f[kEsStack], sa_l[kEsStack];
-    __shared__ signed char sa_d[kEsStack];
-    __shared__ unsigned s_wl[kEsTaskWaves], s_wr[kEsTaskWaves], s_cnt[kEsTaskWaves];
-    __shared__ unsigned s_first, s_last, s_pivot, s_state, s_fail;
-    __shared__ int s_depth;
+    using namespace es_lds;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     bool take_init = init_n != 0u && blockIdx.x == 0;
@@ -567,101 +737,12 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                 __syncthreads();
             }
             ES_MARK(3);
-            // ---- phase B: every remaining sub-range (<= kEsCoop records, queued by phase A) belongs to ONE wave, which runs its whole
-            // subtree depth first from a private stack: no queue traffic, no waiting between partitions ----
-            for (;;) {
-                unsigned slot = 0u;
-                if (lane == 0) slot = atomicAdd(&lq_head, 1u);
-                slot = __shfl(slot, 0, 64);
-                if (slot >= lq_tail || slot >= (unsigned)kEsLocalQ) break;  // (lq_tail is final: phase A filled the queue)
-                int sp = 0;
-                if (lane == 0) { ws_t[w][0] = qt[slot]; ws_d[w][0] = qd[slot]; }
-                sp = 1;
-                while (sp > 0) {
-                    --sp;
-                    const unsigned task_word = ws_t[w][sp];
-                    const int d = ws_d[w][sp];
-                    const unsigned f = task_word & 0xffffu, l = task_word >> 16;
-                    if (d == 0) {  // depth limit: heap sort by one lane; the range is sorted, every record a final block of its own
-                        if (lane == 0) es_heap_sort(sk + f, sv + f, (int)(l - f));
-                        for (unsigned i = f + 1u + (unsigned)lane; i < l; i += 64u) atomicOr(&bmask[i >> 5], 1u << (i & 31u));
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        continue;
-                    }
-                    unsigned p = 0u;
-                    if (lane == 0) {
-                        const unsigned a = f + 1u, b = f + (l - f) / 2u, c = l - 1u;
-                        const unsigned ka = sk[a], kb = sk[b], kc = sk[c];
-                        unsigned med;
-                        if (ka < kb) { if (kb < kc) med = b; else if (ka < kc) med = c; else med = a; }
-                        else if (ka < kc) med = a;
-                        else if (kb < kc) med = c;
-                        else med = b;
-                        const unsigned k0 = sk[f], v0 = sv[f];
-                        sk[f] = sk[med]; sv[f] = sv[med]; sk[med] = k0; sv[med] = v0;
-                        p = sk[f];
-                    }
-                    p = __shfl(p, 0, 64);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    // one pass: both stop lists with left ranks (the running counts are the ranks); four rounds of reads in flight
-                    unsigned nL = 0u, nR = 0u;
-                    for (unsigned base = f + 1u; base < l; base += 64u * 4u) {
-                        unsigned kk[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { const unsigned i = base + 64u * u + lane; kk[u] = i < l ? sk[i] : 0u; }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const unsigned i = base + 64u * u + lane;
-                            const bool fl = i < l && kk[u] >= p, fr = i < l && kk[u] <= p;
-                            const unsigned long long ml = __ballot(fl), mr = __ballot(fr);
-                            if (fl) lp[f + nL + (unsigned)__popcll(ml & lt_mask)] = (unsigned short)i;
-                            if (fr) rl[f + nR + (unsigned)__popcll(mr & lt_mask)] = (unsigned short)i;
-                            nL += (unsigned)__popcll(ml); nR += (unsigned)__popcll(mr);
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    unsigned K = 0u;
-                    for (unsigned k0 = 0u; k0 < nL; k0 += 64u) {
-                        const unsigned k = k0 + lane;
-                        bool c = false;
-                        unsigned a = 0u, b = 0u;
-                        if (k < nL) { a = lp[f + k]; b = k < nR ? (unsigned)rl[f + nR - 1u - k] : f; c = a < b; }
-                        if (c) { const unsigned ka = sk[a], va = sv[a]; sk[a] = sk[b]; sv[a] = sv[b]; sk[b] = ka; sv[b] = va; }
-                        const unsigned long long mc = __ballot(c);
-                        K += (unsigned)__popcll(mc);
-                        if (mc != ~0ull) break;  // (monotone: nothing beyond the first false)
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    // cut + children (wave-uniform values: every lane computes them from the same LDS words)
-                    const unsigned INF = 0xFFFFFFFFu;
-                    const unsigned ca = K < nL ? (unsigned)lp[f + K] : INF;
-                    const unsigned cb = K >= 1u ? (K - 1u < nR ? (unsigned)rl[f + nR - K] : f) : INF;
-                    const unsigned cut = ca < cb ? ca : cb;
-                    if (lane == 0) atomicOr(&bmask[cut >> 5], 1u << (cut & 31u));
-                    // depth first, the SMALLER child next (the stack stays logarithmic)
-                    const unsigned m0 = cut - f, m1 = l - cut;
-                    const unsigned big_f = m0 >= m1 ? f : cut, big_l = m0 >= m1 ? cut : l, sm_f = m0 >= m1 ? cut : f, sm_l = m0 >= m1 ? l : cut;
-                    if (big_l - big_f > (unsigned)kEsThreshold) {
-                        if (sp < kEsWaveStack) { if (lane == 0) { ws_t[w][sp] = big_f | (big_l << 16); ws_d[w][sp] = (signed char)(d - 1); } ++sp; }
-                        else if (lane == 0) __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    if (sm_l - sm_f > (unsigned)kEsThreshold) {
-                        if (sp < kEsWaveStack) { if (lane == 0) { ws_t[w][sp] = sm_f | (sm_l << 16); ws_d[w][sp] = (signed char)(d - 1); } ++sp; }
-                        else if (lane == 0) __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-            }
+            // ---- phase B (round 5): the remaining sub-ranges (<= kEsCoop records) are tasks of a TICKET QUEUE in LDS.  A wave takes a ticket,
+            // waits until that slot is published (or until no task is open any more: nothing will ever be published), partitions the range
+            // and keeps the SMALLER child on its private stack; a larger child longer than kEsShare records goes back to the queue, where an
+            // idle wave picks it up.  (Round 4 gave every queued range with its whole subtree to one wave: <= 8 tasks for 16 waves, 40-80 us
+            // on the slowest wave -- profiles/r05_a_vg_*_before_exact_sort_stamps.log.)  open = queue tasks not yet finished, subtrees included.
+            es_phase_b(m);
             ES_MARK(4);
             __syncthreads();
             ES_MARK(5);
