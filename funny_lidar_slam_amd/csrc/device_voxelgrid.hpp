@@ -95,7 +95,7 @@ struct DeviceExactSort {
         }
         es_debug_mailbox() = mb_host;
         work_cap = unsigned(64 * (n / kEsLds + 1) + 1024);
-        tile_cap = unsigned(n / kEsTile + n / kEsTaskMax + 2);
+        tile_cap = unsigned(n / kEsTile + kEsMaxSeg + 2);
         seg_a.reserve(kEsMaxSeg); seg_b.reserve(kEsMaxSeg);
         work.reserve(work_cap);
         ready.reserve(work_cap);
@@ -114,13 +114,51 @@ struct DeviceExactSort {
         allocate(n);
         return EsInitArgs{st.p, queue.p, ready.p, work_cap};
     }
+    // Ranges longer than `big` records are partitioned LEVEL-SYNCHRONOUSLY by the whole device -- four launches per level (es_level_begin / count /
+    // scatter / swap, the regime-1 kernels), pre-enqueued without a host round trip: one workgroup needs 3 us + 0.38 us per thousand records
+    // for a partition (profiles/r05_d_ndt_global_levels.log: 47 us at 115,200), a level of launches ~14 us whatever the size.  The number of
+    // levels is a guess (the larger child keeps ~13/16 of a LiDAR range); levels that find nothing left are empty launches, ranges still longer
+    // than `big` after the last one are the task kernel's (one workgroup each, as in round 4).  FLS_ES_BIG = 0 switches the top levels off.
+    static unsigned big_threshold() {
+        static const unsigned v = [] { const char* e = std::getenv("FLS_ES_BIG"); return e ? unsigned(std::atoi(e)) : 32768u; }();
+        return v;
+    }
     void fused_launch(unsigned* key, unsigned* val, const size_t n, const unsigned* skip, hipStream_t s) {
         ++runs;
         const unsigned grid = unsigned(std::min<size_t>(256, std::max<size_t>(8, n / kEsLds + 4)));
         static const bool dbg_marks = std::getenv("FLS_ES_DEBUG") != nullptr;
         if (dbg_marks) std::memset(mb_host->mark, 0, sizeof(mb_host->mark));
+        const unsigned big = big_threshold();
+        int top = 0;
+        if (big != 0u && n > size_t(big)) {
+            for (size_t m = n; m > size_t(big); m = m * 13 / 16) ++top;
+            static const int extra = [] { const char* e = std::getenv("FLS_ES_TOP_EXTRA"); return e ? std::atoi(e) : 0; }();
+            top = std::max(1, top + extra);
+        }
+        if (top == 0) {
+            hipLaunchKernelGGL(es_task_kernel, dim3(grid), dim3(kEsTaskThreads), 0, s, key, val, work.p, ready.p, work_cap, queue.p, Lp.p, Rl.p, st.p,
+                               dbg_marks ? mb_dev : (EsMailbox*)nullptr, unsigned(n), skip);
+            return;
+        }
+        auto next_seq = [&]() { seq = (seq + 1u) & 0x7fffffffu; if (!seq) seq = 1u; return seq; };
+        EsSeg* prev = seg_a.p;
+        EsSeg* cur = seg_b.p;
+        hipLaunchKernelGGL(es_level_begin, dim3(1), dim3(256), 0, s, key, val, unsigned(n), (const EsSeg*)prev, cur, work.p, work_cap, (const unsigned*)Lp.p,
+                           (const unsigned*)Rl.p, st.p, (EsMailbox*)nullptr, next_seq(), 1, tile_seg.p, tile_cap, big, 0, queue.p, skip);
+        for (int l = 0; l < top; ++l) {
+            hipLaunchKernelGGL(es_count_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, (const unsigned*)key, (const EsSeg*)cur, (const EsState*)st.p,
+                               (const unsigned*)tile_seg.p, tile_cnt.p);
+            hipLaunchKernelGGL(es_scatter_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, (const unsigned*)key, cur, (const EsState*)st.p, (const unsigned*)tile_seg.p,
+                               (const uint2*)tile_cnt.p, Lp.p, Rl.p);
+            hipLaunchKernelGGL(es_swap_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, key, val, cur, (const EsState*)st.p, (const unsigned*)tile_seg.p,
+                               (const unsigned*)Lp.p, (const unsigned*)Rl.p);
+            std::swap(prev, cur);
+            hipLaunchKernelGGL(es_level_begin, dim3(1), dim3(256), 0, s, key, val, unsigned(n), (const EsSeg*)prev, cur, work.p, work_cap, (const unsigned*)Lp.p,
+                               (const unsigned*)Rl.p, st.p, (EsMailbox*)nullptr, next_seq(), 0, tile_seg.p, tile_cap, big, l == top - 1 ? 1 : 0, queue.p, skip);
+            ++levels;
+        }
         hipLaunchKernelGGL(es_task_kernel, dim3(grid), dim3(kEsTaskThreads), 0, s, key, val, work.p, ready.p, work_cap, queue.p, Lp.p, Rl.p, st.p,
-                           dbg_marks ? mb_dev : (EsMailbox*)nullptr, unsigned(n), skip);
+                           dbg_marks ? mb_dev : (EsMailbox*)nullptr, 0u, skip);
     }
     // queues the whole sort on `s`; false: refused before anything ran (sizes).  The verdict of the sort itself (introsort's heap-sort
     // case) is only known once the stream has drained: failed_after_sync().
@@ -148,7 +186,7 @@ struct DeviceExactSort {
         EsSeg* prev = seg_a.p;
         EsSeg* cur = seg_b.p;
         hipLaunchKernelGGL(es_level_begin, dim3(1), dim3(256), 0, s, key, val, unsigned(n), (const EsSeg*)prev, cur, work.p, work_cap, (const unsigned*)Lp.p,
-                           (const unsigned*)Rl.p, st.p, mb_dev, next_seq(), 1, tile_seg.p, tile_cap);
+                           (const unsigned*)Rl.p, st.p, mb_dev, next_seq(), 1, tile_seg.p, tile_cap, unsigned(kEsTaskMax), 0, (EsQueue*)nullptr, (const unsigned*)nullptr);
         // regime 1 (ranges longer than kEsTaskMax: only clouds beyond 131 k points get here)
         int expected = 0;
         for (size_t m = n; m > size_t(kEsTaskMax); m = (m + 1) / 2) ++expected;
@@ -163,7 +201,7 @@ struct DeviceExactSort {
                                    (const unsigned*)Lp.p, (const unsigned*)Rl.p);
                 std::swap(prev, cur);
                 hipLaunchKernelGGL(es_level_begin, dim3(1), dim3(256), 0, s, key, val, unsigned(n), (const EsSeg*)prev, cur, work.p, work_cap, (const unsigned*)Lp.p,
-                                   (const unsigned*)Rl.p, st.p, mb_dev, next_seq(), 0, tile_seg.p, tile_cap);
+                                   (const unsigned*)Rl.p, st.p, mb_dev, next_seq(), 0, tile_seg.p, tile_cap, unsigned(kEsTaskMax), 0, (EsQueue*)nullptr, (const unsigned*)nullptr);
                 ++levels;
             }
             FLS_HIP(hipGetLastError());
@@ -195,6 +233,13 @@ struct DeviceExactSort {
             auto us = [&](int a, int b) { return mk[a] && mk[b] ? 0.01 * double(int(mk[b] - mk[a])) : -1.0; };
             std::fprintf(stderr, "[fls exact sort] workgroup 0, first task [us]: pop->start %.1f, global partitions %.1f, LDS load %.1f, phase A (workgroup partitions) %.1f, phase B (wave tasks) %.1f, "
                          "ranks + write-back %.1f\n", us(0, 2), us(2, 9), us(9, 10), us(10, 3), us(3, 4), us(5, 6));
+            for (int i = 0; i < 32 && mb_host->lvl[i][0]; ++i) {
+                const unsigned* q = mb_host->lvl[i];
+                auto d = [&](int a, int b) { return 0.01 * double(int(q[b] - q[a])); };
+                std::fprintf(stderr, "[fls exact sort]   global partition %2d: %6u records | median %.1f | count %.1f | lists %.1f | swaps %.1f | cut + push %.1f | total %.1f us\n", i, q[0], d(1, 2), d(2, 3),
+                             d(3, 4), d(4, 5), d(5, 6), d(1, 6));
+            }
+            std::memset(mb_host->lvl, 0, sizeof(mb_host->lvl));
         }
         return false;
     }

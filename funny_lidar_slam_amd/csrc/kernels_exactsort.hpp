@@ -37,6 +37,7 @@ constexpr int kEsMaxSeg = 64;       // regime-1 ranges of one level (n / kEsTask
 
 struct EsSeg { unsigned first, last; int depth; unsigned pivot, nL, nR, K, tile0; };
 struct EsWork { unsigned first, last; int depth, pad; };
+struct EsQueue { unsigned head, tail, open, n_init; };  // the task kernel's queue (entries below n_init are ready without a flag)
 struct EsState {
     unsigned n_cur;     // regime-1 ranges of the level in flight
     unsigned n_tiles;   // their tiles
@@ -46,7 +47,7 @@ struct EsState {
     unsigned pad[3];
 };
 // what the host polls (host-mapped): written by every es_level_begin
-struct EsMailbox { unsigned seq, n_cur, n_work, fail; unsigned mark[12]; };  // mark: progress counters of es_task_kernel (diagnostics)
+struct EsMailbox { unsigned seq, n_cur, n_work, fail; unsigned mark[12]; unsigned lvl[32][8]; };  // mark / lvl: stage stamps of es_task_kernel (diagnostics, FLS_ES_DEBUG): lvl[i] = {range size, 100 MHz stamps of the phases of workgroup 0's i-th partition out of global memory}
 
 __device__ __forceinline__ void es_swap_rec(unsigned* __restrict__ key, unsigned* __restrict__ val, const unsigned a, const unsigned b) {
     const unsigned ka = key[a], kb = key[b], va = val[a], vb = val[b];
@@ -72,14 +73,25 @@ __global__ void __launch_bounds__(256)
 es_level_begin(unsigned* __restrict__ key, unsigned* __restrict__ val, const unsigned n, const EsSeg* __restrict__ prev, EsSeg* __restrict__ cur,
                EsWork* __restrict__ work, const unsigned work_cap, const unsigned* __restrict__ Lp, const unsigned* __restrict__ Rl,
                EsState* __restrict__ st, EsMailbox* __restrict__ mb, const unsigned seq, const int first_level, unsigned* __restrict__ tile_seg,
-               const unsigned tile_cap) {
+               const unsigned tile_cap,
+               // round 5 (the pre-enqueued top levels of the one-stream VoxelGrid, DeviceExactSort::fused_launch): ranges longer than `big` stay
+               // level-synchronous; final_level: every child becomes a task and the task kernel's queue is written here; *skip != 0: nothing to sort
+               const unsigned big, const int final_level, EsQueue* __restrict__ q_out, const unsigned* __restrict__ skip) {
     __shared__ unsigned s_ncur, s_nwork, s_fail, s_tiles[kEsMaxSeg], s_total;
+    if (skip != nullptr && *skip != 0u) {
+        if (threadIdx.x == 0) {
+            st->n_cur = 0u; st->n_tiles = 0u; st->n_work = 0u;
+            if (q_out != nullptr) *q_out = EsQueue{0u, 0u, 0u, 0u};
+        }
+        return;
+    }
     if (threadIdx.x == 0) { s_ncur = 0u; s_nwork = first_level ? 0u : st->n_work; s_fail = first_level ? 0u : st->fail; }
     __syncthreads();
+    const unsigned stay = final_level ? 0xFFFFFFFFu : big;
     auto child = [&](const unsigned f, const unsigned l, const int depth) {
         const unsigned m = l - f;
         if (m < 2u) return;
-        if (m > (unsigned)kEsTaskMax) {
+        if (m > stay) {
             const unsigned slot = atomicAdd(&s_ncur, 1u);
             if (slot < (unsigned)kEsMaxSeg) cur[slot] = EsSeg{f, l, depth, 0u, 0u, 0u, 0u, 0u};
             else s_fail = 1u;
@@ -138,11 +150,14 @@ es_level_begin(unsigned* __restrict__ key, unsigned* __restrict__ val, const uns
         st->n_work = s_nwork < work_cap ? s_nwork : work_cap;
         st->fail = s_fail;
         st->level = first_level ? 0u : st->level + 1u;
-        __hip_atomic_store(&mb->n_cur, st->n_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mb->n_work, st->n_work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mb->fail, s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (q_out != nullptr && final_level) { const unsigned nw = st->n_work; *q_out = EsQueue{0u, nw, nw, nw}; }
+        if (mb != nullptr) {  // (the host steers the levels only beyond kEsTaskMax records; the pre-enqueued levels of the one-stream form pass nullptr)
+            __hip_atomic_store(&mb->n_cur, st->n_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mb->n_work, st->n_work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mb->fail, s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 // workgroup -> (range, tile)
@@ -218,16 +233,41 @@ es_swap_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsSeg* __
     unsigned seg, tile;
     if (!es_locate(cur, st, tile_seg, seg, tile)) return;
     const EsSeg g = cur[seg];
-    auto Lk = [&](const unsigned k) { return Lp[g.first + k]; };
-    auto Rk = [&](const unsigned k) { return k < g.nR ? Rl[g.first + g.nR - 1u - k] : g.first; };  // (the pivot itself stops the downward scan last)
-    auto cond = [&](const unsigned k) { return k < g.nL && Lk(k) < Rk(k); };
+    // (round 5: three phases with every item's loads in flight together -- stop positions, then records, then stores.  The item-by-item loop it
+    // replaces chained eight dependent three-hop round trips per thread: 9-11 us per launch in profiles/r05_e_ndt_top_levels_sequence.txt)
+    const unsigned span = g.last - g.first - 1u;
+    const unsigned kmax = g.nL < g.nR + 1u ? g.nL : g.nR + 1u;  // pairs beyond min(nL, nR + 1) cannot hold
+    unsigned a[kEsItems + 0], b[kEsItems + 0];
+    bool c[kEsItems], cn[kEsItems];
 #pragma unroll
     for (int q = 0; q < kEsItems; ++q) {
         const unsigned k = tile * (unsigned)kEsTile + q * (unsigned)kEsBlock + threadIdx.x;
-        if (k >= g.last - g.first - 1u) continue;
-        if (!cond(k)) continue;
-        es_swap_rec(key, val, Lk(k), Rk(k));
-        if (!cond(k + 1u)) cur[seg].K = k + 1u;
+        const bool in = k < span && k < kmax;
+        a[q] = in ? Lp[g.first + k] : 0u;
+        b[q] = in ? (k < g.nR ? Rl[g.first + g.nR - 1u - k] : g.first) : 0u;
+    }
+    unsigned an[kEsItems], bn[kEsItems];
+#pragma unroll
+    for (int q = 0; q < kEsItems; ++q) {  // the pair after it (the K* test): the same words one thread further, L1-resident
+        const unsigned k = tile * (unsigned)kEsTile + q * (unsigned)kEsBlock + threadIdx.x + 1u;
+        const bool in = k < span && k < kmax;
+        an[q] = in ? Lp[g.first + k] : 0u;
+        bn[q] = in ? (k < g.nR ? Rl[g.first + g.nR - 1u - k] : g.first) : 0u;
+    }
+    unsigned ka[kEsItems], kb[kEsItems], va[kEsItems], vb[kEsItems];
+#pragma unroll
+    for (int q = 0; q < kEsItems; ++q) {
+        const unsigned k = tile * (unsigned)kEsTile + q * (unsigned)kEsBlock + threadIdx.x;
+        c[q] = k < span && k < kmax && a[q] < b[q];
+        cn[q] = k + 1u < span && k + 1u < kmax && an[q] < bn[q];
+        if (c[q]) { ka[q] = key[a[q]]; kb[q] = key[b[q]]; va[q] = val[a[q]]; vb[q] = val[b[q]]; }
+    }
+#pragma unroll
+    for (int q = 0; q < kEsItems; ++q) {
+        if (!c[q]) continue;
+        const unsigned k = tile * (unsigned)kEsTile + q * (unsigned)kEsBlock + threadIdx.x;
+        key[a[q]] = kb[q]; key[b[q]] = ka[q]; val[a[q]] = vb[q]; val[b[q]] = va[q];
+        if (!cn[q]) cur[seg].K = k + 1u;
     }
 }
 
@@ -258,7 +298,6 @@ constexpr int kEsShare = FLS_ES_SHARE;  // a wave hands children longer than thi
 constexpr int kEsStack = 64;     // pending workgroup-level sub-ranges (disjoint, each > kEsCoop records: at most kEsLds / kEsCoop)
 constexpr int kEsWaveStack = 48; // a wave's depth-first stack (smaller child first: <= log2(kEsCoop) + 1 pending ranges)
 constexpr int kEsLocalQ = 1024;  // sub-range tasks of one LDS range (<= 2 per partition, <= kEsLds / 17 partitions)
-struct EsQueue { unsigned head, tail, open, n_init; };
 
 __device__ __forceinline__ unsigned es_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // push a range (>= 2 records) onto the global queue; the caller has released its writes
@@ -492,6 +531,7 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     bool take_init = init_n != 0u && blockIdx.x == 0;
+    int glvl = 0;  // (diagnostics: partitions out of global memory this workgroup has done)
     for (;;) {
         // ---- pop a task (thread 0), broadcast ----
         if (t == 0 && take_init) {
@@ -541,9 +581,13 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
             // no queue round trip (pop, acquire, ~10 atomics) on the critical path of a lopsided recursion ============
             if (depth == 0) { if (t == 0) atomicExch(&st->fail, 1u); dead = true; break; }  // (introsort switches to heap sort here)
             if (t == 0) atomicAdd(&st->pad[0], 1u);  // diagnostics: partitions done from global memory
+#define ES_LVL(j) do { if (dbg && t == 0 && blockIdx.x == 0 && glvl < 32) dbg->lvl[glvl][j] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
             {
+                if (dbg && t == 0 && blockIdx.x == 0 && glvl < 32) dbg->lvl[glvl][0] = m;
+                ES_LVL(1);
                 if (t == 0) s_pivot = es_median_to_first(key, val, first, last);
                 __syncthreads();
+                ES_LVL(2);
                 const unsigned p = s_pivot;
                 // wave w owns a contiguous slice of [first + 1, last), a multiple of 64 positions long
                 const unsigned span = last - first - 1u, per = ((span + kEsTaskWaves - 1u) / kEsTaskWaves + 63u) & ~63u;
@@ -565,6 +609,7 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                 }
                 if (lane == 0) { s_wl[w] = cl; s_wr[w] = cr; }
                 __syncthreads();
+                ES_LVL(3);
                 unsigned bl = 0u, br = 0u, nL = 0u, nR = 0u;
                 for (int x = 0; x < kEsTaskWaves; ++x) { const unsigned a = s_wl[x], b = s_wr[x]; if (x < w) { bl += a; br += b; } nL += a; nR += b; }
                 for (unsigned base = w0; base < w1; base += 64u * U) {
@@ -582,6 +627,7 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                     }
                 }
                 __syncthreads();
+                ES_LVL(4);
                 // the K* swaps (cond is monotone in k: K* = the number of k it holds for).  Pair k needs L_k and the k-th R-stop from the
                 // right; candidates beyond min(nL, nR + 1) cannot hold.  Conditions first (independent loads), then the records.
                 auto Rk = [&](const unsigned k) { return k < nR ? Rl[first + nR - 1u - k] : first; };
@@ -612,6 +658,7 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                 if (lane == 0) s_cnt[w] = mine;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's swaps have left the CU
                 __syncthreads();
+                ES_LVL(5);
                 if (t == 0) {
                     unsigned K = 0u;
                     for (int x = 0; x < kEsTaskWaves; ++x) K += s_cnt[x];
@@ -626,6 +673,8 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                     else { es_push(q, tasks, ready, cap, st, cut, last, depth - 1); s_first = first; s_last = cut; }
                 }
                 __syncthreads();
+                ES_LVL(6);
+                if (blockIdx.x == 0) ++glvl;
                 first = s_first; last = s_last; m = last - first; --depth;
             }
         }
