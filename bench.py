@@ -190,6 +190,22 @@ def bench_other_configs(reg, synth, util, O, budget_s=6.0):
         m = reg.make_matcher(mode, y, is_localization_mode=loc)
         m.AddCloudToLocalMap(maps)
         cl = util.cluster_for(mode, cfg["scan"], corner)
+        # What the reference's Match does, with its input already in device memory: IcpOptimized / IncrementalNDT VoxelGrid their source cloud
+        # FIRST (icp_optimized.h:57, incremental_ndt.h:231-232), so `scans_per_s` times fls_scan_upload_raw + fls_match_resident -- the raw
+        # cloud resident, the pcl::VoxelGrid (bit-identical device filter) inside every timed call.  The round-1..4
+        # figure -- the filter done once at upload, only the iterations timed -- stays as `resident_filtered_*`.
+        filters_inside = mode in ("IcpOptimized", "IncrementalNDT")
+        ts_raw = None
+        if filters_inside:
+            m.UploadScanRaw(cl)
+            run_raw, Tv_raw = m.resident_call(np.eye(4))
+            for _ in range(5):
+                run_raw()
+            ts_raw = []
+            for _ in range(30):
+                t = time.perf_counter(); run_raw(); ts_raw.append(time.perf_counter() - t)
+            T_raw = np.array(Tv_raw)
+            iters_raw = int(m.stats.iterations)
         m.UploadScan(cl)
         run, Tv = m.resident_call(np.eye(4))
         for _ in range(5):
@@ -197,6 +213,8 @@ def bench_other_configs(reg, synth, util, O, budget_s=6.0):
         ts = []
         for _ in range(30):
             t = time.perf_counter(); run(); ts.append(time.perf_counter() - t)
+        if filters_inside:
+            assert np.array_equal(T_raw, np.array(Tv)) and iters_raw == int(m.stats.iterations), "filter inside the call must not change the result"
         m.set_profiling(True)
         for _ in range(10):
             run()
@@ -257,8 +275,13 @@ def bench_other_configs(reg, synth, util, O, budget_s=6.0):
                 bytes_iter = algorithmic_bytes(q.shape[0] + qc.shape[0], pr + pr2, hi + hi2, ca + ca2)
         avg_launch_s = (ms / 1e3) / max(nl, 1)
         ach = bytes_iter / avg_launch_s / 1e9 if nl else 0.0
+        t_whole = float(np.median(ts_raw)) if filters_inside else float(np.median(ts))
         out[f"configs[{cid}]"] = {
-            "workload": name, "scans_per_s": 1.0 / float(np.median(ts)), "match_us": 1e6 * float(np.median(ts)), "gn_iterations": iters,
+            "workload": name, "scans_per_s": 1.0 / t_whole, "match_us": 1e6 * t_whole,
+            "timed_call": ("fls_scan_upload_raw once, then fls_match_resident: the source pcl::VoxelGrid + every iteration per call (the whole reference Match, input resident)"
+                           if filters_inside else "fls_scan_upload once, then fls_match_resident (this kind's Match has no source filter)"),
+            "resident_filtered_match_us": 1e6 * float(np.median(ts)), "resident_filtered_scans_per_s": 1.0 / float(np.median(ts)),
+            "gn_iterations": iters,
             "converged": bool(m.stats.converged), "source_points": n_pts, "pose_err_vs_oracle_m_rad": [dt, dr],
             "match_from_host_buffers_us": from_host,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -577,7 +600,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # under a launcher (torch.distributed.run sets RANK / WORLD_SIZE) the process group is ALWAYS created, also at world size 1: that is how
+    # the RCCL branch -- nccl init with device_id, CUDA-tensor broadcast / all_gather / all_reduce, the nccl + gloo group mix -- runs on a
+    # 1-GPU box (tests/test_gpu_batch_ranks.py::test_rccl_path_at_world_size_1; VERDICT r4 missing #1)
+    distributed = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
     n_gpus = world if distributed else 1
 
     from funny_lidar_slam_amd import batch, synth
@@ -632,19 +658,27 @@ def main():
     map_bcast = None
     if distributed:
         # rank 0 builds the map, its image travels in one broadcast, every other GPU imports it
-        te0 = time.perf_counter()
-        blob = m.ExportMap() if rank == 0 else None
-        export_ms = 1e3 * (time.perf_counter() - te0)  # (rank 0: device image -> host mirror -> blob; the other ranks export nothing)
-        tb0 = time.perf_counter()
-        blob = batch.broadcast_blob(blob, src=0, device=coll_dev)
-        tb1 = time.perf_counter()
-        if rank != 0:
-            m.ImportMap(blob)
-        ti = torch.tensor([time.perf_counter() - tb1], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(ti, op=dist.ReduceOp.MAX)  # rank 0 imports nothing: the slowest importing rank
-        map_bcast = {"blob_MB": blob.size / 1e6, "export_ms_rank0": export_ms, "broadcast_ms": 1e3 * (tb1 - tb0), "import_ms_max_over_ranks": 1e3 * float(ti.item()),
-                     "note": "separate processes: the blob travels; one process driving N GPUs copies the device image instead (c5_batch_native, fls_replicas_*)"}
-        del blob
+        # (round 5: the DEVICE image travels -- exported straight into the collective's buffer, imported from it; rounds 2-4 shipped the host blob:
+        # ExportMap 90 ms + ImportMap 78 ms per rank.  FLS_BENCH_BLOB_BROADCAST=1 keeps that form for A/B.)
+        if os.environ.get("FLS_BENCH_BLOB_BROADCAST", "0") == "1":
+            te0 = time.perf_counter()
+            blob = m.ExportMap() if rank == 0 else None
+            export_ms = 1e3 * (time.perf_counter() - te0)
+            tb0 = time.perf_counter()
+            blob = batch.broadcast_blob(blob, src=0, device=coll_dev)
+            tb1 = time.perf_counter()
+            if rank != 0:
+                m.ImportMap(blob)
+            tr = {"image_MB": blob.size / 1e6, "export_ms": export_ms, "broadcast_ms": 1e3 * (tb1 - tb0), "import_ms": 1e3 * (time.perf_counter() - tb1), "buffer": "host blob"}
+            del blob
+        else:
+            tr = batch.broadcast_map_image(m, src=0, device=coll_dev)
+        ti = torch.tensor([tr["import_ms"], tr["export_ms"], tr["broadcast_ms"]], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(ti, op=dist.ReduceOp.MAX)  # rank 0 imports nothing, the others export nothing: the slowest rank of each
+        map_bcast = {"image_MB": tr["image_MB"], "buffer": tr["buffer"], "export_ms_rank0": float(ti[1].item()), "broadcast_ms": float(ti[2].item()),
+                     "import_ms_max_over_ranks": float(ti[0].item()),
+                     "note": "the flat device image (points | brick directory | cells) written into the collective's own buffer by fls_map_image_export and taken "
+                             "from it by fls_map_image_import; importing ranks are read-only replicas"}
     t_map = time.perf_counter() - t_map
     cluster = reg.PointcloudCluster(planar_cloud_=cfg["scan"])
     m.UploadScan(cluster)  # inputs resident in HBM before the timed region
@@ -800,7 +834,7 @@ def main():
             "metric": baseline_metric(),
             "value": value, "unit": "scans/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "distributed_backend": (args.backend if distributed else None),
             "protocol": {"version": 3, "pre_warm_matches": PRE_WARM_MATCHES, "event_bracketed_steps": "mid-period, one step in 32",
                          "note": "version 3 since round 3 (256 untimed pre-warm Matches, mid-period event brackets, call-k oracle comparison); rounds 1-2 "
                                  "lines (protocol 1 / 2: no pre-warm, bracket on step 0 / every 8th step) are not directly comparable"},

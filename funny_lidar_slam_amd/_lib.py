@@ -16,7 +16,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 # every symbol include/fls_reg.h declares (tests check they are all exported)
 EXPORTED_SYMBOLS = [
     "fls_create", "fls_destroy", "fls_add_cloud_to_local_map", "fls_match", "fls_get_fitness_score",
-    "fls_scan_upload", "fls_scan_upload_raw", "fls_match_resident", "fls_match_batch", "fls_map_export", "fls_map_import", "fls_get_iteration_log", "fls_get_correspondences", "fls_map_size",
+    "fls_scan_upload", "fls_scan_upload_raw", "fls_match_resident", "fls_match_batch", "fls_map_export", "fls_map_import", "fls_map_image_bytes", "fls_map_image_export", "fls_map_image_import", "fls_get_iteration_log", "fls_get_correspondences", "fls_map_size",
     "fls_set_profiling", "fls_get_kernel_time", "fls_get_traffic_counters", "fls_get_debug_stamps", "fls_debug_fullpiv_qr6", "fls_debug_voxel_grid", "fls_debug_exact_sort", "fls_debug_exact_sort_marks", "fls_voxel_grid_cloud", "fls_loop_match", "fls_status_string", "fls_abi_version", "fls_abi_revision",
     "fls_device_count",
     "fls_replicas_create", "fls_replicas_refresh", "fls_replicas_match_batch", "fls_replicas_import_ms", "fls_replicas_destroy",
@@ -142,6 +142,12 @@ def lib():
         L.fls_get_fitness_score.argtypes = [hp, C.c_float, fp]
         L.fls_scan_upload.restype = C.c_int
         L.fls_scan_upload.argtypes = [hp, fp, C.c_size_t, fp, C.c_size_t, C.c_int]
+        L.fls_map_image_bytes.restype = C.c_size_t
+        L.fls_map_image_bytes.argtypes = [hp]
+        L.fls_map_image_export.restype = C.c_int
+        L.fls_map_image_export.argtypes = [hp, C.c_void_p, C.c_size_t, C.c_int]
+        L.fls_map_image_import.restype = C.c_int
+        L.fls_map_image_import.argtypes = [hp, C.c_void_p, C.c_size_t, C.c_int]
         L.fls_scan_upload_raw.restype = C.c_int
         L.fls_scan_upload_raw.argtypes = [hp, fp, C.c_size_t, fp, C.c_size_t, C.c_int]
         L.fls_match_resident.restype = C.c_int

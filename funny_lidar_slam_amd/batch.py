@@ -76,6 +76,48 @@ def broadcast_blob(blob, src: int = 0, device=None) -> np.ndarray:
     return buf.cpu().numpy()
 
 
+def broadcast_map_image(m, src: int = 0, device=None) -> dict:
+    """The DEVICE image of rank `src`'s map to every rank ("rank 0 builds the device map image, one broadcast over xGMI"):
+    fls_map_image_export writes the flat image straight into the tensor the collective works on -- a CUDA tensor with RCCL (the bytes
+    never touch the host), pinned host memory with gloo -- and every other rank's handle takes it with fls_map_image_import and becomes
+    a read-only replica.  No host mirror, no re-flatten (round 4: ExportMap 90 ms + ImportMap 78 ms per rank for the 1e6-point map).
+    `m`: a RegistrationInterface mirror of the iVox kind on every rank.  Returns the timings of this rank."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    inited = dist.is_initialized()
+    rank = dist.get_rank() if inited else 0
+    on_dev = device is not None and str(device).startswith("cuda")
+    n = torch.tensor([m.MapImageBytes() if rank == src else 0], dtype=torch.int64, device=device)
+    if inited:
+        dist.broadcast(n, src=src)
+    nbytes = int(n.item())
+    if nbytes == 0:
+        raise RuntimeError("broadcast_map_image: rank %d has no device image to export" % src)
+    if on_dev:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    else:
+        buf = torch.empty(nbytes, dtype=torch.uint8)
+        if torch.cuda.is_available():
+            buf = buf.pin_memory()  # device <-> host copies at PCIe speed on both sides
+    t0 = time.perf_counter()
+    if rank == src:
+        m.ExportMapImage(buf.data_ptr(), nbytes, on_dev)  # (synchronous: the image is in `buf` when it returns)
+    t1 = time.perf_counter()
+    if inited:
+        dist.broadcast(buf, src=src)
+        if on_dev:
+            torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    if rank != src:
+        m.ImportMapImage(buf.data_ptr(), nbytes, on_dev)
+    t3 = time.perf_counter()
+    return {"image_MB": nbytes / 1e6, "export_ms": 1e3 * (t1 - t0), "broadcast_ms": 1e3 * (t2 - t1), "import_ms": 1e3 * (t3 - t2),
+            "buffer": "device" if on_dev else "pinned host"}
+
+
 def pack_result(T: np.ndarray, ok: bool, iterations: int, n_valid: int, sum_res: float) -> np.ndarray:
     """Job result row: 16 pose doubles (row-major 4x4) + [ok, iterations, n_valid, sum_res]."""
     return np.concatenate([np.asarray(T, dtype=np.float64).reshape(16), [float(ok), float(iterations), float(n_valid), float(sum_res)]])

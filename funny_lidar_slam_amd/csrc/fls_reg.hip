@@ -147,6 +147,21 @@ fls_status fls_match(fls_handle h, const float* s0, size_t n0, const float* s1, 
     });
 }
 
+size_t fls_map_image_bytes(fls_handle h) {
+    if (!h) return 0;
+    size_t n = 0;
+    guarded([&]() -> fls_status { FLS_HIP(hipSetDevice(h->device)); n = h->map_image_bytes(); return FLS_OK; });
+    return n;
+}
+fls_status fls_map_image_export(fls_handle h, void* dst, size_t cap_bytes, int dst_on_device) {
+    if (!h || !dst) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status { FLS_HIP(hipSetDevice(h->device)); return h->map_image_export(dst, cap_bytes, dst_on_device); });
+}
+fls_status fls_map_image_import(fls_handle h, const void* src, size_t n_bytes, int src_on_device) {
+    if (!h || !src) return FLS_ERR_INVALID;
+    return guarded([&]() -> fls_status { FLS_HIP(hipSetDevice(h->device)); return h->map_image_import(src, n_bytes, src_on_device); });
+}
+
 fls_status fls_match_batch(fls_handle h, size_t n_jobs, const float* const* src0, const size_t* n0, const float* const* src1,
                            const size_t* n1, int stride, double* T, fls_stats* stats, int32_t* status, int lanes) {
     if (!h || stride < 3 || (n_jobs && (!src0 || !n0 || !T))) return FLS_ERR_INVALID;

@@ -256,6 +256,78 @@ struct IvoxImage {
         FLS_HIP(hipStreamSynchronize(s));
     }
 
+    // ---- the image as ONE flat buffer (round 5: fls_map_image_export / _import, include/fls_reg.h): header | points | [table] | [directory | cells].
+    // What clone_for_reading copies between two handles of one process, laid out so that another PROCESS (another rank of a torch.distributed
+    // job) can take it: the buffer is a device allocation the collective broadcasts in place (RCCL) or pinned host memory (gloo).  A receiver
+    // becomes a read-only replica, exactly like a member of a replica set.
+    struct FlatHeader {
+        char magic[8];            // "FLSIMG01"
+        unsigned kind, want_hash, have_bricks, is_first, use_dense, mask, dir_mask, pad;
+        float resolution, pad_f;
+        unsigned long long used, n_pts_live, n_bricks_live, n_bricks_cap, total_bytes;
+    };
+    static size_t flat_bytes(const FlatHeader& h) {
+        size_t b = sizeof(FlatHeader) + size_t(h.used) * sizeof(float4);
+        if (h.want_hash) b += (size_t(h.mask) + 1) * sizeof(HashEntry);
+        if (h.have_bricks) b += (size_t(h.dir_mask) + 1) * sizeof(HashEntry) + size_t(h.n_bricks_live) * kBrickStride * sizeof(uint2);
+        return b;
+    }
+    FlatHeader flat_header(size_t used_slots, size_t n_bricks_live) const {
+        FlatHeader h{};
+        std::memcpy(h.magic, "FLSIMG01", 8);
+        h.want_hash = want_hash ? 1u : 0u; h.have_bricks = have_bricks ? 1u : 0u;
+        h.mask = mask; h.dir_mask = dir_mask;
+        h.used = used_slots; h.n_pts_live = n_pts_live; h.n_bricks_live = have_bricks ? n_bricks_live : 0; h.n_bricks_cap = n_bricks_cap;
+        h.total_bytes = flat_bytes(h);
+        return h;
+    }
+    // `dst` holds flat_bytes(h) bytes (device memory of THIS handle's device, or host memory); the owner's stream must be idle
+    void export_flat(const FlatHeader& h, void* dst, bool dst_on_device, hipStream_t s) const {
+        char* w = static_cast<char*>(dst);
+        const hipMemcpyKind body = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        FLS_HIP(hipMemcpyAsync(w, &h, sizeof(h), dst_on_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost, s));
+        size_t off = sizeof(h);
+        auto put = [&](const void* q, size_t bytes) { if (bytes) FLS_HIP(hipMemcpyAsync(w + off, q, bytes, body, s)); off += bytes; };
+        put(d_pts.p, size_t(h.used) * sizeof(float4));
+        if (h.want_hash) put(d_table.p, (size_t(h.mask) + 1) * sizeof(HashEntry));
+        if (h.have_bricks) { put(d_dir.p, (size_t(h.dir_mask) + 1) * sizeof(HashEntry)); put(d_cells.p, size_t(h.n_bricks_live) * kBrickStride * sizeof(uint2)); }
+        FLS_HIP(hipStreamSynchronize(s));
+    }
+    // the header is untrusted (it comes off a broadcast): every size is bounded by the payload before anything is allocated
+    static bool flat_header_ok(const FlatHeader& h, size_t n_bytes) {
+        if (std::memcmp(h.magic, "FLSIMG01", 8) != 0) return false;
+        auto pow2m1 = [](unsigned m) { return (m & (m + 1u)) == 0u; };
+        if (h.want_hash > 1u || h.have_bricks > 1u || (!h.want_hash && !h.have_bricks)) return false;
+        if (!pow2m1(h.mask) || !pow2m1(h.dir_mask)) return false;
+        const unsigned long long cap = (unsigned long long)n_bytes / 8ull;  // no array can hold more records than the payload has 8-byte words
+        if (h.used > cap || h.n_bricks_live > cap / kBrickStride + 1 || h.n_bricks_cap > (1ull << 31) || h.n_bricks_live > h.n_bricks_cap || h.n_pts_live > h.used) return false;
+        if ((unsigned long long)h.mask > cap || (unsigned long long)h.dir_mask > cap) return false;
+        return h.total_bytes == (unsigned long long)n_bytes && flat_bytes(h) == n_bytes;
+    }
+    void import_flat(const FlatHeader& h, const void* src, bool src_on_device, hipStream_t s) {
+        const char* r = static_cast<const char*>(src);
+        const hipMemcpyKind body = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        want_hash = h.want_hash != 0; have_bricks = h.have_bricks != 0;
+        used = size_t(h.used); garbage = 0; n_pts_live = size_t(h.n_pts_live);
+        table.clear(); brick_index.clear(); brick_keys.clear(); dir.clear(); dir_dirty = false; meta_cells = 0;
+        cell_upd.clear(); pt_upd.clear();
+        mask = h.mask; dir_mask = h.dir_mask; n_bricks_cap = size_t(h.n_bricks_cap);
+        size_t off = sizeof(h);
+        auto get = [&](void* d, size_t bytes) { if (bytes) FLS_HIP(hipMemcpyAsync(d, r + off, bytes, body, s)); off += bytes; };
+        d_pts.reserve(std::max<size_t>(used, 1));
+        get(d_pts.p, used * sizeof(float4));
+        if (want_hash) { d_table.reserve(size_t(mask) + 1); get(d_table.p, (size_t(mask) + 1) * sizeof(HashEntry)); }
+        if (have_bricks) {
+            d_dir.reserve(size_t(dir_mask) + 1);
+            get(d_dir.p, (size_t(dir_mask) + 1) * sizeof(HashEntry));
+            const size_t nb = size_t(h.n_bricks_live);
+            d_cells.reserve(std::max<size_t>(nb, 1) * kBrickStride);
+            if (nb == 0) FLS_HIP(hipMemsetAsync(d_cells.p, 0, kBrickStride * sizeof(uint2), s));
+            get(d_cells.p, nb * kBrickStride * sizeof(uint2));
+        }
+        FLS_HIP(hipStreamSynchronize(s));
+    }
+
     // cell_upd (and pt_upd) -> the device image
     void scatter_cell_records(hipStream_t s, PinnedBuf<char>& stage) {
         const size_t np = pt_upd.size(), nc = cell_upd.size();

@@ -573,6 +573,29 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
 struct PtUpdDev { unsigned slot; float x, y, z; int id; };
 struct CellUpdDev { unsigned long long idx; unsigned begin, count; };
 
+// An image that arrived from another process (fls_map_image_import): every {begin, count} must stay inside the point array and every
+// directory entry must name a brick the image holds, or a query kernel would read out of bounds.  bad = number of offending entries.
+__global__ void __launch_bounds__(256)
+ivox_image_validate_kernel(const uint2* __restrict__ cells, const unsigned long long n_cells, const HashEntry* __restrict__ dir, const unsigned long long n_dir,
+                           const unsigned n_bricks_live, const HashEntry* __restrict__ table, const unsigned long long n_table, const unsigned long long used,
+                           unsigned* __restrict__ bad) {
+    unsigned b = 0u;
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n_cells; i += stride) {
+        const uint2 c = cells[i];
+        b += ((unsigned long long)c.x + (unsigned long long)c.y > used) ? 1u : 0u;
+    }
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n_dir; i += stride) {
+        const HashEntry e = dir[i];
+        b += (e.key != kEmptyKey && e.begin >= n_bricks_live) ? 1u : 0u;
+    }
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n_table; i += stride) {
+        const HashEntry e = table[i];
+        b += (e.key != kEmptyKey && (unsigned long long)e.begin + (unsigned long long)e.count > used) ? 1u : 0u;
+    }
+    if (b) atomicAdd(bad, b);
+}
+
 __global__ void __launch_bounds__(256)
 ivox_apply_updates_kernel(const PtUpdDev* __restrict__ pu, const int npu, const CellUpdDev* __restrict__ cu, const int ncu,
                           float4* __restrict__ pts, uint2* __restrict__ cells) {

@@ -69,6 +69,10 @@ struct fls_matcher {
     virtual size_t map_size(int slot) const = 0;
     virtual size_t map_export(void*, size_t) { return 0; }                       // 0: this kind has no exportable image
     virtual fls_status map_import(const void*, size_t) { return FLS_ERR_STATE; }
+    // the DEVICE image as one flat buffer (fls_map_image_*): 0 / FLS_ERR_STATE: this kind has none
+    virtual size_t map_image_bytes() { return 0; }
+    virtual fls_status map_image_export(void*, size_t, int /*buffer on this handle's device*/) { return FLS_ERR_STATE; }
+    virtual fls_status map_image_import(const void*, size_t, int) { return FLS_ERR_STATE; }
     // fls_replicas_*: this handle becomes a READ-ONLY copy of `owner`'s device map image (device to device, no host mirror): it serves
     // fls_match_batch and nothing else until a map_import / a cleared map makes it an ordinary handle again
     virtual bool can_replicate() const { return false; }

@@ -791,6 +791,60 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         return FLS_OK;
     }
 
+    // ---- the device image as one flat buffer, for replicas in OTHER processes (torch.distributed ranks): fls_map_image_bytes / _export / _import.
+    // The exporter keeps its map; the importer becomes a read-only replica (fls_match / fls_match_batch with update_map == 0), like a
+    // member of a replica set.  No host mirror, no re-flatten: 44 MB for the 1e6-point map, copied at memory speed on either side.
+    size_t map_image_bytes() override {
+        if (borrowed || replica_only) return 0;
+        if (prepare_batch() != FLS_OK) return 0;
+        size_t nb = 0;
+        const size_t used_now = live_counts(nb);
+        return size_t(image.flat_header(used_now, nb).total_bytes);
+    }
+    fls_status map_image_export(void* dst, size_t cap, int on_device) override {
+        if (borrowed || replica_only || !dst) return FLS_ERR_STATE;
+        const fls_status prc = prepare_batch();  // image current, the stream idle
+        if (prc != FLS_OK) return prc;
+        size_t nb = 0;
+        const size_t used_now = live_counts(nb);
+        IvoxImage::FlatHeader h = image.flat_header(used_now, nb);
+        h.kind = unsigned(kind); h.is_first = is_first ? 1u : 0u; h.use_dense = use_dense ? 1u : 0u; h.resolution = ivox.resolution;
+        if (cap < size_t(h.total_bytes)) return FLS_ERR_RANGE;
+        image.export_flat(h, dst, on_device != 0, stream);
+        return FLS_OK;
+    }
+    fls_status map_image_import(const void* src, size_t n, int on_device) override {
+        if (borrowed || !src || n < sizeof(IvoxImage::FlatHeader)) return FLS_ERR_INVALID;
+        IvoxImage::FlatHeader h;
+        FLS_HIP(hipMemcpy(&h, src, sizeof(h), on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+        if (!IvoxImage::flat_header_ok(h, n) || h.kind != unsigned(kind)) return FLS_ERR_INVALID;
+        if (!(h.resolution > 0.f) || h.resolution != ivox.resolution) return FLS_ERR_INVALID;
+        FLS_HIP(hipStreamSynchronize(stream));
+        device_map = false;
+        replica_only = false;
+        ivox.clear();
+        image_built = false; image_dirty = true;  // (an import that fails half-way leaves an empty map that rebuilds its image)
+        use_dense = h.use_dense != 0;
+        image.import_flat(h, src, on_device != 0, stream);
+        // the contents are as untrusted as the header: no {begin, count} may leave the point array, no directory entry may name a missing brick
+        d_counter_img.reserve(1);
+        FLS_HIP(hipMemsetAsync(d_counter_img.p, 0, sizeof(unsigned), stream));
+        const unsigned long long n_cells = image.have_bricks ? (unsigned long long)h.n_bricks_live * kBrickStride : 0ull;
+        hipLaunchKernelGGL(ivox_image_validate_kernel, dim3(512), dim3(256), 0, stream, (const uint2*)image.d_cells.p, n_cells, (const HashEntry*)image.d_dir.p,
+                           image.have_bricks ? (unsigned long long)h.dir_mask + 1ull : 0ull, unsigned(h.n_bricks_live), (const HashEntry*)image.d_table.p,
+                           image.want_hash ? (unsigned long long)h.mask + 1ull : 0ull, (unsigned long long)h.used, d_counter_img.p);
+        unsigned bad = 0;
+        FLS_HIP(hipMemcpyAsync(&bad, d_counter_img.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        FLS_HIP(hipStreamSynchronize(stream));
+        if (bad != 0u) return FLS_ERR_INVALID;  // (the handle is an empty map whose image is rebuilt from the empty mirror on its next use)
+        is_first = h.is_first != 0;
+        replica_only = true;
+        image_built = true; image_dirty = false; rebuild_after_replay = false;
+        nn_n = 0; have_final = false; nn_rows_current = true; spec_pending = false;
+        return FLS_OK;
+    }
+    DevBuf<unsigned> d_counter_img;
+
     std::unique_ptr<fls_matcher> clone_for_lane() override {
         auto q = std::make_unique<P2PlaneIvoxMatcher>();
         q->kind = kind; q->p = p; q->device = device;

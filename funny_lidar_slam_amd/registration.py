@@ -229,6 +229,22 @@ class RegistrationInterface:
         if rc != _lib.FLS_OK:
             raise FlsError(rc, "fls_map_import")
 
+    def MapImageBytes(self) -> int:
+        """fls_map_image_bytes: size of the flat DEVICE image (0: this kind has none)."""
+        return int(_lib.lib().fls_map_image_bytes(self._h))
+
+    def ExportMapImage(self, ptr: int, nbytes: int, on_device: bool) -> None:
+        """fls_map_image_export into caller memory (`ptr`: device memory of this handle's device, or host memory)."""
+        rc = _lib.lib().fls_map_image_export(self._h, C.c_void_p(ptr), nbytes, 1 if on_device else 0)
+        if rc != _lib.FLS_OK:
+            raise FlsError(rc, "fls_map_image_export")
+
+    def ImportMapImage(self, ptr: int, nbytes: int, on_device: bool) -> None:
+        """fls_map_image_import: this handle becomes a read-only replica of the exporter's map."""
+        rc = _lib.lib().fls_map_image_import(self._h, C.c_void_p(ptr), nbytes, 1 if on_device else 0)
+        if rc != _lib.FLS_OK:
+            raise FlsError(rc, "fls_map_image_import")
+
     def map_size(self, slot: int = 0) -> int:
         return int(_lib.lib().fls_map_size(self._h, slot))
 

@@ -37,9 +37,9 @@ extern "C" {
 #define FLS_ABI_VERSION 1
 /* Additive revision of ABI version 1: entry points are only ever ADDED under one FLS_ABI_VERSION (existing signatures, struct layouts and
  * status codes do not change), and this number counts the additions -- 1: fls_match_batch, map export / import; 2: fls_voxel_grid_cloud,
- * fls_features_*; 3: fls_replicas_*, fls_loop_match; 4: fls_debug_exact_sort; 5: fls_scan_upload_raw.  A caller built against revision r works with any library
+ * fls_features_*; 3: fls_replicas_*, fls_loop_match; 4: fls_debug_exact_sort; 5: fls_scan_upload_raw; 6: fls_map_image_*.  A caller built against revision r works with any library
  * whose fls_abi_revision() >= r. */
-#define FLS_ABI_REVISION 5
+#define FLS_ABI_REVISION 6
 
 /* Which reference class the handle replaces (mode strings: include/common/constant_variable.h:21-25). */
 typedef enum fls_kind {
@@ -157,6 +157,15 @@ fls_status fls_match_batch(fls_handle h, size_t n_jobs, const float* const* src0
  * (other kinds: export returns 0, import FLS_ERR_STATE).  fls_map_export(h, NULL, 0) returns the size needed.            */
 size_t fls_map_export(fls_handle h, void* blob, size_t cap_bytes);
 fls_status fls_map_import(fls_handle h, const void* blob, size_t n_bytes);
+/* The DEVICE image itself as one flat buffer (revision 6): what a torch.distributed rank broadcasts to the others in place of the blob above
+ * ("rank 0 builds the device map image, one broadcast over xGMI").  `dst` / `src` is memory of the handle's own device when
+ * *_on_device != 0 -- e.g. the data_ptr of the CUDA tensor an RCCL broadcast works on -- or host memory (pinned for speed; gloo).  The exporter
+ * keeps its map.  The importer becomes a READ-ONLY REPLICA, like a member of fls_replicas_*: fls_match / fls_match_batch with update_map == 0;
+ * fls_map_import or a replica refresh makes it an ordinary handle again.  Header and contents are validated on import (sizes against n_bytes,
+ * every cell inside the point array): FLS_ERR_INVALID otherwise.  Only the iVox kind has such an image (others: 0 / FLS_ERR_STATE). */
+size_t fls_map_image_bytes(fls_handle h);
+fls_status fls_map_image_export(fls_handle h, void* dst, size_t cap_bytes, int dst_on_device);
+fls_status fls_map_image_import(fls_handle h, const void* src, size_t n_bytes, int src_on_device);
 
 /* ---- one process, several GPUs ("one process + N host threads"; BASELINE configs[4]) ---------------------------
  * A replica set = one handle per entry of device_ids, each holding a READ-ONLY copy of the owner's device map image, copied device
