@@ -275,6 +275,18 @@ def bench_other_configs(reg, synth, util, O, budget_s=6.0):
                 bytes_iter = algorithmic_bytes(q.shape[0] + qc.shape[0], pr + pr2, hi + hi2, ca + ca2)
         avg_launch_s = (ms / 1e3) / max(nl, 1)
         ach = bytes_iter / avg_launch_s / 1e9 if nl else 0.0
+        # HBM bytes per launch and what limits the kernel, from the committed PMC passes of this kind's correspondence kernel
+        # (tools/prof_round5.sh kinds -> tools/make_kernel_traffic_json.py -> profiles/traffic_<kernel>.json; rocprofv3 cannot collect counters from inside this process)
+        traffic, tdetail = None, None
+        try:
+            tname = {"IncrementalNDT": "ndt_lanes", "IcpOptimized": "icp_knn_fit", "LoamFull_KdTree": "grid_knn_dual"}[mode]
+            with open(os.path.join(ROOT, "profiles", "traffic_%s.json" % tname)) as f:
+                tj = json.load(f)
+            traffic = tj.get("hbm_bytes_per_launch")
+            tdetail = {k: tj[k] for k in ("kernel", "trace_avg_launch_us", "measured_hbm_GBs", "l2_hit_rate", "valu_busy_pct", "wave_wait_pct", "waves_per_launch") if k in tj}
+            tdetail["source"] = "profiles/traffic_%s.json" % tname
+        except (OSError, KeyError, ValueError):
+            pass
         t_whole = float(np.median(ts_raw)) if filters_inside else float(np.median(ts))
         out[f"configs[{cid}]"] = {
             "workload": name, "scans_per_s": 1.0 / t_whole, "match_us": 1e6 * t_whole,
@@ -284,7 +296,7 @@ def bench_other_configs(reg, synth, util, O, budget_s=6.0):
             "gn_iterations": iters,
             "converged": bool(m.stats.converged), "source_points": n_pts, "pose_err_vs_oracle_m_rad": [dt, dr],
             "match_from_host_buffers_us": from_host,
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "detail": tdetail,
                          "algorithmic_bytes_per_iteration": bytes_iter, "correspondence_launch_us": 1e6 * avg_launch_s,
                          "note": "8d formula; kd-tree kinds: counters of the survey's 27-cell grid (cell = sqrt(gate)) at the final pose, the bracket covers one "
                                  "iteration's correspondence launch(es)"},

@@ -392,11 +392,14 @@ __global__ void __launch_bounds__(kSolveThreads)
 gn_solve_loam_kernel(GnState* __restrict__ st, const int first, const Pose16 T0, const double* __restrict__ partials_a,
                      const int nrows_a, const double* __restrict__ partials_b, const int nrows_b, const double rot_thr,
                      const double pos_thr, Mailbox* __restrict__ mb, const unsigned match_id) {
-    // every state word the tail needs is loaded up front (latency overlaps the partial reduction)
+    // every state word the tail needs is loaded up front (latency overlaps the partial reduction); the pose waits in LDS, not in 32 registers of
+    // every lane: at 1,024 threads the kernel has 128 VGPRs and spilled 17 words to scratch with the pose live across the solve
     const int done = first ? 0 : st->done;
-    double Tl[16];
+    __shared__ double Tl[16];
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) Tl[q] = first ? T0.m[q] : st->T[q];
+        for (int q = 0; q < 16; ++q) Tl[q] = first ? T0.m[q] : st->T[q];
+    }
     const double last_rot = first ? 0.0 : st->last_rot, last_pos = first ? 0.0 : st->last_pos;
     const int it = first ? 0 : st->iter;
     if (done) return;

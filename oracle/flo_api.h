@@ -89,6 +89,10 @@ int flo_get_iteration_log(void* h, double* T_iters /*cap x 16*/, int32_t* n_vali
  * slot: 0 planar/ordered, 1 corner.  ids: n x K int32 (K=5, or 1 for ICP, 7 voxel ids for NDT). */
 int flo_get_correspondences(void* h, int slot, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap_points);
 int flo_get_counters(void* h, flo_counters* out);
+/* per query of the last Match: 1 = its current neighbour list came out of a search with an exact distance tie (order / membership decided by
+ * libstdc++'s introselect); returns the number of queries (0: this kind keeps no tie flags).  The GPU parity tests require every row that
+ * differs from the oracle's to carry this flag. */
+size_t flo_get_tie_flags(void* h, uint8_t* out, size_t cap);
 /* 0: the kNN stage skips its traffic / tie bookkeeping (an extra vector + sort per query): what cpu_baseline times */
 void flo_set_instrumentation(void* h, int on);
 /* last Match's per-iteration H (36, col-major) and g (6) for reduction-tolerance tests */

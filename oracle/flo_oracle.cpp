@@ -47,6 +47,10 @@ struct MatcherBase {
     std::vector<IterLog> log;
     double last_H[36]{}, last_g[6]{};
     bool instrument = true;  // traffic / tie counters of the kNN stage (flo_set_instrumentation: off for timing runs)
+    // per query: the neighbour list it holds now was written by a search that met an exact distance tie (nearest two, or across the K / K + 1
+    // boundary) -- the rows whose slot order / membership libstdc++'s introselect decides.  Sticky like the list itself (Q15).  Kinds
+    // without tie instrumentation leave it empty.
+    std::vector<uint8_t> tie_flag;
     virtual ~MatcherBase() = default;
     virtual int AddCloud(const Cloud& c0, const Cloud& c1) = 0;
     virtual bool Match(const Cloud& s0, const Cloud& s1, double* T, bool update_map) = 0;
@@ -237,6 +241,7 @@ struct P2PlaneIvox final : MatcherBase {
 
     void PlanerMatch(const Cloud& source) {  // :256-324
         nearest_points.resize(number_planar_point);
+        tie_flag.resize(number_planar_point, 0);
         const long n = long(number_planar_point);
         uint64_t probes = 0, hits = 0, cand = 0, ties = 0;
 #pragma omp parallel for schedule(static) reduction(+ : probes, hits, cand, ties)
@@ -245,8 +250,9 @@ struct P2PlaneIvox final : MatcherBase {
             const P4 tp = transform_point_d(sp, T_);
             std::vector<Near>& pv = nearest_points[size_t(i)];
             KnnCounters kc;
-            ivox->GetClosestPoint(tp, pv, instrument ? &kc : nullptr, 5);
+            const bool rewritten = ivox->GetClosestPoint(tp, pv, instrument ? &kc : nullptr, 5);
             probes += kc.probes; hits += kc.hits; cand += kc.cand; ties += kc.ties;
+            if (instrument && rewritten) tie_flag[size_t(i)] = kc.ties ? 1 : 0;
             if (pv.size() < 5) continue;
             P4 nn[5];
             for (int j = 0; j < 5; ++j) nn[j] = pv[size_t(j)].pt;
@@ -1032,6 +1038,12 @@ int flo_get_correspondences(void* h, int slot, int32_t* ids, uint8_t* cnt, uint8
     return static_cast<MatcherBase*>(h)->GetCorr(slot, ids, cnt, valid, cap);
 }
 int flo_get_counters(void* h, flo_counters* out) { *out = static_cast<MatcherBase*>(h)->counters; return 0; }
+size_t flo_get_tie_flags(void* h, uint8_t* out, size_t cap) {
+    const std::vector<uint8_t>& f = static_cast<MatcherBase*>(h)->tie_flag;
+    const size_t n = std::min(cap, f.size());
+    if (out && n) std::memcpy(out, f.data(), n);
+    return f.size();
+}
 int flo_get_last_system(void* h, double* H36, double* g6) {
     auto* m = static_cast<MatcherBase*>(h);
     std::memcpy(H36, m->last_H, sizeof(m->last_H));

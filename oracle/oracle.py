@@ -169,6 +169,8 @@ def lib():
         L.flo_get_iteration_log.argtypes = [C.c_void_p, dp, ip, dp, C.c_int]
         L.flo_get_correspondences.argtypes = [C.c_void_p, C.c_int, ip, bp, bp, C.c_size_t]
         L.flo_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.flo_get_tie_flags.restype = C.c_size_t
+        L.flo_get_tie_flags.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
         L.flo_set_instrumentation.restype = None
         L.flo_set_instrumentation.argtypes = [C.c_void_p, C.c_int]
         L.flo_get_last_system.argtypes = [C.c_void_p, dp, dp]
@@ -310,6 +312,15 @@ class OracleMatcher:
     def set_instrumentation(self, on: bool) -> None:
         """False: no traffic / tie counters in the kNN stage (timing runs: cpu_baseline)."""
         lib().flo_set_instrumentation(self._h, 1 if on else 0)
+
+    def tie_rows(self):
+        """bool per query of the last Match: the row's neighbour list was decided by an exact distance tie (None: no tie flags for this kind)."""
+        n = lib().flo_get_tie_flags(self._h, None, 0)
+        if n == 0:
+            return None
+        out = np.zeros(n, np.uint8)
+        lib().flo_get_tie_flags(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), n)
+        return out.astype(bool)
 
     def counters(self) -> Counters:
         c = Counters()
