@@ -864,6 +864,25 @@ def main():
         }
         if detail:
             line["roofline"]["detail"] = detail
+        # the OTHER kernel of an iteration: per-point plane fit + Jacobian + the 29 normal-equation sums + the Gauss-Newton tail in the last
+        # workgroup.  Not a streaming kernel: ~600 FP64 flop and 112 B of gathered rows per point, then a serial fan-in + one-wave tail.
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic_p2plane_fit_solve.json")) as f:
+                fj = json.load(f)
+            n_pts = int(cfg["scan"].shape[0])
+            fit_bytes = n_pts * (12 + 32 + 5 * 16 + 7 * 8 + 1)  # xyz + id row + five gathered map points + J s | |d| row (Q1 state) + flag, per point
+            fit_flop = n_pts * 600
+            lus = float(fj["trace_avg_launch_us"])
+            line["roofline_fit_kernel"] = {
+                "kernel": "p2plane_fit_solve_kernel", "avg_launch_us": lus, "launch_geometry": "225 workgroups x 512 threads = 1.76 waves / SIMD, 112 VGPRs",
+                "algorithmic_bytes_per_launch": fit_bytes, "achieved_GBs_by_algorithmic_bytes": fit_bytes / (lus * 1e-6) / 1e9, "frac_of_hbm_peak": fit_bytes / (lus * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "fp64_flop_per_launch": fit_flop, "achieved_fp64_TFLOPs": fit_flop / (lus * 1e-6) / 1e12,
+                "traffic": fj.get("hbm_bytes_per_launch"), "measured_hbm_GBs": fj.get("measured_hbm_GBs"), "valu_busy_pct": fj.get("valu_busy_pct"),
+                "wave_wait_pct": fj.get("wave_wait_pct"), "l2_hit_rate": fj.get("l2_hit_rate"),
+                "bound": "latency: ~8 us of parallel per-point work, then the fan-in of 225 partial rows and a single-wave Gauss-Newton tail (serial)",
+                "source": "profiles/traffic_p2plane_fit_solve.json (tools/prof_round5.sh kinds: kernel trace + four PMC passes)"}
+        except (OSError, KeyError, ValueError):
+            pass
         if c5 is not None:
             line["c5_batch"] = c5
         if c5n is not None:

@@ -393,7 +393,10 @@ struct DeviceVoxelGrid {
         if (!vseq) vseq = 1u;
         const float inv = 1.0f / leaf;
         // (the reference sorts the FINITE points only: a cloud with a non-finite point is the host's, refuse_bad = 1)
-        hipLaunchKernelGGL(vg_minmax_plan, dim3(unsigned(std::min(nb1, 48))), dim3(kVgBlock), 0, s, x, y, z, ni, inv, 1, d_acc.p, d_plan.p, es);
+        // (blocks: 48 in rounds 2-4 -- "few blocks: six header atomics each" -- left a 115,200-point scan to 12 k threads, 11-12 us in the trace
+        // of the call; 160 blocks = three points per thread and < 1,000 atomics: FLS_VG_MINMAX_BLOCKS for A/B)
+        static const int mm_blocks = [] { const char* e = std::getenv("FLS_VG_MINMAX_BLOCKS"); return e ? std::max(1, std::atoi(e)) : 160; }();
+        hipLaunchKernelGGL(vg_minmax_plan, dim3(unsigned(std::min(nb1, mm_blocks))), dim3(kVgBlock), 0, s, x, y, z, ni, inv, 1, d_acc.p, d_plan.p, es);
         hipLaunchKernelGGL(vg_index_plan, dim3(unsigned(nb1)), dim3(kVgBlock), 0, s, x, y, z, ni, (const VgPlan*)d_plan.p, sort.k0, sort.v0);
         exact.fused_launch(sort.k0, sort.v0, n, &d_plan.p->status, s);
         hipLaunchKernelGGL(vg_heads_plan, dim3(unsigned(nb2)), dim3(kVgScanBlock), 0, s, (const unsigned*)sort.k0, (const unsigned*)sort.v0, ni, (const VgPlan*)d_plan.p,
