@@ -9,6 +9,7 @@
 #include "kernels_voxelgrid_plan.hpp"
 #include "kernels_gridbuild.hpp"
 #include "matcher_base.hpp"
+#include <atomic>
 #include <cstdlib>
 #include <climits>
 
@@ -57,7 +58,9 @@ struct DevicePairSort {
 // (every source scan) are ONE begin launch + ONE persistent task launch; beyond that the host steers the level-synchronous top of the
 // recursion: it enqueues the expected number of levels, polls a host-mapped word (no stream synchronisation) and tops up two levels
 // at a time while ranges longer than kEsTaskMax remain.
-inline EsMailbox*& es_debug_mailbox() { static EsMailbox* p = nullptr; return p; }  // the last sort's host-mapped words (diagnostics)
+// the host-mapped words of the last sort started with FLS_ES_DEBUG set (diagnostics: fls_debug_exact_sort_marks reads them from another host thread
+// while a sort is in flight, so the pointer is atomic and published only in debug runs; the owner withdraws it before freeing the memory)
+inline std::atomic<EsMailbox*>& es_debug_mailbox() { static std::atomic<EsMailbox*> p{nullptr}; return p; }
 struct DeviceExactSort {
     DevBuf<EsSeg> seg_a, seg_b;
     DevBuf<EsWork> work;
@@ -72,7 +75,11 @@ struct DeviceExactSort {
     EsMailbox* mb_dev = nullptr;
     unsigned seq = 0;
     unsigned long long runs = 0, failures = 0, levels = 0;
-    ~DeviceExactSort() { if (es_debug_mailbox() == mb_host) es_debug_mailbox() = nullptr; if (mb_host) (void)hipHostFree(mb_host); }
+    ~DeviceExactSort() {
+        EsMailbox* mine = mb_host;
+        es_debug_mailbox().compare_exchange_strong(mine, nullptr);
+        if (mb_host) (void)hipHostFree(mb_host);
+    }
     unsigned wait(const unsigned want, hipStream_t s) {
         for (unsigned long long spin = 1;; ++spin) {
             if (__atomic_load_n(&mb_host->seq, __ATOMIC_ACQUIRE) == want) return want;
@@ -93,7 +100,8 @@ struct DeviceExactSort {
             std::memset(mb_host, 0, sizeof(EsMailbox));
             FLS_HIP(hipHostGetDevicePointer((void**)&mb_dev, mb_host, 0));
         }
-        es_debug_mailbox() = mb_host;
+        static const bool publish_dbg = std::getenv("FLS_ES_DEBUG") != nullptr;
+        if (publish_dbg) es_debug_mailbox().store(mb_host, std::memory_order_release);
         work_cap = unsigned(64 * (n / kEsLds + 1) + 1024);
         tile_cap = unsigned(n / kEsTile + kEsMaxSeg + 2);
         seg_a.reserve(kEsMaxSeg); seg_b.reserve(kEsMaxSeg);

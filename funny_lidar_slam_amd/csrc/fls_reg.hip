@@ -339,13 +339,14 @@ fls_status fls_debug_voxel_grid(int device_id, const float* pts, size_t n, int s
 
 fls_status fls_debug_exact_sort(int device_id, uint32_t* key, uint32_t* val, size_t n, int on_host) {
     if ((!key || !val) && n) return FLS_ERR_INVALID;
-    if (on_host) {
-        std::vector<VoxelLeafRec> r(n);
-        for (size_t i = 0; i < n; ++i) r[i] = VoxelLeafRec{key[i], val[i]};
-        std::sort(r.begin(), r.end());  // operator< compares idx only: libstdc++'s introsort decides the order of equal keys
-        for (size_t i = 0; i < n; ++i) { key[i] = r[i].idx; val[i] = r[i].pt; }
-        return FLS_OK;
-    }
+    if (on_host)
+        return guarded([&]() -> fls_status {  // (an allocation failure must not cross the C ABI: ADVICE r4)
+            std::vector<VoxelLeafRec> r(n);
+            for (size_t i = 0; i < n; ++i) r[i] = VoxelLeafRec{key[i], val[i]};
+            std::sort(r.begin(), r.end());  // operator< compares idx only: libstdc++'s introsort decides the order of equal keys
+            for (size_t i = 0; i < n; ++i) { key[i] = r[i].idx; val[i] = r[i].pt; }
+            return FLS_OK;
+        });
     return guarded([&]() -> fls_status {
         FLS_HIP(hipSetDevice(device_id));
         if (n == 0) return FLS_OK;
@@ -363,8 +364,9 @@ fls_status fls_debug_exact_sort(int device_id, uint32_t* key, uint32_t* val, siz
     });
 }
 
-extern "C" int fls_debug_exact_sort_marks(unsigned* out, int n) {  // diagnostics only (not in the header): progress counters of the sort in flight
-    EsMailbox* m = es_debug_mailbox();
+extern "C" int fls_debug_exact_sort_marks(unsigned* out, int n) {  // diagnostics only (declared in fls_reg.h): progress stamps of the sort in flight
+    if (!out || n <= 0) return -1;
+    EsMailbox* m = es_debug_mailbox().load(std::memory_order_acquire);
     if (!m) return -1;
     for (int i = 0; i < n && i < 12; ++i) out[i] = __atomic_load_n(&m->mark[i], __ATOMIC_RELAXED);
     return 0;

@@ -134,6 +134,14 @@ struct IvoxImage {
         dir_dirty = false;
     }
 
+    // what one brick of the pool costs: cells 8 B + the per-cell side arrays of the device AddPoints (cap 1 + stamp 8 + pend 4 + rank 4) per
+    // slab cell, the reverse key and the neighbour-index row
+    static constexpr size_t kPoolBrickBytes = size_t(kBrickStride) * (8 + 1 + 8 + 4 + 4) + 8 + 32 * 4;
+    bool budget_exceeded = false;  // sticky: the owner switches to the hash-table form (P2PlaneIvoxMatcher::refresh_image)
+    static size_t brick_budget_bytes() {
+        static const size_t v = [] { const char* e = std::getenv("FLS_IVOX_BRICK_BUDGET_MB"); return size_t(e ? std::max(1L, std::atol(e)) : 16384L) << 20; }();
+        return v;
+    }
     // ---- full build from the host mirror ----
     void build_from_ivox(HostIvox& m, hipStream_t s, PinnedBuf<char>& stage) {
         // voxels in brick order (z, y, x), inside a brick in (z, y, x): spatially adjacent voxels get adjacent point buckets
@@ -153,21 +161,32 @@ struct IvoxImage {
             return std::make_tuple(a.z >> kBrickLog, a.y >> kBrickLog, a.x >> kBrickLog, a.z, a.y, a.x);
         };
         std::sort(refs.begin(), refs.end(), [&](const Ref& a, const Ref& b) { return order_key(a) < order_key(b); });
-        have_bricks = !want_hash;
         std::vector<Pt4> pts;
         pts.reserve(slots);
-        if (want_hash) {
-            const unsigned ts = table_size_for(m.n_alive);
-            mask = ts - 1;
-            table.assign(ts, HashEntry{kEmptyKey, 0u, 0u});
-        } else {
+        if (!want_hash) {
             table.clear();
             mask = 0;
             // bricks: first the voxels' own (in sorted order), then the neighbours that only hold halo copies
             brick_index.clear();
             brick_keys.clear();
-            size_t cap_guess = n_bricks_cap ? n_bricks_cap : 8192;
+            // first pool: sized from the mirror (own bricks of the voxels, x3 for the halo-only neighbours and growth), not a fixed 8,192
+            // bricks = 200 MB for an empty map
+            size_t own = 0;
+            for (size_t i = 0; i < refs.size(); ++i)
+                if (i == 0 || (refs[i].x >> kBrickLog) != (refs[i - 1].x >> kBrickLog) || (refs[i].y >> kBrickLog) != (refs[i - 1].y >> kBrickLog) ||
+                    (refs[i].z >> kBrickLog) != (refs[i - 1].z >> kBrickLog)) ++own;
+            size_t cap_guess = std::max<size_t>(n_bricks_cap, 256);
+            while (cap_guess < 3 * own) cap_guess *= 2;
             for (;;) {  // (size the pool before inserting: get_brick refuses beyond the capacity)
+                if (cap_guess * kPoolBrickBytes > brick_budget_bytes()) {
+                    // A spatially sparse map at the reference's 1e6-voxel capacity would need a brick per voxel (~25 KB each): beyond the
+                    // budget the image takes the per-voxel hash table (host-maintained AddPoints) instead of failing an allocation
+                    want_hash = true;
+                    budget_exceeded = true;
+                    n_bricks_cap = 0;
+                    dir.clear(); brick_index.clear(); brick_keys.clear();
+                    break;
+                }
                 n_bricks_cap = cap_guess;
                 size_t ds = 4096;
                 while (ds < 4 * n_bricks_cap) ds <<= 1;
@@ -184,6 +203,12 @@ struct IvoxImage {
                 if (ok && 2 * brick_keys.size() <= n_bricks_cap) break;  // room for as many bricks again before the next rebuild
                 cap_guess = std::max(cap_guess * 2, 2 * brick_keys.size());
             }
+        }
+        have_bricks = !want_hash;
+        if (want_hash) {
+            const unsigned ts = table_size_for(m.n_alive);
+            mask = ts - 1;
+            table.assign(ts, HashEntry{kEmptyKey, 0u, 0u});
         }
         cell_upd.clear();
         pt_upd.clear();

@@ -106,13 +106,18 @@ __device__ __forceinline__ unsigned brick_find_or_create(const IvoxUpdArrays& a,
     {   // fast path: the entry is there and published (one plain 16-byte load; entries are write-once, so a stale line can only look
         // emptier than the truth and sends us to the careful loop below)
         const HashEntry e = a.dir[h];
-        if (e.key == key && e.begin < a.n_bricks_cap) return e.begin;
+        if (e.key == key && e.begin < a.n_bricks_cap) return e.begin;  // (an invalid index falls through to the careful loop, which raises kUpdArrayFull)
     }
     for (unsigned tries = 0; tries < 65536u; ++tries) {
         const unsigned long long k = __hip_atomic_load(&a.dir[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k == key) {
             const unsigned idx = __hip_atomic_load(&a.dir[h].begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (idx != kBrickPending) return idx;
+            if (idx != kBrickPending) {
+                // an index beyond the pool (kBrickInvalid, published by the claimant of a full pool) must never coexist with an OK verdict,
+                // whoever reads it and in whichever batch (today the host rebuilds the directory before the next batch anyway)
+                if (idx >= a.n_bricks_cap) atomicOr(&st->status, kUpdArrayFull);
+                return idx;
+            }
             continue;  // claimed by another thread, index not yet published
         }
         if (k == kEmptyKey) {

@@ -74,7 +74,7 @@ struct fls_matcher {
     virtual fls_status map_image_export(void*, size_t, int /*buffer on this handle's device*/) { return FLS_ERR_STATE; }
     virtual fls_status map_image_import(const void*, size_t, int) { return FLS_ERR_STATE; }
     // fls_replicas_*: this handle becomes a READ-ONLY copy of `owner`'s device map image (device to device, no host mirror): it serves
-    // fls_match_batch and nothing else until a map_import / a cleared map makes it an ordinary handle again
+    // fls_match_batch (and fls_match with update_map == 0) and nothing else until fls_map_import makes it an ordinary handle again (fls_add_cloud_to_local_map is refused: FLS_ERR_STATE)
     virtual bool can_replicate() const { return false; }
     virtual fls_status replicate_from(fls_matcher&) { return FLS_ERR_STATE; }
     // state a FRESH reference matcher would not have (e.g. nearest_points_ of an earlier Match): cleared per batch job

@@ -149,6 +149,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             ++n_incremental;
         } else {
             image.build_from_ivox(ivox, stream, upd_stage);
+            if (image.budget_exceeded) use_dense = false;  // brick pool over its byte budget: per-voxel hash table from now on (map_size(132))
             image_built = true;
             ++n_full_rebuilds;
         }
@@ -895,6 +896,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         if (slot == 117) return n_device_evictions;  //              voxels evicted inside device batches
         if (slot == 126) return n_device_recreated;  //              ... of which re-created by a later point of the same batch (eviction-order conflicts resolved on the device)
         if (slot == 119) return n_refused_conflict;  //              refusals by reason: eviction order conflict / point array full / point outside the window
+        if (slot == 132) return image.budget_exceeded ? 1u : 0u;  // the brick pool went over FLS_IVOX_BRICK_BUDGET_MB: hash-table image, host AddPoints
         if (slot == 120) return n_refused_full;
         if (slot == 121) return n_refused_outside;
         if (slot == 102) return device_map ? dev_n_alive : ivox.n_alive;     // occupied voxels

@@ -195,9 +195,14 @@ void fls_replicas_destroy(fls_replicas_handle r);
  * is too small -> FLS_ERR_INVALID).
  *   FLS_VOXELGRID_EXACT   the reference's arithmetic bit for bit (leaf sums in libstdc++'s std::sort order) on the host worker pool;
  *                         needs no device.  PCL's "leaf size too small" case copies the input, as PCL does.
- *   FLS_VOXELGRID_DEVICE  on the GPU: leaves, order and integers exact, a leaf's float sum in ascending point index (contract:
- *                         csrc/kernels_voxelgrid.hpp).  FLS_ERR_STATE when the device path declines (empty / no finite point /
- *                         the "leaf size too small" case / n > 4,194,304): call again with FLS_VOXELGRID_EXACT.            */
+ *   FLS_VOXELGRID_DEVICE  on the GPU, the same bits (since round 4: the device sort reproduces libstdc++'s std::sort permutation,
+ *                         csrc/kernels_exactsort.hpp; FLS_DEVICE_VOXELGRID=2 keeps the older ascending-point-index sums for A/B).
+ *                         FLS_ERR_STATE when the device path declines (empty / no finite point / a non-finite point / the "leaf size
+ *                         too small" case / n > 4,194,304 / introsort's heap-sort case on a long range): call again with FLS_VOXELGRID_EXACT.
+ * "Bit for bit" is a statement about ONE toolchain: PCL 1.10 (Ubuntu 20.04 / ROS Noetic, what the reference's Dockerfile pulls) sorts the
+ * leaf index vector with std::sort, and libstdc++'s introsort is what both filters reproduce.  PCL >= 1.11 sorts that vector with
+ * boost::sort::spreadsort::integer_sort instead (unverified here: PCL is absent from this image): against such a build leaves of three or
+ * more points can differ in the last float bits from EITHER filter -- the same order of magnitude as FLS_DEVICE_VOXELGRID=2. */
 typedef enum fls_voxelgrid_mode { FLS_VOXELGRID_EXACT = 0, FLS_VOXELGRID_DEVICE = 1 } fls_voxelgrid_mode;
 fls_status fls_voxel_grid_cloud(int device_id, fls_voxelgrid_mode mode, const float* pts, size_t n, int stride_floats, float leaf_size,
                                 float* out, size_t cap_points, size_t* n_out);
@@ -274,8 +279,8 @@ fls_status fls_get_debug_stamps(fls_handle h, int64_t out[16]);
  * against the oracle's restatement, rank-deficient systems included.                                                      */
 fls_status fls_debug_fullpiv_qr6(int device_id, const double* H, const double* g, int n, double* x);
 
-/* test hook (= fls_voxel_grid_cloud(..., FLS_VOXELGRID_DEVICE, ...)): the device VoxelGrid (pcl::VoxelGrid<PointXYZI>::filter semantics; opt-in source filter of the ICP / NDT kinds,
- * FLS_DEVICE_VOXELGRID=1) on a caller-supplied cloud: pts (n x stride floats, intensity as in fls_match) -> out (cap x 4
+/* test hook (= fls_voxel_grid_cloud(..., FLS_VOXELGRID_DEVICE, ...)): the device VoxelGrid (pcl::VoxelGrid<PointXYZI>::filter semantics; the default source filter
+ * of the ICP / NDT kinds, FLS_DEVICE_VOXELGRID=1) on a caller-supplied cloud: pts (n x stride floats, intensity as in fls_match) -> out (cap x 4
  * floats x, y, z, intensity), *n_out = number of leaves.  FLS_ERR_STATE when the device path declines (empty / no finite
  * point / PCL's "leaf size too small" case / n > 4,194,304: the matchers then run the host filter), FLS_ERR_INVALID when
  * out is too small (*n_out is still set).  Contract: csrc/kernels_voxelgrid.hpp; tests/test_gpu_voxelgrid.py.          */
