@@ -29,7 +29,13 @@
 
 namespace fls {
 
-constexpr int kEsLds = 8192;        // records a workgroup sorts in LDS
+// (A/B r05, fls_match from host buffers: 8192 / 4096 / 2048 / 1024 records -> NDT 0.533 / 0.505 / 0.491 / 0.619 ms, ICP 0.443 / 0.415 / 0.408 / 0.404 ms.
+// One CU sorts a range at ~13 us per thousand records -- 16 waves, ~1.1 us of dependent LDS round trips per partition -- while splitting a range
+// in two out of global memory costs 3 us + 0.38 us per thousand: smaller LDS ranges on more CUs win until the queue traffic takes over)
+#ifndef FLS_ES_LDS
+#define FLS_ES_LDS 2048
+#endif
+constexpr int kEsLds = FLS_ES_LDS;  // records a workgroup sorts in LDS
 constexpr int kEsTaskMax = 131072;  // ranges up to here are tasks of the persistent kernel; longer ones go through the level-synchronous launches
 constexpr int kEsThreshold = 16;    // _S_threshold
 constexpr int kEsTile = 2048, kEsBlock = 256, kEsItems = kEsTile / kEsBlock;
@@ -293,7 +299,7 @@ constexpr int kEsTaskThreads = 1024, kEsTaskWaves = kEsTaskThreads / 64;
 #ifndef FLS_ES_SHARE
 #define FLS_ES_SHARE 64    // (A/B r05: 384 / 192 / 96 / 64 / 48 / 32 -> 0.497 / 0.451 / 0.444 / 0.445 / 0.445 / 0.475 ms)
 #endif
-constexpr int kEsCoop = FLS_ES_COOP;    // sub-ranges of an LDS range longer than this are partitioned by the whole workgroup, shorter ones by single waves
+constexpr int kEsCoop = FLS_ES_COOP < FLS_ES_LDS ? FLS_ES_COOP : FLS_ES_LDS;    // sub-ranges of an LDS range longer than this are partitioned by the whole workgroup, shorter ones by single waves
 constexpr int kEsShare = FLS_ES_SHARE;  // a wave hands children longer than this to the workgroup's queue (another wave takes them), shorter ones stay on its own stack
 constexpr int kEsStack = 64;     // pending workgroup-level sub-ranges (disjoint, each > kEsCoop records: at most kEsLds / kEsCoop)
 constexpr int kEsWaveStack = 48; // a wave's depth-first stack (smaller child first: <= log2(kEsCoop) + 1 pending ranges)

@@ -28,7 +28,7 @@ def active_mean(v):
 
 launch_us = active_mean(durs)
 fetch, write = active_mean(vals.get("FETCH_SIZE")), active_mean(vals.get("WRITE_SIZE"))
-out = {"kernel": sub, "workload": workload, "launches_in_trace": len(durs), "trace_avg_launch_us": launch_us,
+out = {"kernel": sub, "workload": workload, "source": "rocprofv3 --kernel-trace --pmc <one group per pass> (tools/prof_round5.sh) -> tools/make_kernel_traffic_json.py, directory " + os.path.basename(os.path.normpath(d)), "launches_in_trace": len(durs), "trace_avg_launch_us": launch_us,
        "fetch_size_kb_per_launch_raw": fetch, "write_size_kb_per_launch_raw": write, "fetch_correction": 2.0,
        "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 if fetch is not None and write is not None else None}
 if out["hbm_bytes_per_launch"] and launch_us:
