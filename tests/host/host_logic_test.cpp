@@ -291,6 +291,24 @@ int main() {
             }
             CHECK(next == n);
         }
+    // ---- flat device image header (fls_map_image_import): the header comes off a broadcast, every size must be bounded by the payload ----
+    {
+        IvoxImage img;
+        img.have_bricks = true; img.want_hash = false; img.mask = 0; img.dir_mask = 4095; img.n_bricks_cap = 64; img.n_pts_live = 900;
+        IvoxImage::FlatHeader h = img.flat_header(1000, 10);
+        const size_t n = size_t(h.total_bytes);
+        CHECK(n == sizeof(IvoxImage::FlatHeader) + 1000 * 16 + 4096 * 16 + 10 * size_t(kBrickStride) * 8);
+        CHECK(IvoxImage::flat_header_ok(h, n));
+        CHECK(!IvoxImage::flat_header_ok(h, n - 8));                                   // truncated payload
+        { auto g = h; g.magic[0] = 'X'; CHECK(!IvoxImage::flat_header_ok(g, n)); }
+        { auto g = h; g.used = ~0ull / 4; CHECK(!IvoxImage::flat_header_ok(g, n)); }      // would wrap a size computation
+        { auto g = h; g.n_bricks_live = 65; CHECK(!IvoxImage::flat_header_ok(g, n)); }   // more live bricks than the pool
+        { auto g = h; g.dir_mask = 4094; CHECK(!IvoxImage::flat_header_ok(g, n)); }      // not 2^k - 1
+        { auto g = h; g.have_bricks = 0; CHECK(!IvoxImage::flat_header_ok(g, n)); }      // neither form
+        { auto g = h; g.n_pts_live = 1001; CHECK(!IvoxImage::flat_header_ok(g, n)); }
+        { auto g = h; g.total_bytes += 16; CHECK(!IvoxImage::flat_header_ok(g, n)); }
+        CHECK(IvoxImage::kPoolBrickBytes > 25000 && IvoxImage::kPoolBrickBytes < 27000);
+    }
     std::printf("host logic ok\n");
     return 0;
 }
