@@ -92,3 +92,20 @@ def test_leaf_indices_of_a_real_scan():
 def test_large_cloud_many_levels():
     rng = np.random.default_rng(9)
     check(rng.integers(0, 200000, 1400000), "1.4 M records (a LoamFull planar deque)")
+
+
+def test_fuzz_against_std_sort():
+    """tools/es_fuzz.py: 300 arrays around every regime boundary of the device sort (16 / 64 / 2,048 / 4,096 / 32,768 / 131,072 records), key
+    distributions from all-equal to all-distinct, LiDAR-like piecewise-monotone keys, sorted / reversed / organ-pipe / sawtooth inputs: every
+    sort the device accepts equals std::sort's record for record (adversarial inputs that hit introsort's depth limit on a long range are
+    declined -- FLS_ERR_STATE -- and counted, not compared)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "es_fuzz.py"), "300", "4242"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    tail = run.stdout.strip().splitlines()[-1]
+    assert " 0 mismatches" in tail, tail
+    print(tail)
