@@ -59,17 +59,20 @@ __device__ __forceinline__ void es_swap_rec(unsigned* __restrict__ key, unsigned
     const unsigned ka = key[a], kb = key[b], va = val[a], vb = val[b];
     key[a] = kb; key[b] = ka; val[a] = vb; val[b] = va;
 }
-// std::__move_median_to_first(result = first, a = first + 1, b = mid, c = last - 1) on the keys; returns the pivot key
+// std::__move_median_to_first(result = first, a = first + 1, b = mid, c = last - 1) on the keys; returns the pivot key.
+// All four records are loaded before anything is decided (ONE memory round trip instead of three dependent ones -- candidates, then the
+// two records to swap, then the pivot read back: es_level_begin is a chain of such hops, 5.3 us per level in the trace).
 __device__ __forceinline__ unsigned es_median_to_first(unsigned* __restrict__ key, unsigned* __restrict__ val, const unsigned first, const unsigned last) {
     const unsigned a = first + 1u, b = first + (last - first) / 2u, c = last - 1u;
-    const unsigned ka = key[a], kb = key[b], kc = key[c];
-    unsigned med;
-    if (ka < kb) { if (kb < kc) med = b; else if (ka < kc) med = c; else med = a; }
-    else if (ka < kc) med = a;
-    else if (kb < kc) med = c;
-    else med = b;
-    es_swap_rec(key, val, first, med);
-    return key[first];
+    const unsigned ka = key[a], kb = key[b], kc = key[c], kf = key[first];
+    const unsigned va = val[a], vb = val[b], vc = val[c], vf = val[first];
+    unsigned med, km, vm;
+    if (ka < kb) { if (kb < kc) { med = b; km = kb; vm = vb; } else if (ka < kc) { med = c; km = kc; vm = vc; } else { med = a; km = ka; vm = va; } }
+    else if (ka < kc) { med = a; km = ka; vm = va; }
+    else if (kb < kc) { med = c; km = kc; vm = vc; }
+    else { med = b; km = kb; vm = vb; }
+    key[first] = km; val[first] = vm; key[med] = kf; val[med] = vf;  // (a, b, c are distinct positions of a range of more than 16 records)
+    return km;
 }
 
 // ---- regime 1 ----------------------------------------------------------------------------------------------------------------------
@@ -84,6 +87,7 @@ es_level_begin(unsigned* __restrict__ key, unsigned* __restrict__ val, const uns
                // level-synchronous; final_level: every child becomes a task and the task kernel's queue is written here; *skip != 0: nothing to sort
                const unsigned big, const int final_level, EsQueue* __restrict__ q_out, const unsigned* __restrict__ skip) {
     __shared__ unsigned s_ncur, s_nwork, s_fail, s_tiles[kEsMaxSeg], s_total;
+    __shared__ EsSeg s_cur[kEsMaxSeg];  // the new level's ranges: completed here (pivot, tile map), written out once
     if (skip != nullptr && *skip != 0u) {
         if (threadIdx.x == 0) {
             st->n_cur = 0u; st->n_tiles = 0u; st->n_work = 0u;
@@ -99,7 +103,7 @@ es_level_begin(unsigned* __restrict__ key, unsigned* __restrict__ val, const uns
         if (m < 2u) return;
         if (m > stay) {
             const unsigned slot = atomicAdd(&s_ncur, 1u);
-            if (slot < (unsigned)kEsMaxSeg) cur[slot] = EsSeg{f, l, depth, 0u, 0u, 0u, 0u, 0u};
+            if (slot < (unsigned)kEsMaxSeg) s_cur[slot] = EsSeg{f, l, depth, 0u, 0u, 0u, 0u, 0u};
             else s_fail = 1u;
         } else {
             const unsigned slot = atomicAdd(&s_nwork, 1u);
@@ -128,13 +132,12 @@ es_level_begin(unsigned* __restrict__ key, unsigned* __restrict__ val, const uns
     __syncthreads();
     const unsigned nc = s_ncur < (unsigned)kEsMaxSeg ? s_ncur : (unsigned)kEsMaxSeg;
     for (unsigned s = threadIdx.x; s < nc; s += 256u) {
-        EsSeg g = cur[s];
+        EsSeg g = s_cur[s];
         if (g.depth == 0) { s_fail = 1u; g.pivot = key[g.first]; }  // (introsort switches to heap sort here)
         else g.pivot = es_median_to_first(key, val, g.first, g.last);
-        cur[s] = g;
+        s_cur[s] = g;
+        s_tiles[s] = (g.last - g.first - 1u + (unsigned)kEsTile - 1u) / (unsigned)kEsTile;
     }
-    __syncthreads();
-    for (unsigned s = threadIdx.x; s < nc; s += 256u) s_tiles[s] = (cur[s].last - cur[s].first - 1u + (unsigned)kEsTile - 1u) / (unsigned)kEsTile;
     __syncthreads();
     if (threadIdx.x == 0) {  // exclusive prefix of the tile counts (LDS, <= kEsMaxSeg entries)
         unsigned t = 0u;
@@ -146,7 +149,9 @@ es_level_begin(unsigned* __restrict__ key, unsigned* __restrict__ val, const uns
     if (!s_fail)
         for (unsigned s = threadIdx.x; s < nc; s += 256u) {  // tile -> range map (one load per workgroup in the three launches that follow)
             const unsigned t0 = s_tiles[s], t1 = s + 1u < nc ? s_tiles[s + 1u] : s_total;
-            cur[s].tile0 = t0;
+            EsSeg g = s_cur[s];
+            g.tile0 = t0;
+            cur[s] = g;
             for (unsigned q = t0; q < t1; ++q) tile_seg[q] = s;
         }
     if (threadIdx.x == 0) {
