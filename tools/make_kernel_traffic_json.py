@@ -21,7 +21,8 @@ if os.path.exists(tr):
 def active_mean(v):
     if not v:
         return None
-    top = max(v)
+    w = sorted(v)
+    top = w[min(len(w) - 1, (9 * len(w)) // 10)]  # the 90th percentile, not the maximum: one slow launch must not define "active"
     a = [x for x in v if x > 0.5 * top]  # early-exit launches (a converged Match, an empty level) are tiny
     return sum(a) / len(a)
 
@@ -53,7 +54,7 @@ if wc:
     if wa is not None: out["wave_wait_pct"] = 100.0 * wa / wc
     if wi is not None: out["wave_issue_stall_pct"] = 100.0 * wi / wc
     if ai is not None: out["wave_issuing_pct"] = 100.0 * ai / wc
-out["note"] = ("mean over the active launches (> half of the largest value); FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE uncorrected; "
+out["note"] = ("mean over the active launches (> half of the 90th percentile); FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE uncorrected; "
                "l2_read_bytes assumes 128-B TCP->TCC read requests; instruction_floor = SQ_INSTS_VALU wave-instructions x 4 cycles / 1024 SIMDs at 2.4 GHz")
 with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_%s.json" % name), "w") as f:
     json.dump(out, f, indent=1)
