@@ -385,8 +385,7 @@ struct DeviceVoxelGrid {
         if (!d_acc.p) {  // armed once; the last block of every vg_minmax_plan re-arms it
             d_acc.reserve(1);
             d_plan.reserve(1);
-            const VgAccum init{{0xffffffffu, 0xffffffffu, 0xffffffffu}, {0u, 0u, 0u}, 0u, 0u};
-            FLS_HIP(hipMemcpyAsync(d_acc.p, &init, sizeof(VgAccum), hipMemcpyHostToDevice, s));
+            FLS_HIP(hipMemsetAsync(d_acc.p, 0, sizeof(VgAccum), s));  // (the ticket; the rows are written before they are read)
             FLS_HIP(hipStreamSynchronize(s));
         }
         const int ni = int(n);
@@ -403,7 +402,7 @@ struct DeviceVoxelGrid {
         // (the reference sorts the FINITE points only: a cloud with a non-finite point is the host's, refuse_bad = 1)
         // (blocks: 48 in rounds 2-4 -- "few blocks: six header atomics each" -- left a 115,200-point scan to 12 k threads, 11-12 us in the trace
         // of the call; 160 blocks = three points per thread and < 1,000 atomics: FLS_VG_MINMAX_BLOCKS for A/B)
-        static const int mm_blocks = [] { const char* e = std::getenv("FLS_VG_MINMAX_BLOCKS"); return e ? std::max(1, std::atoi(e)) : 160; }();
+        static const int mm_blocks = [] { const char* e = std::getenv("FLS_VG_MINMAX_BLOCKS"); return e ? std::min(kVgMinmaxMaxBlocks, std::max(1, std::atoi(e))) : 160; }();
         hipLaunchKernelGGL(vg_minmax_plan, dim3(unsigned(std::min(nb1, mm_blocks))), dim3(kVgBlock), 0, s, x, y, z, ni, inv, 1, d_acc.p, d_plan.p, es);
         hipLaunchKernelGGL(vg_index_plan, dim3(unsigned(nb1)), dim3(kVgBlock), 0, s, x, y, z, ni, (const VgPlan*)d_plan.p, sort.k0, sort.v0);
         exact.fused_launch(sort.k0, sort.v0, n, &d_plan.p->status, s);

@@ -3,7 +3,7 @@
 // Rounds 2-4 read the bounds back (hipMemcpyAsync + hipStreamSynchronize) to derive the leaf grid on the host, initialised the exact
 // sort's queue with three runtime fill / copy operations, and synchronised the stream again for the output size: ~90 us of a 680 us
 // IncrementalNDT call were idle queue (profiles/r05_a_vg_ndt_before_sequence.txt).  Here
-//   vg_minmax_plan   bounds (per-block atomics) + ticket; the LAST block derives the leaf grid with the host's float arithmetic
+//   vg_minmax_plan   bounds (one write-through row per block) + ticket; the LAST block folds the rows, derives the leaf grid with the host's float arithmetic
 //                    (voxel_grid.hpp:69-92: "leaf size too small" refusal, min_b / div_b / divb_mul), writes the VgPlan the following
 //                    kernels read, re-arms the accumulators for the next call and initialises the exact sort's queue;
 //   vg_index_plan / vg_heads_plan / vg_centroid_plan   the round-2 bodies, grid and verdict read from the plan;
@@ -25,8 +25,11 @@ struct VgPlan {
     unsigned n_bad;
     unsigned mn[3], mx[3];  // ordered-uint bounds (diagnostics / tests)
 };
-// accumulators of vg_minmax_plan: armed once at allocation, re-armed by the last block of every call
-struct VgAccum { unsigned mn[3], mx[3], n_bad, ticket; };
+// what the blocks of vg_minmax_plan hand to their last arriver: one row of partial bounds per block (written write-through, read with sc1 loads:
+// the hand-off of the fit kernels) and one ticket.  (Until late in round 5 every block folded its bounds into six shared words with device-scope
+// atomics: 160 blocks x 6 atomics on six addresses serialise at the memory side -- 11 us for a kernel that reads 1.4 MB.)
+constexpr int kVgMinmaxMaxBlocks = 512;
+struct VgAccum { unsigned ticket, pad[7]; unsigned part[kVgMinmaxMaxBlocks][8]; };  // part[b] = {mn x y z, mx x y z, n_bad, -}
 // host-mapped: the verdict of one call
 struct VgMailbox { unsigned seq, n_out, status, sort_fail; };
 // what the last block of vg_minmax_plan initialises for es_task_kernel (st == nullptr: no exact sort follows)
@@ -37,7 +40,7 @@ __device__ __forceinline__ float vg_unord_dev(const unsigned u) { return __uint_
 __global__ void __launch_bounds__(kVgBlock)
 vg_minmax_plan(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int n, const float inv, const int refuse_bad,
                VgAccum* __restrict__ acc, VgPlan* __restrict__ plan, const EsInitArgs es) {
-    __shared__ unsigned red[kVgBlock / 64][6];
+    __shared__ unsigned red[kVgBlock / 64][6], s_bad[kVgBlock / 64];
     __shared__ unsigned s_last;
     unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u}, bad = 0u;
     for (int i = blockIdx.x * kVgBlock + threadIdx.x; i < n; i += gridDim.x * kVgBlock) {
@@ -56,39 +59,74 @@ vg_minmax_plan(const float* __restrict__ x, const float* __restrict__ y, const f
             hi[a] = max(hi[a], (unsigned)__shfl_xor((int)hi[a], o, 64));
         }
     }
-    if (bad) atomicAdd(&acc->n_bad, bad);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) {
+    {
+        unsigned b2 = bad;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { red[w][a] = lo[a]; red[w][3 + a] = hi[a]; }
+        for (int o = 32; o > 0; o >>= 1) b2 += __shfl_xor(b2, o, 64);
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { red[w][a] = lo[a]; red[w][3 + a] = hi[a]; }
+            s_bad[w] = b2;
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 7) {
         const int a = threadIdx.x;
-        unsigned v = red[0][a];
-        for (int q = 1; q < kVgBlock / 64; ++q) v = a < 3 ? min(v, red[q][a]) : max(v, red[q][a]);
-        if (a < 3) atomicMin(&acc->mn[a], v);
-        else atomicMax(&acc->mx[a - 3], v);
+        unsigned v;
+        if (a < 6) {
+            v = red[0][a];
+            for (int q = 1; q < kVgBlock / 64; ++q) v = a < 3 ? min(v, red[q][a]) : max(v, red[q][a]);
+        } else {
+            v = 0u;
+            for (int q = 0; q < kVgBlock / 64; ++q) v += s_bad[q];
+        }
+        __hip_atomic_store(&acc->part[blockIdx.x][a], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
     }
-    // the block's atomics have been performed (device scope: at the memory side) before its ticket is taken
+    // the block's row has left the chip's caches (drained) before its ticket is taken
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&acc->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
+    // last block: fold the rows (one per thread, sc1 loads), then one thread derives the plan
+    {
+        unsigned r[7] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u};
+        for (unsigned bq = threadIdx.x; bq < gridDim.x; bq += kVgBlock) {
+#pragma unroll
+            for (int a = 0; a < 7; ++a) {
+                const unsigned v = __hip_atomic_load(&acc->part[bq][a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                r[a] = a < 3 ? min(r[a], v) : a < 6 ? max(r[a], v) : r[a] + v;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned t2 = (unsigned)__shfl_xor((int)r[a], o, 64);
+                r[a] = a < 3 ? min(r[a], t2) : a < 6 ? max(r[a], t2) : r[a] + t2;
+            }
+        }
+        __syncthreads();  // (red / s_bad are reused)
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) red[w][a] = r[a];
+            s_bad[w] = r[6];
+        }
+        __syncthreads();
+    }
     if (es.st != nullptr) {  // the exact sort's queue: the whole array is workgroup 0's first task (open = 1 stands for it)
         for (unsigned i = threadIdx.x; i < es.work_cap; i += kVgBlock) es.ready[i] = 0u;
         if (threadIdx.x < sizeof(EsState) / 4u) reinterpret_cast<unsigned*>(es.st)[threadIdx.x] = 0u;
         if (threadIdx.x == 0) *es.q = EsQueue{0u, 0u, 1u, 0u};
     }
     if (threadIdx.x != 0) return;
-    unsigned umn[3], umx[3];
+    unsigned umn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, umx[3] = {0u, 0u, 0u}, nbad = 0u;
+    for (int q = 0; q < kVgBlock / 64; ++q) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        umn[a] = __hip_atomic_load(&acc->mn[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        umx[a] = __hip_atomic_load(&acc->mx[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int a = 0; a < 3; ++a) { umn[a] = min(umn[a], red[q][a]); umx[a] = max(umx[a], red[q][3 + a]); }
+        nbad += s_bad[q];
     }
-    const unsigned nbad = __hip_atomic_load(&acc->n_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     VgPlan p;
     p.n_bad = nbad;
 #pragma unroll
@@ -128,14 +166,7 @@ vg_minmax_plan(const float* __restrict__ x, const float* __restrict__ y, const f
         }
     }
     *plan = p;
-    // re-arm for the next call (this block is the only one left)
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        __hip_atomic_store(&acc->mn[a], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&acc->mx[a], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __hip_atomic_store(&acc->n_bad, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&acc->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&acc->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next call (this block is the only one left; the rows are simply overwritten)
 }
 
 __global__ void __launch_bounds__(kVgBlock)
