@@ -17,10 +17,15 @@
 //   positions no other swap touches;   cut = min(L_{K*+1}, R_{K*})  (terms that do not exist count as +inf).
 // So one level = flag two predicates, rank them (prefix sums), scatter the two stop lists, swap K* disjoint pairs.  All ranges of one
 // recursion depth are independent and processed together (level-synchronous); values ride along with their keys.
-//   regime 1  ranges longer than kEsLds records: four launches per level over all such ranges (es_level_begin: cuts + children of the
-//             previous level, medians of this one; es_count / es_scatter: stop lists through per-tile counts; es_swap)
-//   regime 2  every range of <= kEsLds records: one workgroup takes it into LDS and runs ALL its remaining levels there
-//             (es_lds_kernel), then ranks the records of every final <= 16 block (= the insertion sort) and writes them back.
+//   regime 1  ranges longer than a threshold: four launches per level over all such ranges (es_level_begin: cuts + children of the previous
+//             level, medians of this one; es_count / es_scatter: stop lists through per-tile counts; es_swap).  Round 5: for clouds up to
+//             kEsTaskMax records the levels above 32,768 records (FLS_ES_BIG) are PRE-ENQUEUED without a host round trip (device_voxelgrid.hpp
+//             fused_launch: a level of launches costs ~20 us whatever the size, one workgroup 3 us + 0.38 us per thousand records); beyond
+//             kEsTaskMax the host steers the levels through a mailbox as in round 4;
+//   regime 2  shorter ranges are TASKS of the persistent es_task_kernel: a workgroup partitions a range longer than kEsLds (2,048) records out
+//             of global memory and hands one child to the queue, takes a range of <= kEsLds records into LDS, runs ALL its remaining levels
+//             there (sub-ranges above kEsCoop by the whole workgroup, the rest as wave tasks through a ticket queue: es_phase_b), then
+//             ranks the records of every final <= 16 block (= the insertion sort) and writes them back.
 // The heap-sort fallback of introsort (recursion deeper than 2 log2 n) IS reproduced for ranges that fit into LDS (es_heap_sort: real scans
 // reach it routinely); only a range still longer than kEsLds records at depth 0 makes the sort report failure (the caller takes the host
 // path).
