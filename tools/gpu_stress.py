@@ -6,9 +6,10 @@ from funny_lidar_slam_amd import registration as reg, synth
 from tests import test_gpu_parity as tp
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+job0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100  # first synth job (seed): a second run with another offset sees other scans
 fails = 0
 t0 = time.time()
-for job in range(100, 100 + n):
+for job in range(job0, job0 + n):
     for mode, y, cid, scale, loc in (("PointToPlane_IVOX", reg.YAML_NCLT_IVOX, 1, 0.04, False), ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, 0.04, False),
                                      ("LoamFull_KdTree", reg.YAML_NCLT_LOAM_FULL, 3, 0.04, False), ("IcpOptimized", reg.YAML_NCLT_ICP, 0, 1.0, True),
                                      ("PointToPlane_KdTree", reg.YAML_NCLT_LOC_KDTREE, 1, 0.04, True)):
@@ -20,4 +21,4 @@ for job in range(100, 100 + n):
         except AssertionError as e:
             fails += 1
             print("FAIL", mode, job, str(e)[:300], flush=True)
-print(f"{n} scans x 5 kinds: {fails} failures, {time.time()-t0:.0f} s")
+print(f"{n} scans (jobs {job0}..{job0 + n - 1}) x 5 kinds: {fails} failures, {time.time()-t0:.0f} s")
