@@ -65,6 +65,8 @@ struct DeviceExactSort {
     DevBuf<EsSeg> seg_a, seg_b;
     DevBuf<EsWork> work;
     DevBuf<uint2> tile_cnt;
+    DevBuf<unsigned long long> tile_pub;  // es_count_scatter_kernel: a tile's published counts + the launch's epoch
+    unsigned pub_epoch = 0;
     DevBuf<unsigned> tile_seg, Lp, Rl;
     DevBuf<EsState> st;
     DevBuf<EsQueue> queue;
@@ -108,6 +110,11 @@ struct DeviceExactSort {
         work.reserve(work_cap);
         ready.reserve(work_cap);
         tile_cnt.reserve(tile_cap); tile_seg.reserve(tile_cap);
+        if (tile_pub.cap < tile_cap) {  // a fresh buffer holds epoch 0, which no launch uses (growth is rare: filled and waited for here)
+            tile_pub.reserve(tile_cap);
+            FLS_HIP(hipMemset(tile_pub.p, 0, tile_pub.cap * sizeof(unsigned long long)));
+            FLS_HIP(hipDeviceSynchronize());
+        }
         Lp.reserve(n); Rl.reserve(n);
         st.reserve(1);
         queue.reserve(1);
@@ -154,10 +161,7 @@ struct DeviceExactSort {
         hipLaunchKernelGGL(es_level_begin, dim3(1), dim3(256), 0, s, key, val, unsigned(n), (const EsSeg*)prev, cur, work.p, work_cap, (const unsigned*)Lp.p,
                            (const unsigned*)Rl.p, st.p, (EsMailbox*)nullptr, next_seq(), 1, tile_seg.p, tile_cap, big, 0, queue.p, skip);
         for (int l = 0; l < top; ++l) {
-            hipLaunchKernelGGL(es_count_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, (const unsigned*)key, (const EsSeg*)cur, (const EsState*)st.p,
-                               (const unsigned*)tile_seg.p, tile_cnt.p);
-            hipLaunchKernelGGL(es_scatter_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, (const unsigned*)key, cur, (const EsState*)st.p, (const unsigned*)tile_seg.p,
-                               (const uint2*)tile_cnt.p, Lp.p, Rl.p);
+            launch_lists(key, cur, s);
             hipLaunchKernelGGL(es_swap_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, key, val, cur, (const EsState*)st.p, (const unsigned*)tile_seg.p,
                                (const unsigned*)Lp.p, (const unsigned*)Rl.p);
             std::swap(prev, cur);
@@ -167,6 +171,21 @@ struct DeviceExactSort {
         }
         hipLaunchKernelGGL(es_task_kernel, dim3(grid), dim3(kEsTaskThreads), 0, s, key, val, work.p, ready.p, work_cap, queue.p, Lp.p, Rl.p, st.p,
                            dbg_marks ? mb_dev : (EsMailbox*)nullptr, 0u, skip);
+    }
+    // the stop lists of a level: one launch (es_count_scatter_kernel: tiles look back at their predecessors' published counts), or the two
+    // launches it replaces (FLS_ES_LOOKBACK=0: counts, launch boundary, lists)
+    void launch_lists(const unsigned* key, EsSeg* cur, hipStream_t s) {
+        static const bool lookback = [] { const char* e = std::getenv("FLS_ES_LOOKBACK"); return e ? std::atoi(e) != 0 : true; }();
+        if (lookback) {
+            if (++pub_epoch == 0u) ++pub_epoch;  // (0 is what a fresh buffer holds)
+            hipLaunchKernelGGL(es_count_scatter_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, key, cur, st.p, (const unsigned*)tile_seg.p, tile_pub.p, pub_epoch,
+                               Lp.p, Rl.p);
+            return;
+        }
+        hipLaunchKernelGGL(es_count_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, key, (const EsSeg*)cur, (const EsState*)st.p, (const unsigned*)tile_seg.p,
+                           tile_cnt.p);
+        hipLaunchKernelGGL(es_scatter_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, key, cur, (const EsState*)st.p, (const unsigned*)tile_seg.p,
+                           (const uint2*)tile_cnt.p, Lp.p, Rl.p);
     }
     // queues the whole sort on `s`; false: refused before anything ran (sizes).  The verdict of the sort itself (introsort's heap-sort
     // case) is only known once the stream has drained: failed_after_sync().
@@ -201,10 +220,7 @@ struct DeviceExactSort {
         int chunk = expected ? expected + 1 : 0;
         for (;;) {
             for (int c = 0; c < chunk; ++c) {
-                hipLaunchKernelGGL(es_count_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, (const unsigned*)key, (const EsSeg*)cur, (const EsState*)st.p,
-                                   (const unsigned*)tile_seg.p, tile_cnt.p);
-                hipLaunchKernelGGL(es_scatter_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, (const unsigned*)key, cur, (const EsState*)st.p, (const unsigned*)tile_seg.p,
-                                   (const uint2*)tile_cnt.p, Lp.p, Rl.p);
+                launch_lists(key, cur, s);
                 hipLaunchKernelGGL(es_swap_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, key, val, cur, (const EsState*)st.p, (const unsigned*)tile_seg.p,
                                    (const unsigned*)Lp.p, (const unsigned*)Rl.p);
                 std::swap(prev, cur);
