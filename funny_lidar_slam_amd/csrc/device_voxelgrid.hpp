@@ -129,9 +129,9 @@ struct DeviceExactSort {
         allocate(n);
         return EsInitArgs{st.p, queue.p, ready.p, work_cap};
     }
-    // Ranges longer than `big` records are partitioned LEVEL-SYNCHRONOUSLY by the whole device -- four launches per level (es_level_begin / count /
-    // scatter / swap, the regime-1 kernels), pre-enqueued without a host round trip: one workgroup needs 3 us + 0.38 us per thousand records
-    // for a partition (profiles/r05_d_ndt_global_levels.log: 47 us at 115,200), a level of launches ~14 us whatever the size.  The number of
+    // Ranges longer than `big` records are partitioned LEVEL-SYNCHRONOUSLY by the whole device -- three launches per level (es_level_begin / count_scatter /
+    // swap, the regime-1 kernels), pre-enqueued without a host round trip: one workgroup needs 3 us + 0.38 us per thousand records
+    // for a partition (profiles/r05_d_ndt_global_levels.log: 47 us at 115,200), a level of launches ~16 us whatever the size.  The number of
     // levels is a guess (the larger child keeps ~13/16 of a LiDAR range); levels that find nothing left are empty launches, ranges still longer
     // than `big` after the last one are the task kernel's (one workgroup each, as in round 4).  FLS_ES_BIG = 0 switches the top levels off.
     static unsigned big_threshold() {

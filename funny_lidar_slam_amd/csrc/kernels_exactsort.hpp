@@ -17,10 +17,11 @@
 //   positions no other swap touches;   cut = min(L_{K*+1}, R_{K*})  (terms that do not exist count as +inf).
 // So one level = flag two predicates, rank them (prefix sums), scatter the two stop lists, swap K* disjoint pairs.  All ranges of one
 // recursion depth are independent and processed together (level-synchronous); values ride along with their keys.
-//   regime 1  ranges longer than a threshold: four launches per level over all such ranges (es_level_begin: cuts + children of the previous
-//             level, medians of this one; es_count / es_scatter: stop lists through per-tile counts; es_swap).  Round 5: for clouds up to
+//   regime 1  ranges longer than a threshold: three launches per level over all such ranges (es_level_begin: cuts + children of the previous
+//             level, medians of this one; es_count_scatter: stop lists through per-tile counts, a tile looks back at its predecessors'
+//             published counts -- es_count / es_scatter are the two-launch form it replaced; es_swap).  Round 5: for clouds up to
 //             kEsTaskMax records the levels above 32,768 records (FLS_ES_BIG) are PRE-ENQUEUED without a host round trip (device_voxelgrid.hpp
-//             fused_launch: a level of launches costs ~20 us whatever the size, one workgroup 3 us + 0.38 us per thousand records); beyond
+//             fused_launch: a level of launches costs ~16 us whatever the size, one workgroup 3 us + 0.38 us per thousand records); beyond
 //             kEsTaskMax the host steers the levels through a mailbox as in round 4;
 //   regime 2  shorter ranges are TASKS of the persistent es_task_kernel: a workgroup partitions a range longer than kEsLds (2,048) records out
 //             of global memory and hands one child to the queue, takes a range of <= kEsLds records into LDS, runs ALL its remaining levels
