@@ -609,22 +609,23 @@ icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
     const int lane = threadIdx.x & 63;
     double* row = &wsum[threadIdx.x >> 6][0];
     bool contrib = false;
+    int id_l = -1;
+    const bool owner = (threadIdx.x & 7) == 0 && r.q >= 0;
+    // ids are reported for accepted correspondences only; with the fused tail they leave after the hand-off of the partial row (kernels_ivox_coop.hpp)
+    auto store_ids = [&]() { if (owner) { nn_id[r.q] = id_l; eff[r.q] = contrib ? 1 : 0; } };
 #if FLS_FIT_MFMA
     // the point's three Jacobian rows go to the matrix cores (kernels_p2plane.hpp::reduce_rank1x3_mfma_and_store): no per-point 21 + 6 products,
     // no 522-instruction DPP tree per wave
     double Jr[18], er[3] = {0.0, 0.0, 0.0}, res = 0.0;
 #pragma unroll
     for (int k = 0; k < 18; ++k) Jr[k] = 0.0;
-    if ((threadIdx.x & 7) == 0 && r.q >= 0) {
-        int id = -1;
+    if (owner) {
         if (r.found >= 1 && r.key != ~0ull && !((double)r.kth > max_corr)) {
             const float4 m = cg.g.pts[r.slot];
-            id = __float_as_int(m.w);
+            id_l = __float_as_int(m.w);
             icp_point_rows(T, sx[r.q], sy[r.q], sz[r.q], m, Jr, er, res);
             contrib = true;
         }
-        nn_id[r.q] = id;  // ids are reported for accepted correspondences only
-        eff[r.q] = contrib ? 1 : 0;
     }
     __shared__ __attribute__((aligned(64))) double mfma_tile[4][512];
     reduce_rank1x3_mfma_and_store(contrib, Jr, er, row, &mfma_tile[threadIdx.x >> 6][0]);
@@ -636,16 +637,13 @@ icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
     for (int k = 0; k < 21; ++k) Hc[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) Bc[k] = 0.0;
-    if ((threadIdx.x & 7) == 0 && r.q >= 0) {
-        int id = -1;
+    if (owner) {
         if (r.found >= 1 && r.key != ~0ull && !((double)r.kth > max_corr)) {
             const float4 m = cg.g.pts[r.slot];
-            id = __float_as_int(m.w);
+            id_l = __float_as_int(m.w);
             icp_point_terms(T, sx[r.q], sy[r.q], sz[r.q], m, Hc, Bc, res);
             contrib = true;
         }
-        nn_id[r.q] = id;  // ids are reported for accepted correspondences only
-        eff[r.q] = contrib ? 1 : 0;
     }
 #pragma unroll
     for (int k = 0; k < 21; ++k) { const double v = wave_sum_dpp(Hc[k]); if (lane == 63) row[k] = v; }
@@ -654,14 +652,15 @@ icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
     const double sr = wave_sum_dpp(res), sc = wave_sum_dpp(contrib ? 1.0 : 0.0);
     if (lane == 63) { row[27] = sr; row[28] = sc; }
 #endif
-    if (!ticket) { block_row_from_wave_sums(wsum, partials); return; }
+    if (!ticket) { store_ids(); block_row_from_wave_sums(wsum, partials); return; }
     // fused Gauss-Newton tail (round 3): the row goes out write-through, the last workgroup to arrive solves and publishes
     __syncthreads();
     const double v = threadIdx.x < 29 ? ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x] : 0.0;
     __shared__ unsigned s_ticket;
     __shared__ LuTailSmem sm;
-    if (!publish_row_and_arrive(v, threadIdx.x < 29, partials, ticket, shards, s_ticket)) return;
+    if (!publish_row_and_arrive(v, threadIdx.x < 29, partials, ticket, shards, s_ticket)) { store_ids(); return; }
     lu_tail<256, true>(st, sm, partials, (int)gridDim.x, tail, T, it);
+    store_ids();
 }
 
 __global__ void __launch_bounds__(256)
@@ -737,16 +736,31 @@ feature_fit_body(const int bid, const float* __restrict__ sx, const float* __res
     const int it = (ft && !first) ? st->iter : 0;
     if (done) return;
     __shared__ double wsum[4][32];
-    bool contrib = false;
+    bool contrib = false, fresh = false, acc_l = false;
     double J[6] = {0, 0, 0, 0, 0, 0}, res = 0.0;
+    int ids_l[5] = {-1, -1, -1, -1, -1};
+    // the per-point outputs; with the fused tail they leave AFTER the hand-off of the partial row (kernels_ivox_coop.hpp: a barrier waits for
+    // every store issued in front of it)
+    auto store_outputs = [&]() {
+        if (i >= n) return;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) nn_id[(size_t)i * 5 + j] = ids_l[j];  // gate-accepted sets only
+        cnt_out[i] = acc_l ? 5 : 0;
+        if (fresh) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) Jst[(size_t)a * n + i] = J[a];
+            Jst[(size_t)6 * n + i] = res;
+            flag[i] = 1;
+        }
+    };
     if (i < n) {
         const bool accepted = nn_cnt[i] == 5 && !(kth_d2[i] > gate);
         float4 nn[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) nn[j] = nn_pts[(size_t)i * 5 + j];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) nn_id[(size_t)i * 5 + j] = accepted ? __float_as_int(nn[j].w) : -1;  // gate-accepted sets only
-        cnt_out[i] = accepted ? 5 : 0;
+        for (int j = 0; j < 5; ++j) ids_l[j] = accepted ? __float_as_int(nn[j].w) : -1;
+        acc_l = accepted;
         bool valid_now = false;
         if (accepted) {
             const float px = sx[i], py = sy[i], pz = sz[i];
@@ -758,10 +772,7 @@ feature_fit_body(const int bid, const float* __restrict__ sx, const float* __res
             else valid_now = plane_residual_dev(nn, px, py, pz, ptx, pty, ptz, T44, thres, J, res);
         }
         if (valid_now) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a) Jst[(size_t)a * n + i] = J[a];
-            Jst[(size_t)6 * n + i] = res;
-            flag[i] = 1;
+            fresh = true;
             contrib = true;
         } else if (flag[i]) {  // Q1 stale slot
 #pragma unroll
@@ -776,7 +787,7 @@ feature_fit_body(const int bid, const float* __restrict__ sx, const float* __res
 #else
     reduce_rank1_and_store(contrib, J, res, &wsum[threadIdx.x >> 6][0]);
 #endif
-    if (!ft) { block_row_from_wave_sums(wsum, partials, bid); return; }
+    if (!ft) { store_outputs(); block_row_from_wave_sums(wsum, partials, bid); return; }
     // fused Gauss-Newton tail (round 3, LOAM dual launch): the row goes out write-through, the last workgroup of the WHOLE launch (both
     // feature classes) sums the corner rows, then the planar rows (SumCoefficient's order) and runs the LOAM-family tail
     __syncthreads();
@@ -790,9 +801,10 @@ feature_fit_body(const int bid, const float* __restrict__ sx, const float* __res
     __syncthreads();
     if (threadIdx.x == 0) s_ticket = fanin_last_arriver(ft->ticket, ft->shards);
     __syncthreads();
-    if (!s_ticket) return;
+    if (!s_ticket) { store_outputs(); return; }
     GnState* const stw = const_cast<GnState*>(st);
     loam_tail<256, true>(stw, sm, ft->partials_a, ft->nrows_a, ft->partials_b, ft->nrows_b, ft->rot_thr, ft->pos_thr, T44, last_rot, last_pos, it, ft->mb, ft->match_id);
+    store_outputs();
 }
 
 template <bool LINE>

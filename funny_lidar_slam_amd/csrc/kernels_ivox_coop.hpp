@@ -456,6 +456,13 @@ ivox_knn_kernel(const float* __restrict__ sx, const float* __restrict__ sy, cons
 // (relaxed agent-scope) loads.  No release fence: an agent-scope release writes back the XCD's whole L2, which
 // this kernel has just dirtied with 28 KB of Jacobian rows per workgroup (measured: 7 us on the critical path).
 // The ticket counters (kTicketWords unsigned words) are reset by their last arrivers, so they are zero at every launch.
+// A point's Jacobian row and flag go to memory AFTER the workgroup has handed its partial row over (in the workgroup that runs the tail: after
+// the tail): __syncthreads() waits for every store a wave has issued, and 28 KB of rows per workgroup in front of the hand-off's barriers sat on
+// the last workgroup's critical path (round 5: -0.3 us per launch here, -1.7 us per Match on a 5.8 k-point scan; same registers, same bits:
+// profiles/r05_ll_ab_late_stores_x_fanin.log).  Nothing inside the launch reads them back.
+// Where the time of the tail workgroup goes (profiles/r05_ll_fanin_stamps.log, -DFLS_TIMING, ~2.3 ticks per ns): its own fit 4.2 us, waiting for
+// the slowest of its eight waves + row store + drain 3.2 us, two ticket levels 1.0 us, row read + reduction 1.6 us, LDL^T 1.45 us, pose update
+// + state + mailbox 1.9 us.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFitThreads = 512;
 template <bool FIRST, int NT = kFitThreads>
@@ -502,8 +509,15 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
 #ifdef FLS_TIMING
     const long long t_begin = (long long)__builtin_readcyclecounter();
 #endif
-    bool contrib = false;
+    bool contrib = false, fresh = false;
     double J[6] = {0, 0, 0, 0, 0, 0}, res = 0.0;
+    auto store_point = [&]() {  // (called once, after the hand-off)
+        if (!fresh) return;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) Jst[(size_t)a * n + i] = J[a];
+        Jst[(size_t)6 * n + i] = res;
+        flag[i] = 1;
+    };
     if (i < n) {
         bool valid_now = false;
         if (cnt == 5) {
@@ -514,10 +528,7 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
             valid_now = plane_residual_dev(nn, px, py, pz, ptx, pty, ptz, T44, plane_thres, J, res);
         }
         if (valid_now) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a) Jst[(size_t)a * n + i] = J[a];
-            Jst[(size_t)6 * n + i] = res;
-            flag[i] = 1;
+            fresh = true;
             contrib = true;
         } else if (stale) {  // Q1: stale contribution of an earlier iteration
 #pragma unroll
@@ -549,17 +560,21 @@ p2plane_fit_solve_kernel(const float* __restrict__ sx, const float* __restrict__
                            (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
+#ifdef FLS_TIMING
+    const long long t_drain = (long long)__builtin_readcyclecounter();
+#endif
     __syncthreads();
     // sharded fan-in (kernels_p2plane.hpp::fanin_last_arriver): which workgroup arrives last
     if (threadIdx.x == 0) s_ticket = fanin_last_arriver(ticket, shards);
     __syncthreads();
-    if (!s_ticket) return;
+    if (!s_ticket) { store_point(); return; }
     // ---- last workgroup: Gauss-Newton tail (reads the rows with sc1 loads: no acquire fence either) ----
 #ifdef FLS_TIMING
-    if (threadIdx.x == 0) { st->dbg[0] = t_begin; st->dbg[13] = t_fit; st->dbg[14] = t_red; }
+    if (threadIdx.x == 0) { st->dbg[0] = t_begin; st->dbg[13] = t_fit; st->dbg[14] = t_red; st->dbg[15] = t_drain; }
 #endif
     FLS_STAMP(1);
     loam_tail<NT, true>(st, sm, nullptr, 0, partials, (int)gridDim.x, rot_thr, pos_thr, T44, last_rot, last_pos, it, mb, match_id);
+    store_point();  // (every thread comes back from the tail: waves 1.. at once, wave 0 after it has published)
 }
 
 // ---------------------------------------------------------------------------------------------
