@@ -124,33 +124,50 @@ def cpu_baseline(cfg, y, budget_s=20.0):
                       f"OpenMP per-point stage + sequential reduction, traffic instrumentation off, best of thread counts up to {ncpu} (best: {thr})"}
 
 
-def cpu_baseline_reference(cfg, y, budget_s=8.0):
-    """The reference's OWN LoamPointToPlaneIVOX<double>::Match (oracle/_ref/libref.so: its sources compiled verbatim against the
-    include-shadow shim of oracle/ref_shim) timed on the headline inputs -- SURVEY.md 8d "report both".  What it is and is not:
-    the reference's loops, containers and allocations exactly as written; but PSTL's par / par_unseq run SERIALLY here (no TBB
-    headers in this image, libstdc++ falls back to the sequential backend) and Eigen / PCL calls go through the shim's stand-ins,
-    so this is a 1-core number of the reference's code, not the reference as deployed.  Localization-mode instance: the same
-    Match loop, without the map update the mapping-mode Match appends (loam_point_to_plane_ivox.h:205-207)."""
+def cpu_baseline_reference(cfg, y, budget_s=10.0):
+    """The reference's OWN LoamPointToPlaneIVOX<double>::Match timed on the headline inputs -- SURVEY.md 8d "report both".
+    oracle/_ref/libref_par.so = the reference's sources compiled verbatim against the include-shadow shim of oracle/ref_shim, with its
+    parallel-STL loops (`std::for_each(std::execution::par_unseq, ...)`, loam_point_to_plane_ivox.h:262) on OpenMP threads: the shim's
+    include/pstl_omp.hpp stands in for the TBB backend the reference links (CMakeLists.txt:96; TBB's headers are absent here, and
+    libstdc++ alone would run those loops on one thread).  What it is and is not: the reference's loops, containers and allocations
+    exactly as written, bit-identical to the serial build (tests/test_ref_pin.py); Eigen / PCL calls go through the shim's stand-ins.
+    `value` = the best of a few thread counts; `one_thread` = the same library held to one thread (round 1-4's figure).
+    Localization-mode instance: the same Match loop, without the map update the mapping-mode Match appends (:205-207)."""
+    os.environ.setdefault("FLS_REF_PAR", "1")
     from oracle import oracle as O, ref as R
-    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref.so")) and not R.available():
+    par = R.PARALLEL and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_par.so"))
+    if not par and not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref.so")) and not R.available():
         return None
     p = O.Params(max_iterations=y["optimization_iter_num"], point_to_planar_thres=y["point_to_planar_thres"], position_converge_thres=y["position_converge_thres"],
                  rotation_converge_thres=y["rotation_converge_thres"], is_localization_mode=1)
     m = R.RefMatcher(O.P2PLANE_IVOX, p)
     m.AddCloudToLocalMap(cfg["map"])
-    ts, t_start, iters = [], time.perf_counter(), 0
-    for rep in range(12):
-        t0 = time.perf_counter()
-        ok, T = m.Match(cfg["scan"], cfg["T_init"])
-        ts.append(time.perf_counter() - t0)
-        iters = int(m.stats.iterations)
-        if rep >= 2 and time.perf_counter() - t_start > budget_s:
-            break
-    t = float(np.median(ts[1:] if len(ts) > 1 else ts))
+    ncpu = os.cpu_count() or 1
+    counts = sorted({min(ncpu, t) for t in (1, 16, 32, 64, ncpu)}) if par else [1]
+    per = {}
+    iters = 0
+    for thr in counts:
+        if par:
+            R.lib().ref_set_threads(thr)
+        ts, t_start = [], time.perf_counter()
+        for rep in range(12):
+            t0 = time.perf_counter()
+            ok, T = m.Match(cfg["scan"], cfg["T_init"])
+            ts.append(time.perf_counter() - t0)
+            iters = int(m.stats.iterations)
+            if rep >= 2 and time.perf_counter() - t_start > budget_s / len(counts):
+                break
+        per[thr] = (float(np.median(ts[1:] if len(ts) > 1 else ts)), len(ts))
     m.close()
-    return {"value": 1.0 / t, "unit": "scans/s", "cores": 1, "kind": "reference",
-            "sample": f"{len(ts)} Match calls (median) of the full 115,200-pt scan into the 1e6-pt iVox map ({iters} GN iterations), the reference's own "
-                      "LoamPointToPlaneIVOX<double> compiled verbatim (oracle/ref_shim): serial PSTL backend (no TBB here), shim Eigen / PCL -- 1 core"}
+    best = min(per, key=lambda k: per[k][0])
+    out = {"value": 1.0 / per[best][0], "unit": "scans/s", "cores": best, "kind": "reference",
+           "one_thread": 1.0 / per[1][0] if 1 in per else None,
+           "scans_per_s_by_threads": {str(k): 1.0 / v[0] for k, v in per.items()},
+           "sample": f"{sum(v[1] for v in per.values())} Match calls (median per thread count, {budget_s:.0f} s budget) of the full 115,200-pt scan into the 1e6-pt iVox map "
+                     f"({iters} GN iterations), the reference's own LoamPointToPlaneIVOX<double> compiled verbatim (oracle/ref_shim), shim Eigen / PCL; "
+                     + ("its parallel-STL loops on OpenMP threads (pstl_omp.hpp in place of the TBB backend the reference links)" if par
+                        else "serial PSTL backend (libref_par.so absent) -- 1 core")}
+    return out
 
 
 def grid_counters(map_xyz, query_xyz, cell):

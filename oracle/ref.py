@@ -19,8 +19,12 @@ from .oracle import (FEAT_ARRAYS, FeatParams, ICP_OPTIMIZED, INCREMENTAL_NDT, LO
                      _cloud)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_ref", "libref.so")
+# FLS_REF_PAR=1: the build whose parallel-STL loops (std::execution::par / par_unseq for_each) run on OpenMP threads
+# (oracle/ref_shim/include/pstl_omp.hpp stands in for the TBB backend the reference links); same sources, same results
 REFERENCE_ROOT = "/root/reference"
+PARALLEL = os.environ.get("FLS_REF_PAR", "0") == "1" and (os.path.exists(os.path.join(_HERE, "_ref", "libref_par.so")) or
+                                                          os.path.isdir(os.path.join(REFERENCE_ROOT, "include", "registration")))
+_LIB_PATH = os.path.join(_HERE, "_ref", "libref_par.so" if PARALLEL else "libref.so")
 _lib = None
 
 
@@ -76,6 +80,8 @@ def lib():
         L.ref_col_index.argtypes = [C.c_float, C.c_float, C.c_char_p]
         L.ref_fast_atan2f.restype = C.c_float
         L.ref_fast_atan2f.argtypes = [C.c_float, C.c_float]
+        L.ref_set_threads.restype = C.c_int
+        L.ref_set_threads.argtypes = [C.c_int]
         L.ref_so3_exp.argtypes = [dp, dp]
         L.ref_rpy.argtypes = [dp, dp]
         _lib = L

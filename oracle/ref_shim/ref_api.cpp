@@ -386,6 +386,16 @@ size_t ref_feat_get(void* hh, int what, void* out, size_t cap) {
 }
 int ref_col_index(float x, float y, const char* lidar_type) { return LidarModel::Instance(lidar_type)->ColIndex(x, y); }
 float ref_fast_atan2f(float y, float x) { return FastAtan2(y, x); }
+// threads of the parallel-STL loops: > 0 only in the libref_par.so build (include/pstl_omp.hpp); 0 = the serial PSTL backend
+int ref_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 0;
+#endif
+}
 void ref_so3_exp(const double v[3], double R_colmajor[9]) {
     const Eigen::Matrix<double, 3, 1> w(v[0], v[1], v[2]);
     const Eigen::Matrix<double, 3, 3> R = SO3Exp(w);

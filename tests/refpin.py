@@ -267,11 +267,12 @@ def run_features_subprocess(name: str) -> dict:
             return z["out"].item()
 
 
-def run_ref_subprocess(name: str) -> dict:
-    """engine 'ref' in a fresh interpreter (function-static state of the reference), result through a temporary .npz."""
+def run_ref_subprocess(name: str, env: dict = None) -> dict:
+    """engine 'ref' in a fresh interpreter (function-static state of the reference), result through a temporary .npz.
+    env: extra environment, e.g. {"FLS_REF_PAR": "1"} for the build whose parallel-STL loops run on OpenMP threads."""
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "out.npz")
-        subprocess.check_call([sys.executable, "-m", "tests.refpin", name, path], cwd=ROOT)
+        subprocess.check_call([sys.executable, "-m", "tests.refpin", name, path], cwd=ROOT, env=dict(os.environ, **(env or {})))
         with np.load(path, allow_pickle=True) as z:
             return z["out"].item()
 

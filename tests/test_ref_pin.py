@@ -34,6 +34,18 @@ def test_oracle_equals_compiled_reference(name):
     assert worst["T"] < 1e-12, worst
 
 
+@need_ref
+@pytest.mark.parametrize("name", refpin.SCENARIOS)
+def test_compiled_reference_parallel_pstl_equals_serial(name):
+    """oracle/_ref/libref_par.so (the reference's `std::execution::par / par_unseq` loops on OpenMP threads -- ref_shim/include/pstl_omp.hpp
+    in place of the TBB backend the reference links; what bench.py times as the multi-core cpu_baseline_ref) against the serial build: every
+    frame, every field, every bit -- the parallel loops write per-index outputs only."""
+    ser = refpin.run_ref_subprocess(name)
+    par = refpin.run_ref_subprocess(name, env={"FLS_REF_PAR": "1", "OMP_NUM_THREADS": "4"})
+    worst = refpin.compare(par, ser, name)
+    assert all(v == 0.0 for v in worst.values()), worst
+
+
 @pytest.mark.parametrize("name", refpin.SCENARIOS)
 def test_oracle_equals_reference_golden(name):
     g = refpin.from_golden(np.load(os.path.join(GOLD, f"ref_{name}.npz")))
