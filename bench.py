@@ -891,7 +891,7 @@ def main():
             fit_flop = n_pts * 600
             lus = float(fj["trace_avg_launch_us"])
             line["roofline_fit_kernel"] = {
-                "kernel": "p2plane_fit_solve_kernel", "avg_launch_us": lus, "launch_geometry": "225 workgroups x 512 threads = 1.76 waves / SIMD, 112 VGPRs",
+                "kernel": "p2plane_fit_solve_kernel", "avg_launch_us": lus, "launch_geometry": "225 workgroups x 512 threads = 1.76 waves / SIMD, 127 VGPRs",
                 "algorithmic_bytes_per_launch": fit_bytes, "achieved_GBs_by_algorithmic_bytes": fit_bytes / (lus * 1e-6) / 1e9, "frac_of_hbm_peak": fit_bytes / (lus * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "fp64_flop_per_launch": fit_flop, "achieved_fp64_TFLOPs": fit_flop / (lus * 1e-6) / 1e12,
                 "traffic": fj.get("hbm_bytes_per_launch"), "measured_hbm_GBs": fj.get("measured_hbm_GBs"), "valu_busy_pct": fj.get("valu_busy_pct"),
