@@ -46,6 +46,20 @@ def test_compiled_reference_parallel_pstl_equals_serial(name):
     assert all(v == 0.0 for v in worst.values()), worst
 
 
+@need_ref
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_oracle_equals_compiled_reference_fuzz(seed):
+    """Seeded random variations of the mapping-mode replays (tests/refpin.py::make_fuzz_scenario: kind by seed % 4; iteration budgets of two,
+    gates far tighter / looser than the YAML's, deques of one or two frames, an effective-point floor the scan cannot meet, iVox LRU capacities
+    of a few hundred voxels, start poses anywhere in the room): the oracle follows the compiled reference through every frame and field.
+    (120 seeds were run once: profiles/r05_ref_pin_fuzz_120_scenarios.log; what the draw had to avoid is a reference crash, see the generator.)"""
+    name = f"fuzz{seed}"
+    ref_out = refpin.run_ref_subprocess(name)
+    ora_out = refpin.run("oracle", name)
+    worst = refpin.compare(ora_out, ref_out, name)
+    assert worst["T"] < 1e-12, worst
+
+
 @pytest.mark.parametrize("name", refpin.SCENARIOS)
 def test_oracle_equals_reference_golden(name):
     g = refpin.from_golden(np.load(os.path.join(GOLD, f"ref_{name}.npz")))
