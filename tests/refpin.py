@@ -61,6 +61,34 @@ def make_scenario(name: str) -> dict:
         return r
     if name.startswith("fuzz"):
         return make_fuzz_scenario(int(name[4:]))
+    if name.startswith("lfuzz"):
+        # localization mode, seeded: kind by seed % 4, a prior map of a random size, 2-3 scans from identity, GetFitnessScore after every Match
+        seed = int(name[5:])
+        rng = np.random.default_rng(99000 + seed)
+        pick = lambda *v: v[int(rng.integers(len(v)))]
+        conv = dict(position_converge_thres=pick(0.001, 0.005, 0.05), rotation_converge_thres=pick(0.001, 0.005, 0.05))
+        k = seed % 4
+        if k == 0:
+            mode, cid, scale = "IcpOptimized", 0, pick(0.3, 1.0)
+            y = dict(reg.YAML_NCLT_ICP, optimization_iter_num=int(rng.integers(2, 20)), point_search_thres=pick(0.3, 1.0, 2.0),
+                     local_map_cloud_filter_size=pick(0.2, 0.4, 0.8), source_cloud_filter_size=pick(0.2, 0.4, 0.8), **conv)
+        elif k == 1:
+            mode, cid, scale = "PointToPlane_KdTree", 1, pick(0.02, 0.03)
+            y = dict(reg.YAML_NCLT_LOC_KDTREE, optimization_iter_num=int(rng.integers(2, 10)), point_to_planar_thres=pick(0.03, 0.1, 0.3),
+                     local_map_cloud_filter_size=pick(0.3, 0.5, 0.8), **conv)
+        elif k == 2:
+            mode, cid, scale = "PointToPlane_IVOX", 1, pick(0.02, 0.03)
+            y = dict(reg.YAML_NCLT_IVOX, optimization_iter_num=int(rng.integers(2, 10)), point_to_planar_thres=pick(0.03, 0.1, 0.3), **conv)
+        else:
+            mode, cid, scale = "IncrementalNDT", 2, pick(0.02, 0.03)
+            y = dict(reg.YAML_NCLT_NDT, optimization_iter_num=int(rng.integers(2, 12)), ndt_voxel_size=pick(1.0, 2.0), ndt_outlier_threshold=pick(1.0, 5.0, 20.0),
+                     source_cloud_filter_size=pick(0.2, 0.5), ndt_min_points_in_voxel=pick(3, 5, 8), ndt_min_effective_pts=pick(10, 50, 3000), **conv)
+        frames, init = [], None
+        for job in range(int(rng.integers(2, 4))):
+            cfg = synth.make_config(cid, job=200 + 10 * seed + job, scale=scale)
+            init = [cfg["map"]]
+            frames.append(dict(scan=cfg["scan"], corner=None, guess_step=np.eye(4), T_gt=cfg["T_gt"], absolute_guess=np.eye(4)))
+        return dict(name=name, mode=mode, y=y, init_clouds=init, frames=frames, loc=True)
     # localization mode: one prior map, a few scans, GetFitnessScore after every Match
     base = {"icp_loc": ("IcpOptimized", reg.YAML_NCLT_ICP, 0, 1.0), "kd_loc": ("PointToPlane_KdTree", reg.YAML_NCLT_LOC_KDTREE, 1, 0.03),
             "ivox_loc": ("PointToPlane_IVOX", reg.YAML_NCLT_IVOX, 1, 0.03), "ndt_loc": ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, 0.03)}[name]
@@ -273,6 +301,24 @@ FEATURE_FIELDS = ("ordered", "depth", "col", "row_start", "row_end", "corner", "
 
 def make_feature_case(name: str):
     from funny_lidar_slam_amd import synth
+    if name.startswith("ffuzz"):
+        # seeded random frame: either lidar model, poses up to 15 deg / 3 m off the scene's axes, thresholds and range gates away from the YAML's,
+        # a random share of the returns dropped (ragged rows, rows that end up too short to extract from), driver order shuffled or not
+        seed = int(name[5:])
+        rng = np.random.default_rng(88000 + seed)
+        pick = lambda *v: v[int(rng.integers(len(v)))]
+        lid = getattr(synth, pick("VELODYNE_64", "VELODYNE_16"))
+        scene = synth.make_scene()
+        raw = synth.cast_raw_scan(scene, synth.random_pose(synth.rng_for(6, 100 + seed), float(pick(2.0, 8.0, 15.0)), float(pick(0.5, 1.5, 3.0))),
+                                  rng=synth.rng_for(6, 100 + seed, 1), **lid)
+        keep = rng.random(raw.shape[0]) >= float(pick(0.0, 0.1, 0.3, 0.9))
+        raw = raw[keep]
+        if rng.integers(2):
+            raw = raw[rng.permutation(raw.shape[0])]
+        params = dict(vertical_scan=lid["n_rings"], horizontal_scan=1800, horizontal_resolution=float(np.float32(0.2) / 180.0 * np.pi),
+                      min_distance=float(pick(2.0, 4.0, 8.0)), max_distance=float(pick(30.0, 60.0, 100.0)), corner_thres=float(pick(0.5, 1.0, 2.0)),
+                      planar_thres=float(pick(0.05, 0.1, 0.3)))
+        return raw, params
     c = FEATURE_CASES[name]
     lid = getattr(synth, c["lidar"])
     scene = synth.make_scene()

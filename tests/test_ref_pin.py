@@ -52,12 +52,38 @@ def test_oracle_equals_compiled_reference_fuzz(seed):
     """Seeded random variations of the mapping-mode replays (tests/refpin.py::make_fuzz_scenario: kind by seed % 4; iteration budgets of two,
     gates far tighter / looser than the YAML's, deques of one or two frames, an effective-point floor the scan cannot meet, iVox LRU capacities
     of a few hundred voxels, start poses anywhere in the room): the oracle follows the compiled reference through every frame and field.
-    (120 seeds were run once: profiles/r05_ref_pin_fuzz_120_scenarios.log; what the draw had to avoid is a reference crash, see the generator.)"""
+    (120 seeds were run once: profiles/r05_ref_pin_fuzz_200_scenarios.log; what the draw had to avoid is a reference crash, see the generator.)"""
     name = f"fuzz{seed}"
     ref_out = refpin.run_ref_subprocess(name)
     ora_out = refpin.run("oracle", name)
     worst = refpin.compare(ora_out, ref_out, name)
     assert worst["T"] < 1e-12, worst
+
+
+@need_ref
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_oracle_equals_compiled_reference_fuzz_localization(seed):
+    """The same for localization mode (kind by seed % 4: IcpOptimized, LoamPointToPlaneKdtree, LoamPointToPlaneIVOX, IncrementalNDT): prior maps of
+    random size, random thresholds / budgets, GetFitnessScore after every Match (40 seeds run once, all equal: the same log file)."""
+    name = f"lfuzz{seed}"
+    ref_out = refpin.run_ref_subprocess(name)
+    ora_out = refpin.run("oracle", name)
+    worst = refpin.compare(ora_out, ref_out, name)
+    assert worst["T"] < 1e-12, worst
+
+
+@need_ref
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_feature_oracle_equals_compiled_reference_fuzz(seed):
+    """PointcloudProjector + FeatureExtractor on seeded random frames (either lidar model, tilted poses, thresholds and range gates away from the
+    YAML's, up to 90 % of the returns dropped, driver order shuffled or not): every array bit for bit (40 seeds run once, all equal)."""
+    name = f"ffuzz{seed}"
+    ref_out = refpin.run_features_subprocess(name)
+    ora = refpin.run_features("oracle", name, sort_mode=1)
+    assert ref_out["digest"] == ora["digest"]
+    assert ref_out["n_ordered"] == ora["n_ordered"] and ref_out["extracted"] == ora["extracted"]
+    for f in refpin.FEATURE_FIELDS:
+        assert ref_out[f].shape == ora[f].shape and np.array_equal(ref_out[f], ora[f]), (name, f)
 
 
 @pytest.mark.parametrize("name", refpin.SCENARIOS)

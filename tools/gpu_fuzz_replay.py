@@ -1,5 +1,5 @@
 """HIP path vs the CPU oracle on the seeded random mapping-mode scenarios of tests/refpin.py::make_fuzz_scenario -- the scenarios on which the
-oracle was checked against the compiled reference (profiles/r05_ref_pin_fuzz_120_scenarios.log), with the assertions of
+oracle was checked against the compiled reference (profiles/r05_ref_pin_fuzz_200_scenarios.log), with the assertions of
 tests/test_gpu_mapping_replay.py::run_replay after every frame (return value, iterations, per-iteration n_valid / pose, flags, counts, ids, map sizes).
 usage: python tools/gpu_fuzz_replay.py [first_seed [n_seeds]]        (default 0 24; ~1-2 s per scenario)
 STATUS: written at the very end of round 5, after the round's GPU budget was spent -- it has NOT been run on a GPU yet."""
