@@ -2,7 +2,8 @@
 oracle was checked against the compiled reference (profiles/r05_ref_pin_fuzz_200_scenarios.log), with the assertions of
 tests/test_gpu_mapping_replay.py::run_replay after every frame (return value, iterations, per-iteration n_valid / pose, flags, counts, ids, map sizes).
 usage: python tools/gpu_fuzz_replay.py [first_seed [n_seeds]]        (default 0 24; ~1-2 s per scenario)
-STATUS: written at the very end of round 5, after the round's GPU budget was spent -- it has NOT been run on a GPU yet."""
+STATUS: written at the very end of round 5; the last seconds of the round's GPU budget ran seeds 0-3 (one per kind): all four equal the oracle
+through every frame (profiles/r05_late_gpu_fuzz_replay_first_seeds.log).  Seeds from 4 on have not been run on a GPU."""
 import os, sys, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import refpin, util
