@@ -59,6 +59,8 @@ def make_scenario(name: str) -> dict:
         r = replay.make_replay("ivox")
         r.update(name=name, loc=False, ivox_capacity=IVOX_LRU_CAPACITY)
         return r
+    if name.startswith("fuzzL"):  # long runs: 8-14 frames (deques past their VoxelGrid length, LRU lists at capacity for many frames)
+        return make_fuzz_scenario(int(name[5:]), long_run=True)
     if name.startswith("fuzz"):
         return make_fuzz_scenario(int(name[4:]))
     if name.startswith("lfuzz"):
@@ -101,7 +103,7 @@ def make_scenario(name: str) -> dict:
     return dict(name=name, mode=mode, y=y, init_clouds=init, frames=frames, loc=True)
 
 
-def make_fuzz_scenario(seed: int) -> dict:
+def make_fuzz_scenario(seed: int, long_run: bool = False) -> dict:
     """Seeded random variation of a mapping-mode replay: kind by seed % 4, parameters drawn from ranges that reach the branches the fixed scenarios
     touch once or never (two-iteration budgets, gates far tighter / looser than the YAML's, tiny deques, an effective-point floor the scan cannot
     meet, LRU capacities of a few hundred voxels, a start pose anywhere in the room).  The oracle must follow the compiled reference through all of it."""
@@ -138,8 +140,11 @@ def make_fuzz_scenario(seed: int) -> dict:
     yaw = float(rng.uniform(-np.pi, np.pi))
     start[:3, :3] = np.array([[np.cos(yaw), -np.sin(yaw), 0.0], [np.sin(yaw), np.cos(yaw), 0.0], [0.0, 0.0, 1.0]])
     start[:3, 3] = [float(rng.uniform(-12.0, 12.0)), float(rng.uniform(-6.0, 6.0)), 0.0]
-    r = replay.make_replay(base, n_frames=int(rng.integers(3, 6)), start=start, max_range=float(pick(25.0, 38.0, 45.0)), y_over=over)
-    r.update(name=f"fuzz{seed}", loc=False, **extra)
+    n_frames = int(rng.integers(3, 6))
+    if long_run:
+        n_frames = int(rng.integers(8, 15))
+    r = replay.make_replay(base, n_frames=n_frames, start=start, max_range=float(pick(25.0, 38.0, 45.0)), y_over=over)
+    r.update(name=f"fuzz{'L' if long_run else ''}{seed}", loc=False, **extra)
     return r
 
 
