@@ -61,6 +61,16 @@ def test_oracle_equals_compiled_reference_fuzz(seed):
 
 
 @need_ref
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_oracle_equals_compiled_reference_fuzz_long_runs(seed):
+    """8-14 frames per scenario (one seed per kind here, 60 run once): deques past the length at which the reference VoxelGrids them, LRU lists at
+    capacity for many frames, keyframe gates passing and failing in turn."""
+    name = f"fuzzL{seed}"
+    worst = refpin.compare(refpin.run("oracle", name), refpin.run_ref_subprocess(name), name)
+    assert worst["T"] < 1e-12, worst
+
+
+@need_ref
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_oracle_equals_compiled_reference_fuzz_localization(seed):
     """The same for localization mode (kind by seed % 4: IcpOptimized, LoamPointToPlaneKdtree, LoamPointToPlaneIVOX, IncrementalNDT): prior maps of
