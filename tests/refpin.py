@@ -59,6 +59,19 @@ def make_scenario(name: str) -> dict:
         r = replay.make_replay("ivox")
         r.update(name=name, loc=False, ivox_capacity=IVOX_LRU_CAPACITY)
         return r
+    if name.startswith("deg_"):
+        # degenerate inputs at the boundary (what tests/test_gpu_parity.py::test_empty_and_tiny_inputs feeds the GPU): one frame from identity
+        _, kind, what = name.split("_")
+        mode, y, cid, loc = {"ivox": ("PointToPlane_IVOX", reg.YAML_NCLT_IVOX, 1, False), "icp": ("IcpOptimized", reg.YAML_NCLT_ICP, 0, True),
+                             "ndt": ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, False), "loam": ("LoamFull_KdTree", reg.YAML_NCLT_LOAM_FULL, 3, False),
+                             "kd": ("PointToPlane_KdTree", reg.YAML_NCLT_LOC_KDTREE, 1, True)}[kind]
+        cfg = synth.make_config(cid, scale=0.03 if cid else 1.0)
+        empty = np.zeros((0, 3), np.float32)
+        far = (cfg["scan"][:200] + np.float32(5000.0)).astype(np.float32)  # 5 km away from every map point
+        scan, corner = {"empty": (empty, empty), "tiny": (cfg["scan"][:7].copy(), cfg.get("corner_scan", empty)[:3].copy()), "far": (far, far[:20].copy()),
+                        "tiny12": (cfg["scan"][:12].copy(), empty), "le10": (cfg["scan"][:10].copy(), empty), "nocorner": (cfg["scan"], empty)}[what]
+        frames = [dict(scan=scan, corner=(corner if kind == "loam" else None), guess_step=np.eye(4), T_gt=np.eye(4), absolute_guess=np.eye(4))]
+        return dict(name=name, mode=mode, y=y, init_clouds=[cfg["map"]] + ([cfg["corner_map"]] if "corner_map" in cfg else []), frames=frames, loc=loc)
     if name.startswith("fuzzL"):  # long runs: 8-14 frames (deques past their VoxelGrid length, LRU lists at capacity for many frames)
         return make_fuzz_scenario(int(name[5:]), long_run=True)
     if name.startswith("fuzz"):

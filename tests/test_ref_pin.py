@@ -60,6 +60,28 @@ def test_oracle_equals_compiled_reference_fuzz(seed):
     assert worst["T"] < 1e-12, worst
 
 
+DEGENERATE = ("deg_ivox_empty", "deg_ivox_tiny", "deg_ivox_far", "deg_icp_tiny12", "deg_icp_far", "deg_ndt_empty", "deg_ndt_tiny", "deg_ndt_far",
+              "deg_loam_nocorner", "deg_loam_tiny", "deg_loam_far", "deg_kd_tiny", "deg_kd_far")
+
+
+@need_ref
+@pytest.mark.parametrize("name", DEGENERATE)
+def test_oracle_equals_compiled_reference_degenerate_inputs(name):
+    """Empty source clouds, sources with fewer points than any gate needs, scans that see nothing of the map (every query without candidates),
+    LoamFull without corner features: return value, pose, counts and map state of the oracle are the compiled reference's."""
+    worst = refpin.compare(refpin.run("oracle", name), refpin.run_ref_subprocess(name), name)
+    assert worst["T"] < 1e-10, worst  # (thirty iterations on a rank-deficient 6 x 6 system, deg_loam_tiny, amplify the last bits to 4e-12)
+
+
+@need_ref
+def test_compiled_reference_aborts_on_ten_or_fewer_icp_points():
+    """CHECK_GT(ordered_cloud_.size(), 10u) (icp_optimized.h:55) ends the reference process; the product returns an error status for it
+    (tests/test_gpu_parity.py::test_empty_and_tiny_inputs)."""
+    import subprocess
+    with pytest.raises(subprocess.CalledProcessError):
+        refpin.run_ref_subprocess("deg_icp_le10")
+
+
 @need_ref
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_oracle_equals_compiled_reference_fuzz_long_runs(seed):
