@@ -119,7 +119,7 @@ def cpu_baseline(cfg, y, budget_s=20.0):
         o.close()
     O.set_threads(0)
     t, thr, iters, reps = best
-    return {"value": 1.0 / t, "unit": "scans/s", "cores": thr, "kind": "port",
+    return {"value": 1.0 / t, "unit": "scans/s", "cores": thr, "threads": thr, "host_cores": ncpu, "kind": "port",
             "sample": f"{reps} Match calls (median; {budget_s:.0f} s budget over the thread counts tried) of the full 115,200-pt scan into the 1e6-pt iVox map ({iters} GN iterations each), "
                       f"OpenMP per-point stage + sequential reduction, traffic instrumentation off, best of thread counts up to {ncpu} (best: {thr})"}
 
@@ -160,9 +160,11 @@ def cpu_baseline_reference(cfg, y, budget_s=10.0):
         per[thr] = (float(np.median(ts[1:] if len(ts) > 1 else ts)), len(ts))
     m.close()
     best = min(per, key=lambda k: per[k][0])
-    out = {"value": 1.0 / per[best][0], "unit": "scans/s", "cores": best, "kind": "reference",
+    out = {"value": 1.0 / per[best][0], "unit": "scans/s", "cores": best, "threads": best, "host_cores": ncpu, "kind": "reference",
            "one_thread": 1.0 / per[1][0] if 1 in per else None,
            "scans_per_s_by_threads": {str(k): 1.0 / v[0] for k, v in per.items()},
+           "scaling_note": "beyond ~32 threads this build gets SLOWER (round 5: 64 threads 10.6, 256 threads 2.2 scans/s): the shim's Eigen stand-ins allocate per call and the "
+                           "allocator serialises them -- a property of the shim build, not of the reference with real Eigen + TBB; the best thread count is what `value` reports",
            "sample": f"{sum(v[1] for v in per.values())} Match calls (median per thread count, {budget_s:.0f} s budget) of the full 115,200-pt scan into the 1e6-pt iVox map "
                      f"({iters} GN iterations), the reference's own LoamPointToPlaneIVOX<double> compiled verbatim (oracle/ref_shim), shim Eigen / PCL; "
                      + ("its parallel-STL loops on OpenMP threads (pstl_omp.hpp in place of the TBB backend the reference links)" if par
@@ -317,7 +319,7 @@ def bench_other_configs(reg, synth, util, O, budget_s=6.0):
                          "algorithmic_bytes_per_iteration": bytes_iter, "correspondence_launch_us": 1e6 * avg_launch_s,
                          "note": "8d formula; kd-tree kinds: counters of the survey's 27-cell grid (cell = sqrt(gate)) at the final pose, the bracket covers one "
                                  "iteration's correspondence launch(es)"},
-            "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "scans/s", "cores": min(os.cpu_count() or 1, 64), "kind": "port",
+            "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "scans/s", "cores": min(os.cpu_count() or 1, 64), "threads": min(os.cpu_count() or 1, 64), "host_cores": os.cpu_count() or 1, "kind": "port",
                              "sample": f"{reps} oracle Match calls (median), {int(o.stats.iterations)} iterations each"},
         }
         o.close()
@@ -494,6 +496,57 @@ def bench_loop_closure(reg, O):
             "note": "per-point sums on the device (ndt_p2d_kernel, gicp_cov / corr / fdf kernels), six-parameter optimisers + leaf statistics + exact VoxelGridCloud filters on the host"}
 
 
+def _dig(d, path):
+    for k in path.split("/"):
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return float(d) if isinstance(d, (int, float)) and not isinstance(d, bool) else None
+
+
+# short name -> (path in the bench line, "lower"/"higher" is better).  The LAST key of the printed line (`legs`) is this table evaluated: every leg a
+# round can regress on, flat and short, so that the 2,000-character tail the driver keeps of the line still carries all of them, and
+# tools/bench_diff.py can compare a new line with the previous round's record leg by leg (VERDICT r5 weak #12 / next #1b).
+LEGS = {
+    "headline_us": ("ms_per_step", "lower", 1e3), "knn_us": ("roofline/avg_launch_us", "lower", 1.0), "knn_frac": ("roofline/frac", "higher", 1.0),
+    "fit_us": ("roofline_fit_kernel/avg_launch_us", "lower", 1.0),
+    "icp_sps": ("configs/configs[0]/scans_per_s", "higher", 1.0), "icp_iters_us": ("configs/configs[0]/resident_filtered_match_us", "lower", 1.0),
+    "icp_corr_us": ("configs/configs[0]/roofline/correspondence_launch_us", "lower", 1.0), "icp_frac": ("configs/configs[0]/roofline/frac", "higher", 1.0),
+    "icp_host_us": ("configs/configs[0]/match_from_host_buffers_us/device_filter_exact_default", "lower", 1.0),
+    "icp_host_idx_us": ("configs/configs[0]/match_from_host_buffers_us/device_filter_index_order_ab", "lower", 1.0),
+    "icp_cpu_sps": ("configs/configs[0]/cpu_baseline/value", "higher", 1.0),
+    "ndt_sps": ("configs/configs[2]/scans_per_s", "higher", 1.0), "ndt_iters_us": ("configs/configs[2]/resident_filtered_match_us", "lower", 1.0),
+    "ndt_corr_us": ("configs/configs[2]/roofline/correspondence_launch_us", "lower", 1.0), "ndt_frac": ("configs/configs[2]/roofline/frac", "higher", 1.0),
+    "ndt_host_us": ("configs/configs[2]/match_from_host_buffers_us/device_filter_exact_default", "lower", 1.0),
+    "ndt_host_idx_us": ("configs/configs[2]/match_from_host_buffers_us/device_filter_index_order_ab", "lower", 1.0),
+    "ndt_cpu_sps": ("configs/configs[2]/cpu_baseline/value", "higher", 1.0),
+    "loam_sps": ("configs/configs[3]/scans_per_s", "higher", 1.0), "loam_corr_us": ("configs/configs[3]/roofline/correspondence_launch_us", "lower", 1.0),
+    "loam_frac": ("configs/configs[3]/roofline/frac", "higher", 1.0), "loam_cpu_sps": ("configs/configs[3]/cpu_baseline/value", "higher", 1.0),
+    "map_ivox_ms": ("mapping_mode/device_addpoints/ms_per_scan_match_plus_update", "lower", 1.0),
+    "map_ivox_upd_ms": ("mapping_mode/device_addpoints/ms_map_update_only", "lower", 1.0),
+    "map_ivox_prod_ms": ("mapping_mode/filtered_planar_cloud_0p5m/ms_per_scan_match_plus_update_from_host_buffers", "lower", 1.0),
+    "map_ndt_ms": ("mapping_mode/incremental_ndt/default_device_update_device_filters_exact/ms_per_scan_match_plus_update", "lower", 1.0),
+    "map_ndt_idx_ms": ("mapping_mode/incremental_ndt/device_update_device_filters_index_order_ab/ms_per_scan_match_plus_update", "lower", 1.0),
+    "map_icp_kf_ms": ("mapping_mode/icp_optimized/default_device_filter_exact/ms_keyframe_update_only", "lower", 1.0),
+    "map_icp_kf_idx_ms": ("mapping_mode/icp_optimized/device_filter_index_order_ab/ms_keyframe_update_only", "lower", 1.0),
+    "map_loam_kf_ms": ("mapping_mode/loam_full/default_device_filter_exact/ms_keyframe_update_only", "lower", 1.0),
+    "map_loam_kf_idx_ms": ("mapping_mode/loam_full/device_filter_index_order_ab/ms_keyframe_update_only", "lower", 1.0),
+    "loop_ms": ("loop_closure/ms_per_match", "lower", 1.0), "h2d_us": ("inclusive_h2d/match_us", "lower", 1.0),
+    "c5_sps": ("c5_batch/scans_per_s", "higher", 1.0), "c5n_sps": ("c5_batch_native/scans_per_s", "higher", 1.0),
+    "cpu_sps": ("cpu_baseline/value", "higher", 1.0), "cpu_ref_sps": ("cpu_baseline_ref/value", "higher", 1.0),
+}
+
+
+def legs_from_line(line: dict) -> dict:
+    """The flat leg table of a bench line (also of the lines of earlier rounds, which did not print one)."""
+    out = {}
+    for name, (path, _, scale) in LEGS.items():
+        v = _dig(line, path)
+        if v is not None:
+            out[name] = float(f"{v * scale:.5g}")
+    return out
+
+
 def baseline_metric():
     """BASELINE.json's metric string, verbatim (it travels with the repository); the ASCII spelling if the file is missing"""
     try:
@@ -643,12 +696,9 @@ def main():
     if not args.no_batch:
         job_range = batch.partition(n_jobs, n_gpus, rank)
         t_gen = time.perf_counter()
-        if rank == 0 and not args.no_native_batch:
-            # rank 0 also drives the native one-process form over ALL jobs (c5_batch_native), so it casts every scan
-            all_scans = make_batch_scans(range(n_jobs))
-            my_scans = all_scans[job_range[0]:job_range[1]]
-        else:
-            my_scans = make_batch_scans(range(*job_range))
+        # every rank casts ITS block only; rank 0, which also drives the native one-process form over ALL jobs (c5_batch_native), collects
+        # the other blocks over a host-side gloo group below (round 6: rank 0 cast all 512 scans itself before, 22 s on its own)
+        my_scans = make_batch_scans(range(*job_range))
         t_gen = time.perf_counter() - t_gen
 
     import torch
@@ -664,6 +714,14 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend="gloo")
+    host_group = None  # CPU-side group: the scan gather below, and the idle barrier of the native-batch leg
+    if distributed and not args.no_batch and not args.no_native_batch:
+        host_group = dist.new_group(backend="gloo")
+        t_g = time.perf_counter()
+        all_scans = batch.gather_scans(my_scans, n_jobs, dst=0, group=host_group)
+        t_gather = time.perf_counter() - t_g
+    elif not args.no_batch and not args.no_native_batch:
+        all_scans, t_gather = my_scans, 0.0
     if args.gpus != n_gpus:
         # a launcher that started a different number of ranks than --gpus says: refuse rather than report a line for the wrong N
         if rank == 0:
@@ -816,6 +874,7 @@ def main():
               "ms_passes": [1e3 * t for t in reps], "converged_jobs": int(np.sum(tab[:, 16] == 1.0)),
               "gn_iterations_hist": {str(int(v)): int(c) for v, c in zip(*np.unique(tab[:, 17], return_counts=True))},
               "distinct_poses": int(len({tuple(np.round(r[:16], 9)) for r in tab})), "scan_generation_s": t_gen,
+              "scan_gather_to_rank0_s": (t_gather if not args.no_native_batch else None),
               "note": "one distinct seeded scan per job (seed 20241022 + 4000 + job), all against ONE map; fls_match_batch: per-job scan upload from host "
                       "memory and the result gather are inside the timed region"}
         if map_bcast is not None:
@@ -827,7 +886,7 @@ def main():
     # The other ranks idle on a CPU-side (gloo) barrier meanwhile -- an RCCL barrier would spin a kernel on the GPUs being measured.
     c5n = None
     if not args.no_batch and not args.no_native_batch:
-        idle = dist.new_group(backend="gloo") if distributed else None
+        idle = host_group
         if rank == 0:
             try:
                 c5n = bench_c5_native(m, reg, all_scans, n_gpus, share, tab if c5 is not None else None)
@@ -971,6 +1030,7 @@ def main():
                         line["cpu_baseline_ref"] = ref_line
                 except Exception as e:
                     line["cpu_baseline_ref"] = {"error": repr(e)[:200]}
+        line["legs"] = legs_from_line(line)  # LAST key on purpose: the driver keeps the tail of the line (see LEGS)
         print(json.dumps(line))
     m.close()
     if distributed:

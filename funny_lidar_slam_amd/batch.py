@@ -55,6 +55,48 @@ def gather_results(local: np.ndarray, n_jobs: int, width: int, device=None) -> n
     return table
 
 
+def gather_scans(local_scans: Sequence[np.ndarray], n_jobs: int, dst: int = 0, group=None) -> List[np.ndarray]:
+    """The scans of ALL jobs on rank `dst`, in job order; [] on the other ranks.  Every rank casts only its own block of the configs[4] scans
+    (`partition`); the native one-process form that rank `dst` also measures needs every scan, and receiving 7/8 of them over a host-side
+    (gloo) group costs a second or two where casting them again cost 20 s.  Point-to-point sends of one flat float32
+    buffer per rank; `group` must be a CPU (gloo) group -- the scans are host arrays that fls_match_batch uploads itself."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        return list(local_scans)
+    b, e = partition(n_jobs, world, rank)
+    if len(local_scans) != e - b:
+        raise ValueError("gather_scans: rank %d holds %d scans for the block [%d, %d)" % (rank, len(local_scans), b, e))
+    counts = torch.zeros(n_jobs, dtype=torch.int64)
+    for k, sc in enumerate(local_scans):
+        counts[b + k] = int(np.asarray(sc).shape[0])
+    dist.all_reduce(counts, group=group)  # every job's point count, on every rank
+    if rank != dst:
+        if int(counts[b:e].sum()) > 0:
+            flat = torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(sc, np.float32).reshape(-1, 3) for sc in local_scans], axis=0)))
+            dist.send(flat, dst=dst, group=group)
+        return []
+    out: List[np.ndarray] = [None] * n_jobs  # type: ignore[list-item]
+    out[b:e] = [np.asarray(sc, np.float32).reshape(-1, 3) for sc in local_scans]
+    for r in range(world):
+        if r == dst:
+            continue
+        rb, re_ = partition(n_jobs, world, r)
+        total = int(counts[rb:re_].sum())
+        buf = torch.empty((total, 3), dtype=torch.float32)
+        if total > 0:
+            dist.recv(buf, src=r, group=group)
+        arr, off = buf.numpy(), 0
+        for j in range(rb, re_):
+            c = int(counts[j])
+            out[j] = arr[off:off + c].copy()
+            off += c
+    return out
+
+
 def broadcast_blob(blob, src: int = 0, device=None) -> np.ndarray:
     """The map image exported on rank `src` (RegistrationInterface.ExportMap) to every rank: one broadcast of the size, one of
     the bytes (~25 MB for the 1e6-point iVox map, one RCCL broadcast over xGMI; gloo in the CPU tests).

@@ -96,6 +96,13 @@ struct DeviceExactSort {
         }
     }
     unsigned work_cap = 0, tile_cap = 0;
+    // records a workgroup of the task kernel sorts in LDS, by cloud size (kernels_exactsort.hpp, FLS_ES_LDS): FLS_ES_LDS_SMALL / FLS_ES_LDS_BIG override (A/B)
+    static unsigned lds_cap_for(const size_t n) {
+        static const unsigned small = [] { const char* e = std::getenv("FLS_ES_LDS_SMALL"); const int v = e ? std::atoi(e) : kEsLdsSmall; return unsigned(std::min(std::max(v, 64), kEsLds)); }();
+        static const unsigned big = [] { const char* e = std::getenv("FLS_ES_LDS_BIG"); const int v = e ? std::atoi(e) : kEsLds; return unsigned(std::min(std::max(v, 64), kEsLds)); }();
+        return n <= size_t(kEsTaskMax) ? small : big;
+    }
+    static unsigned task_grid(const size_t n) { return unsigned(std::min<size_t>(256, std::max<size_t>(8, n / lds_cap_for(n) + 4))); }
     void allocate(const size_t n) {
         if (!mb_host) {
             FLS_HIP(hipHostMalloc((void**)&mb_host, sizeof(EsMailbox), hipHostMallocMapped));
@@ -104,7 +111,7 @@ struct DeviceExactSort {
         }
         static const bool publish_dbg = std::getenv("FLS_ES_DEBUG") != nullptr;
         if (publish_dbg) es_debug_mailbox().store(mb_host, std::memory_order_release);
-        work_cap = unsigned(64 * (n / kEsLds + 1) + 1024);
+        work_cap = unsigned(64 * (n / kEsLdsSmall + 1) + 1024);
         tile_cap = unsigned(n / kEsTile + kEsMaxSeg + 2);
         seg_a.reserve(kEsMaxSeg); seg_b.reserve(kEsMaxSeg);
         work.reserve(work_cap);
@@ -140,7 +147,7 @@ struct DeviceExactSort {
     }
     void fused_launch(unsigned* key, unsigned* val, const size_t n, const unsigned* skip, hipStream_t s) {
         ++runs;
-        const unsigned grid = unsigned(std::min<size_t>(256, std::max<size_t>(8, n / kEsLds + 4)));
+        const unsigned grid = task_grid(n);
         static const bool dbg_marks = std::getenv("FLS_ES_DEBUG") != nullptr;
         if (dbg_marks) std::memset(mb_host->mark, 0, sizeof(mb_host->mark));
         const unsigned big = big_threshold();
@@ -152,7 +159,7 @@ struct DeviceExactSort {
         }
         if (top == 0) {
             hipLaunchKernelGGL(es_task_kernel, dim3(grid), dim3(kEsTaskThreads), 0, s, key, val, work.p, ready.p, work_cap, queue.p, Lp.p, Rl.p, st.p,
-                               dbg_marks ? mb_dev : (EsMailbox*)nullptr, unsigned(n), skip);
+                               dbg_marks ? mb_dev : (EsMailbox*)nullptr, unsigned(n), skip, lds_cap_for(n));
             return;
         }
         auto next_seq = [&]() { seq = (seq + 1u) & 0x7fffffffu; if (!seq) seq = 1u; return seq; };
@@ -170,7 +177,7 @@ struct DeviceExactSort {
             ++levels;
         }
         hipLaunchKernelGGL(es_task_kernel, dim3(grid), dim3(kEsTaskThreads), 0, s, key, val, work.p, ready.p, work_cap, queue.p, Lp.p, Rl.p, st.p,
-                           dbg_marks ? mb_dev : (EsMailbox*)nullptr, 0u, skip);
+                           dbg_marks ? mb_dev : (EsMailbox*)nullptr, 0u, skip, lds_cap_for(n));
     }
     // the stop lists of a level: one launch (es_count_scatter_kernel: tiles look back at their predecessors' published counts), or the two
     // launches it replaces (FLS_ES_LOOKBACK=0: counts, launch boundary, lists)
@@ -200,11 +207,11 @@ struct DeviceExactSort {
             FLS_HIP(hipMemsetAsync(st.p, 0, sizeof(EsState), s));
             *h_queue.p = EsQueue{0u, 0u, 1u, 0u};
             FLS_HIP(hipMemcpyAsync(queue.p, h_queue.p, sizeof(EsQueue), hipMemcpyHostToDevice, s));
-            const unsigned grid = unsigned(std::min<size_t>(256, std::max<size_t>(8, n / kEsLds + 4)));
+            const unsigned grid = task_grid(n);
             static const bool dbg_marks = std::getenv("FLS_ES_DEBUG") != nullptr;
             if (dbg_marks) std::memset(mb_host->mark, 0, sizeof(mb_host->mark));
             hipLaunchKernelGGL(es_task_kernel, dim3(grid), dim3(kEsTaskThreads), 0, s, key, val, work.p, ready.p, work_cap, queue.p, Lp.p, Rl.p, st.p,
-                               dbg_marks ? mb_dev : (EsMailbox*)nullptr, unsigned(n), (const unsigned*)nullptr);
+                               dbg_marks ? mb_dev : (EsMailbox*)nullptr, unsigned(n), (const unsigned*)nullptr, lds_cap_for(n));
             FLS_HIP(hipMemcpyAsync(h_st.p, st.p, sizeof(EsState), hipMemcpyDeviceToHost, s));
             FLS_HIP(hipGetLastError());
             return true;
@@ -239,15 +246,31 @@ struct DeviceExactSort {
         if (n_work) {
             *h_queue.p = EsQueue{0u, n_work, n_work, n_work};
             FLS_HIP(hipMemcpyAsync(queue.p, h_queue.p, sizeof(EsQueue), hipMemcpyHostToDevice, s));
-            const unsigned grid = unsigned(std::min<size_t>(256, std::max<size_t>(8, n / kEsLds + 4)));
+            const unsigned grid = task_grid(n);
             static const bool skip = std::getenv("FLS_ES_SKIP_TASKS") != nullptr;  // (bisecting aid)
             if (!skip) hipLaunchKernelGGL(es_task_kernel, dim3(grid), dim3(kEsTaskThreads), 0, s, key, val, work.p, ready.p, work_cap, queue.p, Lp.p, Rl.p, st.p,
-                                          std::getenv("FLS_ES_DEBUG") ? mb_dev : (EsMailbox*)nullptr, 0u, (const unsigned*)nullptr);
+                                          std::getenv("FLS_ES_DEBUG") ? mb_dev : (EsMailbox*)nullptr, 0u, (const unsigned*)nullptr, lds_cap_for(n));
             FLS_HIP(hipMemcpyAsync(h_queue.p, queue.p, sizeof(EsQueue), hipMemcpyDeviceToHost, s));
         }
         FLS_HIP(hipMemcpyAsync(h_st.p, st.p, sizeof(EsState), hipMemcpyDeviceToHost, s));
         FLS_HIP(hipGetLastError());
         return true;
+    }
+    void print_wg_profile() {
+        if (!mb_host) return;
+        {  // where the workgroups of the task kernel spent their time (100 MHz ticks -> us)
+            double w = 0, g = 0, l = 0, wmax = 0, bmax = 0; unsigned nt = 0, used = 0;
+            for (int b = 0; b < 256; ++b) {
+                const unsigned* q = mb_host->wg[b];
+                if (!q[0] && !q[1] && !q[2]) continue;
+                ++used; w += q[0]; g += q[1]; l += q[2]; nt += q[3];
+                wmax = std::max(wmax, double(q[0])); bmax = std::max(bmax, double(q[1]) + double(q[2]));
+            }
+            if (used)
+                std::fprintf(stderr, "[fls exact sort] task kernel, %u workgroups, mean per workgroup [us]: waiting for tasks %.1f, partitions out of global memory %.1f, LDS ranges %.1f; "
+                             "busiest workgroup %.1f us busy, longest wait %.1f us; %u tasks popped\n", used, 0.01 * w / used, 0.01 * g / used, 0.01 * l / used, 0.01 * bmax, 0.01 * wmax, nt);
+            std::memset(mb_host->wg, 0, sizeof(mb_host->wg));
+        }
     }
     // FLS_ES_DEBUG: stage stamps of the last sort (the fused form never copies EsState back)
     bool failed_after_sync_debug_only() {
@@ -264,6 +287,7 @@ struct DeviceExactSort {
                              d(3, 4), d(4, 5), d(5, 6), d(1, 6));
             }
             std::memset(mb_host->lvl, 0, sizeof(mb_host->lvl));
+            print_wg_profile();
         }
         return false;
     }
@@ -276,6 +300,7 @@ struct DeviceExactSort {
             std::fprintf(stderr, "[fls exact sort] workgroup 0, first task [us]: pop->start %.1f, global partitions %.1f, LDS load %.1f, phase A (workgroup partitions) %.1f, phase B (wave tasks) %.1f, "
                          "ranks + write-back %.1f\n", us(0, 2), us(2, 9), us(9, 10), us(10, 3), us(3, 4), us(5, 6));
         }
+        if (dbg) print_wg_profile();
         if (dbg && h_st.p)
             std::fprintf(stderr, "[fls exact sort] regime-1 levels %u, hand-over ranges %u, fail %u; task kernel: %u partitions from global memory, %u ranges (%u records) sorted in LDS\n",
                          h_st.p->level, h_st.p->n_work, h_st.p->fail, h_st.p->pad[0], h_st.p->pad[1], h_st.p->pad[2]);
@@ -343,9 +368,10 @@ struct DeviceVoxelGrid {
         const float inv = 1.0f / leaf;
         float mn[3], mx[3];
         for (int a = 0; a < 3; ++a) { mn[a] = vg_unord(hh.mn[a]); mx[a] = vg_unord(hh.mx[a]); }
-        const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1,
-                        dz = (long long)((mx[2] - mn[2]) * inv) + 1;
-        if (dx * dy * dz > (long long)INT_MAX) return false;
+        const float ex = (mx[0] - mn[0]) * inv, ey = (mx[1] - mn[1]) * inv, ez = (mx[2] - mn[2]) * inv;
+        if (!(ex < 2147483648.0f && ey < 2147483648.0f && ez < 2147483648.0f)) return false;  // (one extent of 2^31 leaves is already beyond INT_MAX; keeps the products inside int64)
+        const long long dx = (long long)ex + 1, dy = (long long)ey + 1, dz = (long long)ez + 1;
+        if (dx * dy > (long long)INT_MAX || dx * dy * dz > (long long)INT_MAX) return false;
         VgGrid g;
         g.inv = inv;
         long long div_b[3];
@@ -682,10 +708,18 @@ struct SourceFilter {
     // fls_scan_upload_raw: the RAW scan stays resident (x | y | z | intensity of raw_n points) and every fls_match_resident runs the source
     // filter itself, like the reference's Match does (icp_optimized.h:57, incremental_ndt.h:231-232) -- what bench.py times for configs[0] / [2]
     bool raw_pending = false;
+    bool withdrawn = false;  // between fls_scan_upload_raw and the next Match: no filtered scan is resident
     size_t raw_n = 0;
     float raw_leaf = 0.f;
     std::vector<float> raw_host;  // packed xyzi rows of the raw scan: only what the device declines goes back to the host filter
-    void upload_raw_only(const float* s0, size_t n0, int stride, float leaf, hipStream_t s) {
+    void upload_raw_only(const float* s0, size_t n0, int stride, float leaf, hipStream_t s, DevScan& scan, std::vector<PtI>& source) {
+        // the filtered scan of the PREVIOUS upload is gone from here on (fitness / correspondences / a map update between this call and
+        // the next fls_match_resident must not see the old scan): nothing is resident until refilter() has run
+        resident = false;
+        scan.n = 0;
+        scan.host.clear();
+        source.clear();
+        withdrawn = true;
         raw_pending = true;
         raw_n = n0;
         raw_leaf = leaf;
@@ -698,6 +732,7 @@ struct SourceFilter {
     }
     void refilter(hipStream_t s, DevScan& scan, std::vector<PtI>& source) {
         resident = false;
+        withdrawn = false;
         if (on_device && raw_n != 0 && vg.run(raw.x.p, raw.y.p, raw.z.p, raw.xyz.p + 3 * raw_n, raw_n, raw_leaf, s)) {
             scan.n = vg.n_out;
             scan.host.clear();

@@ -2,6 +2,7 @@
 // Single translation unit: device kernels (kernels_*.hpp) + host matchers (matcher*.hpp).
 // Built by csrc/Makefile:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
 // There is no CPU fallback: without a gfx950 device fls_create fails with FLS_ERR_DEVICE.
+#include <chrono>
 #include "matcher_p2plane_ivox.hpp"
 #include "matchers_kd.hpp"
 #include "matcher_ndt.hpp"
@@ -333,6 +334,27 @@ fls_status fls_debug_voxel_grid(int device_id, const float* pts, size_t n, int s
         std::vector<float> tmp;
         const std::vector<PtI> c = vg.download(nullptr, tmp);
         std::memcpy(out, c.data(), c.size() * sizeof(PtI));
+        return FLS_OK;
+    });
+}
+
+fls_status fls_debug_voxel_grid_timed(int device_id, const float* pts, size_t n, int stride, float leaf, int reps, double* ms, size_t* n_out) {
+    if (!pts || !n_out || !ms || reps <= 0 || stride < 3 || !(leaf > 0.f)) return FLS_ERR_INVALID;
+    *n_out = 0;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(device_id));
+        DevScan raw;
+        DeviceVoxelGrid vg;  // one filter object for all repetitions: the buffers are allocated by the first one, as in a matcher
+        raw.upload_raw(pts, n, stride, nullptr, true);
+        FLS_HIP(hipDeviceSynchronize());
+        for (int r = 0; r < reps; ++r) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const bool ok = n != 0 && vg.run(raw.x.p, raw.y.p, raw.z.p, raw.xyz.p + 3 * n, n, leaf, nullptr);
+            FLS_HIP(hipStreamSynchronize(nullptr));
+            ms[r] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (!ok) return FLS_ERR_STATE;
+        }
+        *n_out = vg.n_out;
         return FLS_OK;
     });
 }

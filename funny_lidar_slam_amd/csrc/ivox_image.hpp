@@ -301,7 +301,7 @@ struct IvoxImage {
         FlatHeader h{};
         std::memcpy(h.magic, "FLSIMG01", 8);
         h.want_hash = want_hash ? 1u : 0u; h.have_bricks = have_bricks ? 1u : 0u;
-        h.mask = mask; h.dir_mask = dir_mask;
+        h.mask = want_hash ? mask : 0u; h.dir_mask = have_bricks ? dir_mask : 0u;  // (a structure the image does not carry has no mask: flat_header_ok insists)
         h.used = used_slots; h.n_pts_live = n_pts_live; h.n_bricks_live = have_bricks ? n_bricks_live : 0; h.n_bricks_cap = n_bricks_cap;
         h.total_bytes = flat_bytes(h);
         return h;
@@ -324,6 +324,9 @@ struct IvoxImage {
         auto pow2m1 = [](unsigned m) { return (m & (m + 1u)) == 0u; };
         if (h.want_hash > 1u || h.have_bricks > 1u || (!h.want_hash && !h.have_bricks)) return false;
         if (!pow2m1(h.mask) || !pow2m1(h.dir_mask)) return false;
+        // a table the image does not carry has no mask either (`mask != 0` without the table made the query take the hash path into a null table),
+        // and the dense (brick) path is exactly "the image has bricks"
+        if ((!h.want_hash && h.mask != 0u) || (!h.have_bricks && (h.dir_mask != 0u || h.n_bricks_live != 0ull)) || h.use_dense != h.have_bricks) return false;
         const unsigned long long cap = (unsigned long long)n_bytes / 8ull;  // no array can hold more records than the payload has 8-byte words
         if (h.used > cap || h.n_bricks_live > cap / kBrickStride + 1 || h.n_bricks_cap > (1ull << 31) || h.n_bricks_live > h.n_bricks_cap || h.n_pts_live > h.used) return false;
         if ((unsigned long long)h.mask > cap || (unsigned long long)h.dir_mask > cap) return false;
@@ -336,7 +339,8 @@ struct IvoxImage {
         used = size_t(h.used); garbage = 0; n_pts_live = size_t(h.n_pts_live);
         table.clear(); brick_index.clear(); brick_keys.clear(); dir.clear(); dir_dirty = false; meta_cells = 0;
         cell_upd.clear(); pt_upd.clear();
-        mask = h.mask; dir_mask = h.dir_mask; n_bricks_cap = size_t(h.n_bricks_cap);
+        // (the brick bound the query kernels receive is what THIS handle allocates -- the live bricks -- not the exporter's pool size: ADVICE r5)
+        mask = h.mask; dir_mask = h.dir_mask; n_bricks_cap = have_bricks ? size_t(h.n_bricks_live) : 0;
         size_t off = sizeof(h);
         auto get = [&](void* d, size_t bytes) { if (bytes) FLS_HIP(hipMemcpyAsync(d, r + off, bytes, body, s)); off += bytes; };
         d_pts.reserve(std::max<size_t>(used, 1));

@@ -23,12 +23,12 @@
 //             kEsTaskMax records the levels above 32,768 records (FLS_ES_BIG) are PRE-ENQUEUED without a host round trip (device_voxelgrid.hpp
 //             fused_launch: a level of launches costs ~16 us whatever the size, one workgroup 3 us + 0.38 us per thousand records); beyond
 //             kEsTaskMax the host steers the levels through a mailbox as in round 4;
-//   regime 2  shorter ranges are TASKS of the persistent es_task_kernel: a workgroup partitions a range longer than kEsLds (2,048) records out
-//             of global memory and hands one child to the queue, takes a range of <= kEsLds records into LDS, runs ALL its remaining levels
+//   regime 2  shorter ranges are TASKS of the persistent es_task_kernel: a workgroup partitions a range longer than lds_cap (2,048 / 8,192 by cloud size) records out
+//             of global memory and hands one child to the queue, takes a range of <= lds_cap records into LDS, runs ALL its remaining levels
 //             there (sub-ranges above kEsCoop by the whole workgroup, the rest as wave tasks through a ticket queue: es_phase_b), then
 //             ranks the records of every final <= 16 block (= the insertion sort) and writes them back.
 // The heap-sort fallback of introsort (recursion deeper than 2 log2 n) IS reproduced for ranges that fit into LDS (es_heap_sort: real scans
-// reach it routinely); only a range still longer than kEsLds records at depth 0 makes the sort report failure (the caller takes the host
+// reach it routinely); only a range still longer than lds_cap records at depth 0 makes the sort report failure (the caller takes the host
 // path).
 #pragma once
 #include "device_common.hpp"
@@ -38,10 +38,17 @@ namespace fls {
 // (A/B r05, fls_match from host buffers: 8192 / 4096 / 2048 / 1024 records -> NDT 0.533 / 0.505 / 0.491 / 0.619 ms, ICP 0.443 / 0.415 / 0.408 / 0.404 ms.
 // One CU sorts a range at ~13 us per thousand records -- 16 waves, ~1.1 us of dependent LDS round trips per partition -- while splitting a range
 // in two out of global memory costs 3 us + 0.38 us per thousand: smaller LDS ranges on more CUs win until the queue traffic takes over)
+// Round 6: the range a workgroup takes into LDS is a RUN-TIME parameter of es_task_kernel (`lds_cap`), chosen by the size of the cloud
+// (DeviceExactSort::lds_cap_for): 2,048 records for clouds up to kEsTaskMax (every source scan: more CUs busy), 8,192 beyond (the map-side filters
+// of the kd-tree kinds, 0.2-1.6 M records).  There every hand-over between workgroups is an agent-scope release = a write-back of the XCD's L2,
+// whose cost grows with the dirty data 256 streaming workgroups keep in it: 2,048-record ranges meant 1,333 + 1,311 hand-overs for 1.55 M records
+// and es_task_kernel took 3.85 ms where 8,192-record ranges take 0.71 ms (profiles/r06_a_vg_large_bisect.txt) -- the regression between
+// BENCH_r04 and BENCH_r05 (LoamFull keyframe update 2.25 -> 5.54 ms).  FLS_ES_LDS = the capacity the LDS arrays are sized for.
 #ifndef FLS_ES_LDS
-#define FLS_ES_LDS 2048
+#define FLS_ES_LDS 8192
 #endif
-constexpr int kEsLds = FLS_ES_LDS;  // records a workgroup sorts in LDS
+constexpr int kEsLds = FLS_ES_LDS;  // records the LDS arrays hold (the largest lds_cap)
+constexpr int kEsLdsSmall = 2048;   // default lds_cap for clouds up to kEsTaskMax records
 constexpr int kEsTaskMax = 131072;  // ranges up to here are tasks of the persistent kernel; longer ones go through the level-synchronous launches
 constexpr int kEsThreshold = 16;    // _S_threshold
 constexpr int kEsTile = 2048, kEsBlock = 256, kEsItems = kEsTile / kEsBlock;
@@ -59,7 +66,7 @@ struct EsState {
     unsigned pad[3];
 };
 // what the host polls (host-mapped): written by every es_level_begin
-struct EsMailbox { unsigned seq, n_cur, n_work, fail; unsigned mark[12]; unsigned lvl[32][8]; };  // mark / lvl: stage stamps of es_task_kernel (diagnostics, FLS_ES_DEBUG): lvl[i] = {range size, 100 MHz stamps of the phases of workgroup 0's i-th partition out of global memory}
+struct EsMailbox { unsigned seq, n_cur, n_work, fail; unsigned mark[12]; unsigned lvl[32][8]; unsigned wg[256][4]; };  // wg[b] (FLS_ES_DEBUG): workgroup b's 100 MHz ticks waiting for a task | in partitions out of global memory | in LDS ranges, and its task count  // mark / lvl: stage stamps of es_task_kernel (diagnostics, FLS_ES_DEBUG): lvl[i] = {range size, 100 MHz stamps of the phases of workgroup 0's i-th partition out of global memory}
 
 __device__ __forceinline__ void es_swap_rec(unsigned* __restrict__ key, unsigned* __restrict__ val, const unsigned a, const unsigned b) {
     const unsigned ka = key[a], kb = key[b], va = val[a], vb = val[b];
@@ -356,7 +363,7 @@ es_swap_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsSeg* __
 // inside it).  From kEsTaskMax records down, ranges are therefore TASKS: a workgroup pops a range from a global queue and
 //   * partitions it itself out of global memory (16 waves, each over a contiguous slice in coalesced rounds of 64 with ballot ranks:
 //     counts -> wave bases -> stop lists -> K* disjoint swaps) and pushes the two children, or
-//   * (range <= kEsLds) takes it into LDS, where its WAVES run the same partition on sub-ranges from a local queue -- no workgroup
+//   * (range <= lds_cap) takes it into LDS, where its WAVES run the same partition on sub-ranges from a local queue -- no workgroup
 //     barrier per level, every branch advances at its own pace -- then ranks the records of every final <= 16 block (= the insertion
 //     sort) and writes the range back.
 // Hand-off between workgroups (possibly on different XCDs): the producer writes back its L2 (agent-scope release) before it publishes a
@@ -372,7 +379,7 @@ constexpr int kEsTaskThreads = 1024, kEsTaskWaves = kEsTaskThreads / 64;
 #ifndef FLS_ES_SHARE
 #define FLS_ES_SHARE 64    // (A/B r05: 384 / 192 / 96 / 64 / 48 / 32 -> 0.497 / 0.451 / 0.444 / 0.445 / 0.445 / 0.475 ms)
 #endif
-constexpr int kEsCoop = FLS_ES_COOP < FLS_ES_LDS ? FLS_ES_COOP : FLS_ES_LDS;    // sub-ranges of an LDS range longer than this are partitioned by the whole workgroup, shorter ones by single waves
+constexpr int kEsCoop = FLS_ES_COOP < FLS_ES_LDS ? FLS_ES_COOP : FLS_ES_LDS;    // sub-ranges of an LDS range longer than this are partitioned by the whole workgroup, shorter ones by single waves (never more than lds_cap: such ranges do not exist)
 constexpr int kEsShare = FLS_ES_SHARE;  // a wave hands children longer than this to the workgroup's queue (another wave takes them), shorter ones stay on its own stack
 constexpr int kEsStack = 64;     // pending workgroup-level sub-ranges (disjoint, each > kEsCoop records: at most kEsLds / kEsCoop)
 constexpr int kEsWaveStack = 48; // a wave's depth-first stack (smaller child first: <= log2(kEsCoop) + 1 pending ranges)
@@ -603,8 +610,12 @@ __global__ void __launch_bounds__(kEsTaskThreads)
 es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* __restrict__ tasks, unsigned* __restrict__ ready, const unsigned cap,
                EsQueue* __restrict__ q, unsigned* __restrict__ Lp, unsigned* __restrict__ Rl, EsState* __restrict__ st, EsMailbox* __restrict__ dbg,
                const unsigned init_n /* != 0: the whole array [0, init_n) is workgroup 0's first task (no begin launch, no queue entry) */,
-               const unsigned* __restrict__ skip /* nullable; *skip != 0: the caller's plan was refused on the device, nothing to sort */) {
+               const unsigned* __restrict__ skip /* nullable; *skip != 0: the caller's plan was refused on the device, nothing to sort */,
+               const unsigned lds_cap /* ranges up to this many records (<= kEsLds) are sorted in LDS */) {
     if (skip != nullptr && *skip != 0u) return;
+    unsigned pf_wait = 0u, pf_glob = 0u, pf_lds = 0u, pf_tasks = 0u, pf_t = 0u;  // (diagnostics: dbg != nullptr)
+#define ES_PF(acc) do { if (dbg && threadIdx.x == 0) { const unsigned now_ = (unsigned)__builtin_amdgcn_s_memrealtime(); acc += now_ - pf_t; pf_t = now_; } } while (0)
+    if (dbg && threadIdx.x == 0) pf_t = (unsigned)__builtin_amdgcn_s_memrealtime();
 #define ES_MARK(k) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0 && dbg->mark[k] == 0u) dbg->mark[k] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
     using namespace es_lds;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -652,10 +663,12 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
         if (s_state == 2u) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the producer's records, not this CU's cached copies
         ES_MARK(2);
+        ES_PF(pf_wait);
+        ++pf_tasks;
         unsigned first = s_first, last = s_last, m = last - first;
         int depth = s_depth;
         bool dead = false;  // the range hit the depth limit (sort failed) -- nothing left to do for this task
-        while (m > (unsigned)kEsLds) {
+        while (m > lds_cap) {
             // ============ a workgroup partitions the range out of global memory, hands one child to the queue and keeps the other:
             // no queue round trip (pop, acquire, ~10 atomics) on the critical path of a lopsided recursion ============
             if (depth == 0) { if (t == 0) atomicExch(&st->fail, 1u); dead = true; break; }  // (introsort switches to heap sort here)
@@ -758,11 +771,12 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
             }
         }
         ES_MARK(9);
+        ES_PF(pf_glob);
         if (!dead && m >= 2u) {
             if (t == 0) { atomicAdd(&st->pad[1], 1u); atomicAdd(&st->pad[2], m); }  // diagnostics: ranges sorted in LDS, their records
             // ============ the range lives in LDS; its waves partition sub-ranges from a local queue ============
             for (unsigned i = t; i < m; i += kEsTaskThreads) { sk[i] = key[first + i]; sv[i] = val[first + i]; }
-            for (unsigned i = t; i < (unsigned)(kEsLds / 32 + 2); i += kEsTaskThreads) bmask[i] = 0u;
+            for (unsigned i = t; i < (m >> 5) + 2u; i += kEsTaskThreads) bmask[i] = 0u;  // (the words records 0 .. m can touch)
             __syncthreads();
             for (unsigned i = t; i < (unsigned)kEsLocalQ; i += kEsTaskThreads) qt[i] = 0u;
             if (t == 0) {
@@ -902,8 +916,14 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
         __syncthreads();
         if (t == 0) atomicSub(&q->open, 1u);  // (after the children were pushed)
         ES_MARK(7);
+        ES_PF(pf_lds);
     }
     ES_MARK(8);
+    if (dbg && threadIdx.x == 0 && blockIdx.x < 256u) {
+        ES_PF(pf_wait);
+        dbg->wg[blockIdx.x][0] = pf_wait; dbg->wg[blockIdx.x][1] = pf_glob; dbg->wg[blockIdx.x][2] = pf_lds; dbg->wg[blockIdx.x][3] = pf_tasks;
+    }
+#undef ES_PF
 #undef ES_MARK
 }
 

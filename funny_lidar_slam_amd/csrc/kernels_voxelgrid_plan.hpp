@@ -141,11 +141,13 @@ vg_minmax_plan(const float* __restrict__ x, const float* __restrict__ y, const f
         for (int a = 0; a < 3; ++a) { mn[a] = vg_unord_dev(umn[a]); mx[a] = vg_unord_dev(umx[a]); }
         // voxel_grid.hpp:69-74: dx = static_cast<int64_t>((max_p[0] - min_p[0]) * inverse_leaf_size_[0]) + 1, refuse if dx dy dz > INT_MAX
         const float ex = (mx[0] - mn[0]) * inv, ey = (mx[1] - mn[1]) * inv, ez = (mx[2] - mn[2]) * inv;
-        const float lim = 4.0e9f;
+        // one extent of 2^31 leaves or more already makes dx dy dz > INT_MAX: refuse there, and every product below stays inside int64
+        // (the former bound 4e9 let dx dy wrap for two extents of ~3.1e9 leaves)
+        const float lim = 2147483648.0f;
         bool too_small = !(ex < lim && ey < lim && ez < lim);
         if (!too_small) {
             const long long dx = (long long)ex + 1, dy = (long long)ey + 1, dz = (long long)ez + 1;
-            const long long dxy = dx * dy;  // < 1.6e19 / 2: no overflow below the limit
+            const long long dxy = dx * dy;  // <= (2^31 + 1)^2 < 2^63
             too_small = dxy > 0x7fffffffLL || dxy * dz > 0x7fffffffLL;
         }
         if (too_small) p.status = kVgLeafTooSmall;

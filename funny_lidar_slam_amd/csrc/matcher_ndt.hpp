@@ -626,7 +626,7 @@ struct NdtMatcher final : fls_matcher {
         return FLS_OK;
     }
     fls_status scan_upload_raw(const float* s0, size_t n0, const float*, size_t, int stride) override {
-        src_filter.upload_raw_only(s0, n0, stride, p.source_cloud_filter_size, stream);
+        src_filter.upload_raw_only(s0, n0, stride, p.source_cloud_filter_size, stream, scan, source);  // (no filtered scan is resident until the next Match: fitness answers FLS_ERR_STATE)
         return FLS_OK;
     }
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {
@@ -714,8 +714,13 @@ struct NdtMatcher final : fls_matcher {
     fls_status prepare_batch() override { FLS_HIP(hipStreamSynchronize(stream)); return have_map ? FLS_OK : FLS_ERR_STATE; }
     fls_status fitness(float max_range, float* score) override {
         if (!p.is_localization_mode) { *score = std::numeric_limits<float>::max(); return FLS_OK; }  // :346-348
-        if (!have_fitness_grid || !have_final) return FLS_ERR_STATE;
-        return fitness_score_device(*this, fitness_grid, scan, final_T, max_range, score);
+        if (!have_fitness_grid || src_filter.withdrawn) return FLS_ERR_STATE;
+        // A Match that stops at the effective-point floor returns before `final_transformation_ = T` (incremental_ndt.h:306-309 vs :335): the score is then
+        // taken with the PREVIOUS Match's transformation and the new source cloud -- and, when no Match of this matcher has got that far yet, with
+        // the value-initialised member `final_transformation_{}` (:395), the zero matrix in the compiled reference: every point lands on the origin.
+        // Found by running the localization-mode random scenarios on the GPU (round 6, `lfuzz3`: FLS_ERR_STATE where the reference answers).
+        static const double zero_T[16] = {0.0};
+        return fitness_score_device(*this, fitness_grid, scan, have_final ? final_T : zero_T, max_range, score);
     }
     int correspondences(int, int32_t* ids, uint8_t* cnt, uint8_t* valid, size_t cap) override {
         const size_t n = std::min(cap, scan.n);

@@ -591,7 +591,13 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
             // empty planar cloud: H = g = 0 -> dx = 0 -> stop rule fires in iteration 0, n_valid = 0 < 50 -> false (:201-203)
             stats.iterations = 1; stats.converged = 0;
             if (out) *out = stats;
+            // the iteration log of that one iteration (fls_get_iteration_log; the oracle keeps the same row): the input pose, no valid point, no residual
             log_n = 0; log_stale = false;
+            if (h_state.p) {
+                std::memcpy(h_state.p->log_T[0], T, sizeof(double) * 16);
+                h_state.p->log_nv[0] = 0; h_state.p->log_res[0] = 0.0; h_state.p->iter = 1;
+                log_n = 1;
+            }
             return FLS_NOT_CONVERGED;
         }
         if (!borrowed) refresh_image();
@@ -809,7 +815,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         size_t nb = 0;
         const size_t used_now = live_counts(nb);
         IvoxImage::FlatHeader h = image.flat_header(used_now, nb);
-        h.kind = unsigned(kind); h.is_first = is_first ? 1u : 0u; h.use_dense = use_dense ? 1u : 0u; h.resolution = ivox.resolution;
+        h.kind = unsigned(kind); h.is_first = is_first ? 1u : 0u; h.use_dense = h.have_bricks; h.resolution = ivox.resolution;
         if (cap < size_t(h.total_bytes)) return FLS_ERR_RANGE;
         image.export_flat(h, dst, on_device != 0, stream);
         return FLS_OK;
@@ -825,7 +831,7 @@ struct P2PlaneIvoxMatcher final : fls_matcher {
         replica_only = false;
         ivox.clear();
         image_built = false; image_dirty = true;  // (an import that fails half-way leaves an empty map that rebuilds its image)
-        use_dense = h.use_dense != 0;
+        use_dense = h.have_bricks != 0;  // (derived, not trusted: the query takes the brick path exactly when the image carries bricks)
         image.import_flat(h, src, on_device != 0, stream);
         // the contents are as untrusted as the header: no {begin, count} may leave the point array, no directory entry may name a missing brick
         d_counter_img.reserve(1);

@@ -102,7 +102,8 @@ struct IcpMatcher final : fls_matcher {
     }
     fls_status scan_upload_raw(const float* s0, size_t n0, const float*, size_t, int stride) override {
         raw_n = n0;
-        src_filter.upload_raw_only(s0, n0, stride, p.source_cloud_filter_size, stream);
+        src_filter.upload_raw_only(s0, n0, stride, p.source_cloud_filter_size, stream, scan, source);
+        have_final = false;  // (no filtered scan is resident until the next Match: fls_get_fitness_score answers FLS_ERR_STATE)
         return FLS_OK;
     }
     fls_status match_resident(double* T, int update_map, fls_stats* out) override {

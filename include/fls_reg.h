@@ -244,7 +244,10 @@ fls_status fls_match_resident(fls_handle h, double T_colmajor[16], int update_ma
 /* fls_scan_upload_raw (revision 5): like fls_scan_upload, but for the kinds whose Match filters its source cloud first (IcpOptimized
  * icp_optimized.h:57, IncrementalNDT incremental_ndt.h:231-232) the RAW cloud stays resident and EVERY fls_match_resident that follows runs
  * that pcl::VoxelGrid itself before the iterations -- the whole of the reference's Match with its input already in device memory (what
- * bench.py reports for BASELINE configs[0] / [2]).  The other kinds: identical to fls_scan_upload. */
+ * bench.py reports for BASELINE configs[0] / [2]).  The other kinds: identical to fls_scan_upload.
+ * Contract: the call withdraws the previously resident FILTERED scan at once -- between it and the next fls_match_resident the handle holds no
+ * source cloud (fls_get_correspondences returns 0 rows, fls_get_fitness_score FLS_ERR_STATE until a Match has run on the new scan); it keeps one
+ * packed host copy of the raw cloud (what the device filter declines goes to the host filter) and returns after the upload has completed. */
 fls_status fls_scan_upload_raw(fls_handle h, const float* src0, size_t n0, const float* src1, size_t n1, int stride_floats);
 
 /* ---- introspection (parity tests, DLOG-equivalent) ---------------------------------------------- */
@@ -285,6 +288,9 @@ fls_status fls_debug_fullpiv_qr6(int device_id, const double* H, const double* g
  * point / PCL's "leaf size too small" case / n > 4,194,304: the matchers then run the host filter), FLS_ERR_INVALID when
  * out is too small (*n_out is still set).  Contract: csrc/kernels_voxelgrid.hpp; tests/test_gpu_voxelgrid.py.          */
 fls_status fls_debug_voxel_grid(int device_id, const float* pts, size_t n, int stride, float leaf, float* out, size_t cap, size_t* n_out);
+/* measurement hook (tools/gpu_vg_large.py): the same filter `reps` times on one resident cloud, wall-clock milliseconds of every repetition (the
+ * call's own host waits included, upload excluded) in ms[0 .. reps); the first repetition allocates.                                      */
+fls_status fls_debug_voxel_grid_timed(int device_id, const float* pts, size_t n, int stride, float leaf, int reps, double* ms, size_t* n_out);
 /* Test hook of the device VoxelGrid's sort (csrc/kernels_exactsort.hpp): sorts the n records {key[i], val[i]} in place BY KEY ONLY, leaving
  * records of equal key in exactly the order libstdc++'s std::sort leaves them in (what pcl::VoxelGrid's leaf sums depend on,
  * include/common/pointcloud_utility.h:216-271).  on_host = 1: std::sort on the host (the reference permutation, no GPU needed);

@@ -36,6 +36,13 @@ blob = np.frombuffer(bytes(range(256)) * 4099, dtype=np.uint8).copy() if rank ==
 got = batch.broadcast_blob(blob, src=0)
 assert got.dtype == np.uint8 and got.size == 256 * 4099 and int(got[1000:1256].astype(np.int64).sum()) == sum(range(256)), got.size
 b, e = batch.partition(n_jobs, world, rank)
+# every rank casts its own block of scans, rank 0 collects all of them in job order (bench.py: the native one-process leg of configs[4])
+mk = lambda j: (np.arange(3 * (100 + 7 * j), dtype=np.float32).reshape(-1, 3) + np.float32(j))   # ragged on purpose
+allsc = batch.gather_scans([mk(j) for j in range(b, e)], n_jobs, dst=0)
+if rank == 0:
+    assert len(allsc) == n_jobs and all(np.array_equal(allsc[j], mk(j)) for j in range(n_jobs))
+else:
+    assert allsc == []
 local = batch.run_block(worker, b, e)
 table = batch.gather_results(local, n_jobs, batch.RESULT_WIDTH)
 if rank == 0:

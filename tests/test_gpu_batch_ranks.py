@@ -115,6 +115,43 @@ def test_bare_bench_gpus_2_reports_two_ranks(built):
     print("bare --gpus 2:", {k: line[k] for k in ("value", "n_gpus", "ms_per_step")}, "c5", c5["scans_per_s"], "native", c5n["scans_per_s"], c5["map_image_broadcast"])
 
 
+def test_bare_bench_gpus_8_rehearsal_on_one_device(built):
+    """The 8-rank run rehearsed before an 8-GPU node sees it (VERDICT r5 missing #1 / next #4): `python bench.py --gpus 8` with no launcher, eight
+    gloo ranks on the one visible GPU (FLS_BENCH_SHARE_DEVICE=1), 64 jobs = 8 per rank.  Asserted: the line says n_gpus 8 and 8 jobs per rank, the
+    map image was imported on the other seven ranks, every rank cast only its own block of scans and rank 0 collected the rest (gather_scans),
+    the sharded table equals the native one-process table over the device list [0] * 8 bit for bit, and the whole run stays under two minutes.
+    The RCCL twin of this cannot exist on one device -- RCCL refuses two ranks on one GPU ("Duplicate GPU detected") -- so the nccl branch stays
+    at world size 1 (test_rccl_path_at_world_size_1) until the driver's SCALE run; no scaling curve has been measured in any round."""
+    import json
+    import time
+
+    assert _lib.device_count() >= 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FLS_BENCH_SHARE_DEVICE"] = "1"
+    env["GPU_MAX_HW_QUEUES"] = "4"  # eight processes x (1 + 8 lanes) streams on one device
+    t0 = time.perf_counter()
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--no-extras",
+                          "--no-cpu-baseline", "--batch-jobs-total", "64"], env=env, capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, run.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 6 and line["scaling"] == "weak" and line["distributed_backend"] == "gloo"
+    assert abs(line["value"] - 8 * 6 / (line["ms_per_step"] * 6e-3)) < 1e-6 * line["value"]  # whole-job throughput over all eight ranks
+    c5, c5n = line["c5_batch"], line["c5_batch_native"]
+    assert c5["jobs"] == 64 and c5["jobs_per_gpu"] == 8 and c5["converged_jobs"] == 64 and c5["distinct_poses"] == 64
+    mb = c5["map_image_broadcast"]
+    assert mb["image_MB"] > 10.0 and mb["import_ms_max_over_ranks"] > 0.0, mb  # (rank 0 imports nothing: the maximum is an importing rank's)
+    assert c5["scan_gather_to_rank0_s"] is not None and c5["scan_gather_to_rank0_s"] < 30.0
+    assert "error" not in c5n, c5n
+    assert c5n["jobs"] == 64 and c5n["devices"] == [0] * 8 and c5n["converged_jobs"] == 64 and c5n["table_equals_torch_form_bitwise"] is True
+    assert "legs" in line and list(line)[-1] == "legs"
+    assert wall < 120.0, wall
+    print("bare --gpus 8 (one device):", {k: line[k] for k in ("value", "n_gpus", "ms_per_step")}, "c5", c5["scans_per_s"], "native", c5n["scans_per_s"], mb,
+          "scan gather %.2f s, wall %.0f s" % (c5["scan_gather_to_rank0_s"], wall))
+
+
 def test_rccl_path_at_world_size_1(built):
     """The RCCL branch of bench.py executes ONCE before any 8-GPU node sees it (VERDICT r4 missing #1 / next #2): under torch.distributed.run with
     one rank the process group is created with backend nccl and device_id, the map image is exported into a CUDA tensor and broadcast there,

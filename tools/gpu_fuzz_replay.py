@@ -1,38 +1,40 @@
-"""HIP path vs the CPU oracle on the seeded random mapping-mode scenarios of tests/refpin.py::make_fuzz_scenario -- the scenarios on which the
-oracle was checked against the compiled reference (profiles/r05_ref_pin_fuzz_200_scenarios.log), with the assertions of
-tests/test_gpu_mapping_replay.py::run_replay after every frame (return value, iterations, per-iteration n_valid / pose, flags, counts, ids, map sizes).
-usage: python tools/gpu_fuzz_replay.py [first_seed [n_seeds]]        (default 0 24; ~1-2 s per scenario)
-STATUS: written at the very end of round 5; the last seconds of the round's GPU budget ran seeds 0-3 (one per kind): all four equal the oracle
-through every frame (profiles/r05_late_gpu_fuzz_replay_first_seeds.log).  Seeds from 4 on have not been run on a GPU."""
+"""HIP path vs the CPU oracle on the scenarios the oracle was pinned on against the compiled reference (tests/refpin.py), on a GPU box:
+    python tools/gpu_fuzz_replay.py mapping [first [count]]   seeded random mapping-mode replays `fuzz<seed>` (kind by seed % 4; ~1-2 s each)
+    python tools/gpu_fuzz_replay.py long    [first [count]]   `fuzzL<seed>`: 8-14 frames each
+    python tools/gpu_fuzz_replay.py loc     [first [count]]   localization mode + GetFitnessScore, `lfuzz<seed>`
+    python tools/gpu_fuzz_replay.py deg                       the 13 degenerate scenarios (+ the ICP <= 10 points abort)
+Per frame: the assertions of tests/gpu_scenarios.py::run_scenario.  One line per scenario, `failed:` list at the end, exit status 1 if any failed.
+(`python tools/gpu_fuzz_replay.py <first> <count>` = `mapping <first> <count>`, the round-5 form.)"""
 import os, sys, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests import refpin, util
-from tests.test_gpu_mapping_replay import run_replay
+from tests import gpu_scenarios
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+args = sys.argv[1:]
+what = "mapping"
+if args and not args[0].lstrip("-").isdigit():
+    what = args.pop(0)
+first = int(args[0]) if len(args) > 0 else 0
+count = int(args[1]) if len(args) > 1 else 24
+if what == "deg":
+    names = list(gpu_scenarios.DEGENERATE) + ["deg_icp_le10"]
+else:
+    prefix = {"mapping": "fuzz", "long": "fuzzL", "loc": "lfuzz"}[what]
+    names = [f"{prefix}{s}" for s in range(first, first + count)]
 bad = []
-for seed in range(first, first + count):
-    sc = refpin.make_fuzz_scenario(seed)
+t_all = time.perf_counter()
+for name in names:
     t0 = time.perf_counter()
     try:
-        if "ivox_capacity" in sc:
-            # the LRU capacity is a constructor constant of the reference (ivox_map.h); the handle takes it through its test hook
-            os.environ["FLS_IVOX_CAPACITY"] = str(sc["ivox_capacity"])
-            orig = util.oracle_for
-            def with_cap(mode, y, loc=False, _cap=sc["ivox_capacity"]):
-                o = orig(mode, y, loc); o.set_ivox_capacity(_cap); return o
-            util.oracle_for = with_cap
-        r, hist = run_replay(sc["name"], r=sc)
-        print(seed, sc["mode"], "OK", "ok=", [int(h["ok"]) for h in hist], "iters=", [h["iters"] for h in hist], "upd=", [h["upd"] for h in hist],
+        sc = gpu_scenarios.refpin.make_scenario(name)
+        hist = gpu_scenarios.run_scenario(name, sc)
+        print(name, sc["mode"], "OK", "ok=", [h["ok"] if h["ok"] is None else int(h["ok"]) for h in hist], "iters=", [h["iters"] for h in hist], "upd=", [h["upd"] for h in hist],
+              ("fitness= " + " ".join(f"{h['fitness']:.6g}" for h in hist if "fitness" in h)) if any("fitness" in h for h in hist) else "",
               f"{time.perf_counter() - t0:.1f}s", flush=True)
-    except Exception as e:
-        bad.append(seed)
-        print(seed, sc["mode"], "FAIL", repr(e)[:400], flush=True)
-        traceback.print_exc(limit=2)
-    finally:
-        if "ivox_capacity" in sc:
-            os.environ.pop("FLS_IVOX_CAPACITY", None)
-            util.oracle_for = orig
-print("failed seeds:", bad)
+    except BaseException as e:  # (pytest.raises failures derive from BaseException)
+        if isinstance(e, KeyboardInterrupt):
+            raise
+        bad.append(name)
+        print(name, "FAIL", repr(e)[:400], flush=True)
+        traceback.print_exc(limit=3)
+print(f"{what}: {len(names) - len(bad)} of {len(names)} scenarios equal to the oracle in {time.perf_counter() - t_all:.0f} s; failed: {bad}", flush=True)
 sys.exit(1 if bad else 0)
