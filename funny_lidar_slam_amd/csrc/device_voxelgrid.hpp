@@ -15,6 +15,11 @@
 
 namespace fls {
 
+// blocks of vg_minmax (six header atomics each, all on one line): 48 up to 200 k points as in rounds 2-5 ("few blocks"), one per 4,096 points beyond, at
+// most 256.  Round 6: 48 blocks left a 1.55 M-point keyframe deque at 127 points per thread, 58 us in the trace (17 us with 256 blocks); 256 blocks for
+// EVERY size cost the 115,200-point scans 30 us of serialised atomics (the index-order A/B legs, +12 %: tools/bench_diff.py caught it).
+inline int minmax_blocks(const size_t n) { return int(std::min<size_t>(256, std::max<size_t>(48, n / 4096))); }
+
 // stable LSD radix sort of {key, value} pairs (8 bits per pass; values keep their input order among equal keys)
 struct DevicePairSort {
     DevBuf<unsigned> keys, vals;  // ping | pong
@@ -102,7 +107,20 @@ struct DeviceExactSort {
         static const unsigned big = [] { const char* e = std::getenv("FLS_ES_LDS_BIG"); const int v = e ? std::atoi(e) : kEsLds; return unsigned(std::min(std::max(v, 64), kEsLds)); }();
         return n <= size_t(kEsTaskMax) ? small : big;
     }
-    static unsigned task_grid(const size_t n) { return unsigned(std::min<size_t>(256, std::max<size_t>(8, n / lds_cap_for(n) + 4))); }
+    // one workgroup per CU at most; as many as there are 2,048-record pieces -- NOT n / lds_cap: with 8,192-record LDS ranges that left the 475,200-record
+    // deque of IcpOptimized to 62 workgroups, five ranges of ~76 us each in a row on the busiest one (profiles/r06_vg_large_cloud_filters.txt)
+    static unsigned task_grid(const size_t n) {
+        static const size_t cap = [] { const char* e = std::getenv("FLS_ES_GRID"); const int v = e ? std::atoi(e) : 256; return size_t(std::min(std::max(v, 8), 256)); }();  // (A/B)
+        return unsigned(std::min<size_t>(cap, std::max<size_t>(8, n / kEsLdsSmall + 4)));
+    }
+    // clouds beyond kEsTaskMax records: ranges longer than this stay with the level-synchronous launches (the host steers them), shorter ones are tasks.
+    // kEsTaskMax itself until round 6; the deepest chain of one-workgroup partitions below a 131,072-record range (~290 us at 3 us + 0.38 us per thousand
+    // records and 13/16 splits) was the task kernel's critical path.  Measured with the ticket queue, 32,768 / 65,536 / 131,072: planar deque 0.80 / 0.75 /
+    // 0.93 ms, IcpOptimized deque 0.48 / 0.53 / 0.65 ms, corner deque 0.37 / 0.42 / 0.44 ms (profiles/r06_h_*) -- FLS_ES_HANDOVER for A/B
+    static unsigned handover_threshold() {
+        static const unsigned v = [] { const char* e = std::getenv("FLS_ES_HANDOVER"); const int x = e ? std::atoi(e) : 32768; return unsigned(std::min(std::max(x, 4096), kEsTaskMax)); }();
+        return v;
+    }
     void allocate(const size_t n) {
         if (!mb_host) {
             FLS_HIP(hipHostMalloc((void**)&mb_host, sizeof(EsMailbox), hipHostMallocMapped));
@@ -220,10 +238,10 @@ struct DeviceExactSort {
         EsSeg* prev = seg_a.p;
         EsSeg* cur = seg_b.p;
         hipLaunchKernelGGL(es_level_begin, dim3(1), dim3(256), 0, s, key, val, unsigned(n), (const EsSeg*)prev, cur, work.p, work_cap, (const unsigned*)Lp.p,
-                           (const unsigned*)Rl.p, st.p, mb_dev, next_seq(), 1, tile_seg.p, tile_cap, unsigned(kEsTaskMax), 0, (EsQueue*)nullptr, (const unsigned*)nullptr);
-        // regime 1 (ranges longer than kEsTaskMax: only clouds beyond 131 k points get here)
+                           (const unsigned*)Rl.p, st.p, mb_dev, next_seq(), 1, tile_seg.p, tile_cap, handover_threshold(), 0, (EsQueue*)nullptr, (const unsigned*)nullptr);
+        // regime 1 (ranges longer than the hand-over threshold: only clouds beyond 131 k points get here)
         int expected = 0;
-        for (size_t m = n; m > size_t(kEsTaskMax); m = (m + 1) / 2) ++expected;
+        for (size_t m = n; m > size_t(handover_threshold()); m = (m + 1) / 2) ++expected;
         int chunk = expected ? expected + 1 : 0;
         for (;;) {
             for (int c = 0; c < chunk; ++c) {
@@ -232,7 +250,7 @@ struct DeviceExactSort {
                                    (const unsigned*)Lp.p, (const unsigned*)Rl.p);
                 std::swap(prev, cur);
                 hipLaunchKernelGGL(es_level_begin, dim3(1), dim3(256), 0, s, key, val, unsigned(n), (const EsSeg*)prev, cur, work.p, work_cap, (const unsigned*)Lp.p,
-                                   (const unsigned*)Rl.p, st.p, mb_dev, next_seq(), 0, tile_seg.p, tile_cap, unsigned(kEsTaskMax), 0, (EsQueue*)nullptr, (const unsigned*)nullptr);
+                                   (const unsigned*)Rl.p, st.p, mb_dev, next_seq(), 0, tile_seg.p, tile_cap, handover_threshold(), 0, (EsQueue*)nullptr, (const unsigned*)nullptr);
                 ++levels;
             }
             FLS_HIP(hipGetLastError());
@@ -269,6 +287,15 @@ struct DeviceExactSort {
             if (used)
                 std::fprintf(stderr, "[fls exact sort] task kernel, %u workgroups, mean per workgroup [us]: waiting for tasks %.1f, partitions out of global memory %.1f, LDS ranges %.1f; "
                              "busiest workgroup %.1f us busy, longest wait %.1f us; %u tasks popped\n", used, 0.01 * w / used, 0.01 * g / used, 0.01 * l / used, 0.01 * bmax, 0.01 * wmax, nt);
+            // the eight busiest workgroups, one by one
+            std::vector<int> order;
+            for (int b = 0; b < 256; ++b) if (mb_host->wg[b][1] || mb_host->wg[b][2]) order.push_back(b);
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return mb_host->wg[a][1] + mb_host->wg[a][2] > mb_host->wg[b][1] + mb_host->wg[b][2]; });
+            for (size_t i = 0; i < order.size() && i < 8; ++i) {
+                const unsigned* q = mb_host->wg[order[i]];
+                std::fprintf(stderr, "[fls exact sort]   workgroup %3d: %u tasks, wait %.1f, global %.1f, LDS %.1f us | longest LDS range %.1f us (%u records) | longest global chain %.1f us (from %u records)\n",
+                             order[i], q[3], 0.01 * q[0], 0.01 * q[1], 0.01 * q[2], 0.01 * q[4], q[5], 0.01 * q[6], q[7]);
+            }
             std::memset(mb_host->wg, 0, sizeof(mb_host->wg));
         }
     }
@@ -360,7 +387,7 @@ struct DeviceVoxelGrid {
         FLS_HIP(hipMemcpyAsync(d_hdr.p, &h_hdr.p[0], sizeof(VgHeader), hipMemcpyHostToDevice, s));
         const int ni = int(n);
         const int nb1 = (ni + kVgBlock - 1) / kVgBlock, nb2 = (ni + kVgScanBlock - 1) / kVgScanBlock;
-        hipLaunchKernelGGL(vg_minmax, dim3(unsigned(std::min(nb1, 48))), dim3(kVgBlock), 0, s, x, y, z, ni, d_hdr.p);  // few blocks: six header atomics each
+        hipLaunchKernelGGL(vg_minmax, dim3(unsigned(std::min(nb1, minmax_blocks(n)))), dim3(kVgBlock), 0, s, x, y, z, ni, d_hdr.p);
         FLS_HIP(hipMemcpyAsync(&h_hdr.p[1], d_hdr.p, sizeof(VgHeader), hipMemcpyDeviceToHost, s));
         FLS_HIP(hipStreamSynchronize(s));
         const VgHeader& hh = h_hdr.p[1];
@@ -512,7 +539,7 @@ struct DeviceGridBuilder {
         h_hdr.p[0].n_out = 0u; h_hdr.p[0].n_bad = 0u;
         FLS_HIP(hipMemcpyAsync(d_hdr.p, &h_hdr.p[0], sizeof(VgHeader), hipMemcpyHostToDevice, s));
         const int ni = int(n), nb = (ni + kVgBlock - 1) / kVgBlock;
-        hipLaunchKernelGGL(vg_minmax, dim3(unsigned(std::min(nb, 48))), dim3(kVgBlock), 0, s, x, y, z, ni, d_hdr.p);
+        hipLaunchKernelGGL(vg_minmax, dim3(unsigned(std::min(nb, minmax_blocks(n)))), dim3(kVgBlock), 0, s, x, y, z, ni, d_hdr.p);
         FLS_HIP(hipMemcpyAsync(&h_hdr.p[1], d_hdr.p, sizeof(VgHeader), hipMemcpyDeviceToHost, s));
         FLS_HIP(hipStreamSynchronize(s));
         const VgHeader& hh = h_hdr.p[1];

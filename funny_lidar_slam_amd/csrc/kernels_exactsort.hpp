@@ -39,24 +39,24 @@ namespace fls {
 // One CU sorts a range at ~13 us per thousand records -- 16 waves, ~1.1 us of dependent LDS round trips per partition -- while splitting a range
 // in two out of global memory costs 3 us + 0.38 us per thousand: smaller LDS ranges on more CUs win until the queue traffic takes over)
 // Round 6: the range a workgroup takes into LDS is a RUN-TIME parameter of es_task_kernel (`lds_cap`), chosen by the size of the cloud
-// (DeviceExactSort::lds_cap_for): 2,048 records for clouds up to kEsTaskMax (every source scan: more CUs busy), 8,192 beyond (the map-side filters
-// of the kd-tree kinds, 0.2-1.6 M records).  There every hand-over between workgroups is an agent-scope release = a write-back of the XCD's L2,
-// whose cost grows with the dirty data 256 streaming workgroups keep in it: 2,048-record ranges meant 1,333 + 1,311 hand-overs for 1.55 M records
-// and es_task_kernel took 3.85 ms where 8,192-record ranges take 0.71 ms (profiles/r06_a_vg_large_bisect.txt) -- the regression between
-// BENCH_r04 and BENCH_r05 (LoamFull keyframe update 2.25 -> 5.54 ms).  FLS_ES_LDS = the capacity the LDS arrays are sized for.
+// (DeviceExactSort::lds_cap_for): 2,048 records for clouds up to kEsTaskMax (every source scan: more CUs busy), 4,096 beyond (the map-side filters
+// of the kd-tree kinds, 0.2-1.6 M records; measured 2,048 / 4,096 / 8,192: planar deque 0.83 / 0.80 / 0.80 ms, IcpOptimized deque 0.48 / 0.48 / 0.52 ms,
+// profiles/r06_g_*).  FLS_ES_LDS = the capacity the LDS arrays are sized for.
+// (The regression between BENCH_r04 and BENCH_r05 -- LoamFull keyframe update 2.25 -> 5.54 ms -- showed up as "2,048-record ranges are 3.6x slower than
+// 8,192-record ranges on 1.55 M records"; the cause was not the range size but the task queue's pop, see es_task_kernel: the ticket queue.)
 #ifndef FLS_ES_LDS
-#define FLS_ES_LDS 8192
+#define FLS_ES_LDS 4096
 #endif
 constexpr int kEsLds = FLS_ES_LDS;  // records the LDS arrays hold (the largest lds_cap)
 constexpr int kEsLdsSmall = 2048;   // default lds_cap for clouds up to kEsTaskMax records
 constexpr int kEsTaskMax = 131072;  // ranges up to here are tasks of the persistent kernel; longer ones go through the level-synchronous launches
 constexpr int kEsThreshold = 16;    // _S_threshold
 constexpr int kEsTile = 2048, kEsBlock = 256, kEsItems = kEsTile / kEsBlock;
-constexpr int kEsMaxSeg = 64;       // regime-1 ranges of one level (n / kEsTaskMax for n <= 4 Mi, with room)
+constexpr int kEsMaxSeg = 192;      // regime-1 ranges of one level (n / hand-over threshold: 128 for 4 Mi records at 32,768, with room)
 
 struct EsSeg { unsigned first, last; int depth; unsigned pivot, nL, nR, K, tile0; };
 struct EsWork { unsigned first, last; int depth, pad; };
-struct EsQueue { unsigned head, tail, open, n_init; };  // the task kernel's queue (entries below n_init are ready without a flag)
+struct alignas(16) EsQueue { unsigned head, tail, open, n_init; };  // the task kernel's queue (entries below n_init are ready without a flag)
 struct EsState {
     unsigned n_cur;     // regime-1 ranges of the level in flight
     unsigned n_tiles;   // their tiles
@@ -66,8 +66,12 @@ struct EsState {
     unsigned pad[3];
 };
 // what the host polls (host-mapped): written by every es_level_begin
-struct EsMailbox { unsigned seq, n_cur, n_work, fail; unsigned mark[12]; unsigned lvl[32][8]; unsigned wg[256][4]; };  // wg[b] (FLS_ES_DEBUG): workgroup b's 100 MHz ticks waiting for a task | in partitions out of global memory | in LDS ranges, and its task count  // mark / lvl: stage stamps of es_task_kernel (diagnostics, FLS_ES_DEBUG): lvl[i] = {range size, 100 MHz stamps of the phases of workgroup 0's i-th partition out of global memory}
+struct EsMailbox { unsigned seq, n_cur, n_work, fail; unsigned mark[12]; unsigned lvl[32][8]; unsigned wg[256][8]; };  // wg[b] (FLS_ES_DEBUG): workgroup b's 100 MHz ticks waiting for a task | in partitions out of global memory | in LDS ranges, its task count, its longest LDS range (ticks, records), its longest chain of partitions out of global memory (ticks, first range's records)  // mark / lvl: stage stamps of es_task_kernel (diagnostics, FLS_ES_DEBUG): lvl[i] = {range size, 100 MHz stamps of the phases of workgroup 0's i-th partition out of global memory}
 
+// (Round 6, built and REMOVED: "write-through records" -- every key[] / val[] access of the task kernel as an agent-scope relaxed atomic (sc1), the
+// hand-over between workgroups without release / acquire fences.  Times equal to the fenced form within 2 % (profiles/r06_vg_large_cloud_filters.txt), and
+// WRONG under concurrency: with three or four batch lanes sorting at once, ~15 % of the IcpOptimized jobs got a source cloud with too many leaves -- an
+// unsorted piece (tools/dbg_batch_stress.py: 44 of 80 repetitions with a mismatch, 0 of 80 fenced).  The fences stay.)
 __device__ __forceinline__ void es_swap_rec(unsigned* __restrict__ key, unsigned* __restrict__ val, const unsigned a, const unsigned b) {
     const unsigned ka = key[a], kb = key[b], va = val[a], vb = val[b];
     key[a] = kb; key[b] = ka; val[a] = vb; val[b] = va;
@@ -255,7 +259,10 @@ es_scatter_kernel(const unsigned* __restrict__ key, EsSeg* __restrict__ cur, con
 // are served from memory -- instead of waiting for a launch boundary (a dependent launch costs ~4.7 us here, the look-back ~1 us).
 // A tile only ever waits for LOWER workgroup ids of the same launch, and the hardware starts workgroups in id order: no tile waits for
 // one that cannot run.  pub[t] = epoch << 32 | n_R-stops << 16 | n_L-stops (a tile holds 2,048 records); the epoch never repeats, so a
-// word of an earlier level / sort is never taken for this launch's.  A poll that runs dry (4 M spins) fails the sort (host filter).
+// word of an earlier level / sort is never taken for this launch's.  "The hardware starts workgroups in id order" is what dispatch does, not a guarantee
+// (ADVICE r5): with other streams' kernels competing for the CUs a predecessor could in principle still be waiting for a slot while its successor polls.
+// An atomic ticket per workgroup would remove the assumption at ~1 us per launch on the critical path of every level; instead the poll gives up after
+// ~50 ms (40 k polls) and fails the sort, and the caller takes the exact host filter: correct either way, never a stall of seconds.
 __global__ void __launch_bounds__(kEsBlock)
 es_count_scatter_kernel(const unsigned* __restrict__ key, EsSeg* __restrict__ cur, EsState* __restrict__ st, const unsigned* __restrict__ tile_seg,
                         unsigned long long* __restrict__ pub, const unsigned epoch, unsigned* __restrict__ Lp, unsigned* __restrict__ Rl) {
@@ -285,7 +292,7 @@ es_count_scatter_kernel(const unsigned* __restrict__ key, EsSeg* __restrict__ cu
         for (;;) {
             w = __hip_atomic_load(&pub[g.tile0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)(w >> 32) == epoch) break;
-            if (++guard > 4000000u) { dry = 1u; break; }
+            if (++guard > 40000u) { dry = 1u; break; }  // (~40-80 ms; 4 M polls = seconds until round 6)
             __builtin_amdgcn_s_sleep(1);
         }
         p0 += (unsigned)w & 0xFFFFu; p1 += (unsigned)(w >> 16) & 0xFFFFu;
@@ -613,9 +620,20 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                const unsigned* __restrict__ skip /* nullable; *skip != 0: the caller's plan was refused on the device, nothing to sort */,
                const unsigned lds_cap /* ranges up to this many records (<= kEsLds) are sorted in LDS */) {
     if (skip != nullptr && *skip != 0u) return;
-    unsigned pf_wait = 0u, pf_glob = 0u, pf_lds = 0u, pf_tasks = 0u, pf_t = 0u;  // (diagnostics: dbg != nullptr)
+    // (diagnostics, dbg != nullptr: thread 0's time accounts live in LDS -- as registers they cost the whole kernel a dozen VGPRs)
+    __shared__ unsigned pf[10];
+#define pf_wait pf[0]
+#define pf_glob pf[1]
+#define pf_lds pf[2]
+#define pf_tasks pf[3]
+#define pf_t pf[4]
+#define pf_lmax pf[5]
+#define pf_lmax_m pf[6]
+#define pf_gmax pf[7]
+#define pf_gmax_m pf[8]
+#define pf_m0 pf[9]
 #define ES_PF(acc) do { if (dbg && threadIdx.x == 0) { const unsigned now_ = (unsigned)__builtin_amdgcn_s_memrealtime(); acc += now_ - pf_t; pf_t = now_; } } while (0)
-    if (dbg && threadIdx.x == 0) pf_t = (unsigned)__builtin_amdgcn_s_memrealtime();
+    if (dbg && threadIdx.x == 0) { for (int i_ = 0; i_ < 10; ++i_) pf[i_] = 0u; pf_t = (unsigned)__builtin_amdgcn_s_memrealtime(); }
 #define ES_MARK(k) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0 && dbg->mark[k] == 0u) dbg->mark[k] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
     using namespace es_lds;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -632,26 +650,33 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
             s_fail = 0u;
         } else if (t == 0) {
             unsigned state = 0u;  // 1: got a task, 2: all done
-            for (unsigned spin = 0;; ++spin) {
-                if (es_ld(&st->fail)) { state = 2u; break; }
-                const unsigned h = es_ld(&q->head), tl = es_ld(&q->tail);
-                const unsigned lim = tl < cap ? tl : cap;
-                if (h < lim) {
-                    if (atomicCAS(&q->head, h, h + 1u) != h) continue;
-                    if (h >= q->n_init) {
-                        unsigned guard = 0u;
-                        while (__hip_atomic_load(&ready[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++guard < 4000000u) __builtin_amdgcn_s_sleep(1);
-                        if (guard >= 4000000u) { atomicExch(&st->fail, 3u); state = 2u; break; }
+            // TICKET queue (round 6): a workgroup draws a slot number ONCE (one atomic add on `head`) and then waits for THAT slot's flag -- a word no other
+            // workgroup waits for -- or for the end of all work (`open` == 0: every pushed task has been finished, so slot h will never be filled).
+            // Until round 6 every idle workgroup polled {head, tail} and tried a compare-and-swap on `head` whenever a task showed up: with ~200 idle
+            // workgroups each push set off ~200 CAS operations on one word, queued in front of the pushing workgroup's own next atomics -- the chain of
+            // partitions that feeds the queue ran 3-8x slower than unloaded, and halving the number of workgroups made the kernel 1.5x FASTER
+            // (profiles/r06_e_*, r06_f_*).  Slots are handed out in order and filled in order: ticket h gets task h.
+            const unsigned h = atomicAdd(&q->head, 1u);
+            if (h >= cap) state = 2u;  // (no slot left to wait for: a push beyond the table fails the sort on its own; this workgroup just leaves)
+            else {
+                const unsigned n_init = q->n_init;
+                for (unsigned spin = 0;; ++spin) {
+                    if (h < n_init || __hip_atomic_load(&ready[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { state = 1u; break; }
+                    if ((spin & 3u) == 3u) {
+                        if (es_ld(&q->open) == 0u) {  // nothing unfinished anywhere: slot h stays empty (a task pushed into it would count in `open`)
+                            if (__hip_atomic_load(&ready[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { state = 1u; break; }  // (pushed and flagged between the two loads)
+                            state = 2u; break;
+                        }
+                        if ((spin & 63u) == 63u && es_ld(&st->fail)) { state = 2u; break; }
                     }
+                    if (spin > 2000000u) { atomicExch(&st->fail, 2u); state = 2u; break; }  // watchdog (seconds): never hang the device
+                    if (spin < 8u) __builtin_amdgcn_s_sleep(4); else if (spin < 32u) __builtin_amdgcn_s_sleep(20); else __builtin_amdgcn_s_sleep(60);
+                }
+                if (state == 1u) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     const EsWork wk = tasks[h];
                     s_first = wk.first; s_last = wk.last; s_depth = wk.depth;
-                    state = 1u;
-                    break;
                 }
-                if (es_ld(&q->open) == 0u) { state = 2u; break; }
-                if (spin > 4000000u) { atomicExch(&st->fail, 2u); state = 2u; break; }  // watchdog (seconds): never hang the device
-                if (spin < 64u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(20);
             }
             s_state = state;
             s_fail = 0u;
@@ -664,7 +689,7 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the producer's records, not this CU's cached copies
         ES_MARK(2);
         ES_PF(pf_wait);
-        ++pf_tasks;
+        if (dbg && threadIdx.x == 0) { ++pf_tasks; pf_m0 = s_last - s_first; }
         unsigned first = s_first, last = s_last, m = last - first;
         int depth = s_depth;
         bool dead = false;  // the range hit the depth limit (sort failed) -- nothing left to do for this task
@@ -687,7 +712,11 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                 // (every loop below keeps U independent loads in flight: a global round trip costs ~1 us on a freshly invalidated cache, and a
                 // 115 k-record range is 113 rounds of 64 per wave)
                 constexpr int U = FLS_ES_UNROLL;  // (8 until the end of round 4: the passes are latency bound, the workgroup is alone on its CU and has registers to spare)
+                // (round 6, tried and dropped: the whole slice -- 16 / 32 rounds -- read once and kept in registers from the counts to the stop lists.  16 rounds
+                // fit (128 VGPRs, no scratch) and changed nothing (NDT call 0.474-0.479 vs 0.467-0.469 ms), 32 rounds spill: 0.58 ms.  profiles/r06_j_*)
                 unsigned cl = 0u, cr = 0u;
+                unsigned bl = 0u, br = 0u, nL = 0u, nR = 0u;
+                {
                 for (unsigned base = w0; base < w1; base += 64u * U) {
                     unsigned kk[U];
 #pragma unroll
@@ -702,7 +731,6 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                 if (lane == 0) { s_wl[w] = cl; s_wr[w] = cr; }
                 __syncthreads();
                 ES_LVL(3);
-                unsigned bl = 0u, br = 0u, nL = 0u, nR = 0u;
                 for (int x = 0; x < kEsTaskWaves; ++x) { const unsigned a = s_wl[x], b = s_wr[x]; if (x < w) { bl += a; br += b; } nL += a; nR += b; }
                 for (unsigned base = w0; base < w1; base += 64u * U) {
                     unsigned kk[U];
@@ -717,6 +745,7 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
                         if (fr) Rl[first + br + (unsigned)__popcll(mr & lt_mask)] = i;
                         bl += (unsigned)__popcll(ml); br += (unsigned)__popcll(mr);
                     }
+                }
                 }
                 __syncthreads();
                 ES_LVL(4);
@@ -771,7 +800,7 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
             }
         }
         ES_MARK(9);
-        ES_PF(pf_glob);
+        if (dbg && threadIdx.x == 0) { const unsigned before_ = pf_glob; ES_PF(pf_glob); if (pf_glob - before_ > pf_gmax) { pf_gmax = pf_glob - before_; pf_gmax_m = pf_m0; } }
         if (!dead && m >= 2u) {
             if (t == 0) { atomicAdd(&st->pad[1], 1u); atomicAdd(&st->pad[2], m); }  // diagnostics: ranges sorted in LDS, their records
             // ============ the range lives in LDS; its waves partition sub-ranges from a local queue ============
@@ -916,14 +945,25 @@ es_task_kernel(unsigned* __restrict__ key, unsigned* __restrict__ val, EsWork* _
         __syncthreads();
         if (t == 0) atomicSub(&q->open, 1u);  // (after the children were pushed)
         ES_MARK(7);
-        ES_PF(pf_lds);
+        if (dbg && threadIdx.x == 0) { const unsigned before_ = pf_lds; ES_PF(pf_lds); if (pf_lds - before_ > pf_lmax) { pf_lmax = pf_lds - before_; pf_lmax_m = m; } }
     }
     ES_MARK(8);
     if (dbg && threadIdx.x == 0 && blockIdx.x < 256u) {
         ES_PF(pf_wait);
         dbg->wg[blockIdx.x][0] = pf_wait; dbg->wg[blockIdx.x][1] = pf_glob; dbg->wg[blockIdx.x][2] = pf_lds; dbg->wg[blockIdx.x][3] = pf_tasks;
+        dbg->wg[blockIdx.x][4] = pf_lmax; dbg->wg[blockIdx.x][5] = pf_lmax_m; dbg->wg[blockIdx.x][6] = pf_gmax; dbg->wg[blockIdx.x][7] = pf_gmax_m;
     }
 #undef ES_PF
+#undef pf_wait
+#undef pf_glob
+#undef pf_lds
+#undef pf_tasks
+#undef pf_t
+#undef pf_lmax
+#undef pf_lmax_m
+#undef pf_gmax
+#undef pf_gmax_m
+#undef pf_m0
 #undef ES_MARK
 }
 

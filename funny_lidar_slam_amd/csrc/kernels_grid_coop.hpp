@@ -63,6 +63,9 @@ struct GridKnnLane {
     unsigned slot;
     int found, q;
     float kth;
+    // K == 1 (the fused IcpOptimized kernel): the nearest neighbour's coordinates and the query's own source point, kept from the search -- the fit
+    // used to load map point `slot` and the source point again, one more dependent memory round trip in a launch that is a chain of ten (round 6)
+    float bx, by, bz, px, py, pz;
 };
 // UNGATED: the caller searches without a gate (LoamPointToPlaneKdtree): only that instantiation carries the ring walk and the serial
 // fallback below (as a run-time test on `gate` they sat in every instantiation's register budget)
@@ -143,12 +146,16 @@ grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restri
 #pragma unroll
     for (int j = 0; j < K; ++j) { t[j] = ~0ull; sl[j] = 0u; }
     int ncand = 0;
+    constexpr bool CARRY = (K == 1) && !EMIT;  // this lane's best candidate travels with its key
+    float best_x = 0.f, best_y = 0.f, best_z = 0.f;
     auto consider = [&](const float4 p, const unsigned s, const bool ok) {
         const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
         const float d2 = (dx * dx + dy * dy) + dz * dz;  // flann::L2_Simple<float>
         if (ok && !(d2 != d2)) {
             ++ncand;
-            topk_insert<K>(t, sl, ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p.w), s);
+            const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p.w);
+            if constexpr (CARRY) { if (kk < t[0]) { best_x = p.x; best_y = p.y; best_z = p.z; } }
+            topk_insert<K>(t, sl, kk, s);
         }
     };
     // ---- round 0
@@ -212,6 +219,7 @@ grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restri
     unsigned mine_slot = 0u;
     int found = 0;
     float kth = INFINITY;
+    float mine_x = 0.f, mine_y = 0.f, mine_z = 0.f;
     auto merge = [&]() {
         const int total = group_sum_i32<G>(ncand);
         mine_key = ~0ull; last_key = ~0ull; mine_slot = 0u;
@@ -220,6 +228,11 @@ grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restri
             const unsigned long long m = group_min_u64<G>(t[0]);
             const bool owner = (t[0] == m) && (m != ~0ull);
             const unsigned ms = group8_min_u32(owner ? sl[0] : 0xffffffffu);
+            if constexpr (CARRY) {  // keys are unique (the map index is the low word): one owner, whose coordinates every lane of the group receives
+                mine_x = __uint_as_float(group8_min_u32(owner ? __float_as_uint(best_x) : 0xffffffffu));
+                mine_y = __uint_as_float(group8_min_u32(owner ? __float_as_uint(best_y) : 0xffffffffu));
+                mine_z = __uint_as_float(group8_min_u32(owner ? __float_as_uint(best_z) : 0xffffffffu));
+            }
             if (owner) {
 #pragma unroll
                 for (int u = 0; u + 1 < K; ++u) { t[u] = t[u + 1]; sl[u] = sl[u + 1]; }
@@ -244,7 +257,7 @@ grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restri
 #pragma unroll
             for (int j = 0; j < K; ++j) { t[j] = ~0ull; sl[j] = 0u; }
             ncand = 0;
-            if (sub < K && mine_key != ~0ull) { t[0] = mine_key; sl[0] = mine_slot; ncand = 1; }
+            if (sub < K && mine_key != ~0ull) { t[0] = mine_key; sl[0] = mine_slot; ncand = 1; if constexpr (CARRY) { best_x = mine_x; best_y = mine_y; best_z = mine_z; } }
             // 13 shell cells per lane in batches of five: the (pruned) cell lookups of a batch are in flight together, then
             // one flattened candidate loop over the cells that survived -- two memory round trips per batch, not per cell
             auto shell = [&](const int r, unsigned& bb, unsigned& cc) {
@@ -296,7 +309,7 @@ grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restri
 #pragma unroll
             for (int j = 0; j < K; ++j) { t[j] = ~0ull; sl[j] = 0u; }
             ncand = 0;
-            if (sub < K && mine_key != ~0ull) { t[0] = mine_key; sl[0] = mine_slot; ncand = 1; }  // the merged top-K, one entry per lane
+            if (sub < K && mine_key != ~0ull) { t[0] = mine_key; sl[0] = mine_slot; ncand = 1; if constexpr (CARRY) { best_x = mine_x; best_y = mine_y; best_z = mine_z; } }  // the merged top-K, one entry per lane
             const int w = 2 * rho + 1, cube = w * w * w;
             for (int idx = sub; idx < cube; idx += G) {
                 const int dx = idx % w - rho, dy = (idx / w) % w - rho, dz = idx / (w * w) - rho;
@@ -336,6 +349,7 @@ grid_knn_body(const int bid, const float* __restrict__ sx, const float* __restri
     }  // UNGATED
     if (!EMIT) {
         lane_out->key = mine_key; lane_out->slot = mine_slot; lane_out->found = found; lane_out->kth = kth; lane_out->q = active ? q : -1;
+        lane_out->bx = mine_x; lane_out->by = mine_y; lane_out->bz = mine_z; lane_out->px = px; lane_out->py = py; lane_out->pz = pz;
         return;
     }
     if (sub < K && active)
@@ -602,6 +616,7 @@ icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
     __shared__ double wsum[4][32];
     GridKnnLane r;
     r.key = ~0ull; r.slot = 0u; r.found = 0; r.q = -1; r.kth = INFINITY;
+    r.bx = r.by = r.bz = r.px = r.py = r.pz = 0.f;
     grid_knn_body<1, true, false>((int)blockIdx.x, sx, sy, sz, n, st, first, T0, cg, gate, nullptr, nullptr, nullptr, nullptr, &r);
     double T[16];
 #pragma unroll
@@ -621,9 +636,9 @@ icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
     for (int k = 0; k < 18; ++k) Jr[k] = 0.0;
     if (owner) {
         if (r.found >= 1 && r.key != ~0ull && !((double)r.kth > max_corr)) {
-            const float4 m = cg.g.pts[r.slot];
+            const float4 m = make_float4(r.bx, r.by, r.bz, __uint_as_float((unsigned)r.key));  // (= cg.g.pts[r.slot]: the key's low word is the point's id word)
             id_l = __float_as_int(m.w);
-            icp_point_rows(T, sx[r.q], sy[r.q], sz[r.q], m, Jr, er, res);
+            icp_point_rows(T, r.px, r.py, r.pz, m, Jr, er, res);
             contrib = true;
         }
     }
@@ -639,9 +654,9 @@ icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
     for (int k = 0; k < 6; ++k) Bc[k] = 0.0;
     if (owner) {
         if (r.found >= 1 && r.key != ~0ull && !((double)r.kth > max_corr)) {
-            const float4 m = cg.g.pts[r.slot];
+            const float4 m = make_float4(r.bx, r.by, r.bz, __uint_as_float((unsigned)r.key));  // (= cg.g.pts[r.slot])
             id_l = __float_as_int(m.w);
-            icp_point_terms(T, sx[r.q], sy[r.q], sz[r.q], m, Hc, Bc, res);
+            icp_point_terms(T, r.px, r.py, r.pz, m, Hc, Bc, res);
             contrib = true;
         }
     }

@@ -287,40 +287,86 @@ vg_heads(const unsigned* __restrict__ key, const unsigned* __restrict__ val, con
     vg_heads_body(key, val, n, total, x, y, z, in, sorted, lx, bt);
 }
 
-// one thread per run head: float sums in sorted (= ascending point index) order, centroid = sum / count
+// one thread per run head: float sums in sorted (= ascending point index) order, centroid = sum / count.
+// Round 6: a run of kVgLongLeaf points or more is summed by the head's WAVE instead of its one thread -- sixty-four points per round arrive as one
+// coalesced load (the next round's already in flight), then the sums are folded in index order through v_readlane: the same chain of IEEE additions
+// ((s + p0) + p1) + ..., ~19 ns per point instead of ~125 (one thread with eight 16-byte loads in flight).  The map-side filters of the kd-tree kinds
+// see leaves of a thousand points (the keyframe deque near the sensor): vg_centroid 137 us on the 1.55 M-point planar deque of LoamFull before.
+constexpr int kVgLongLeaf = 128;
 __device__ __forceinline__ void vg_centroid_body(const unsigned* __restrict__ key, const float4* __restrict__ sorted, const int n, const unsigned* __restrict__ lx,
                                                  const unsigned* __restrict__ bt, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, float* __restrict__ oi) {
     const int e = blockIdx.x * kVgBlock + threadIdx.x;
-    if (e >= n) return;
-    const unsigned l = lx[e];
-    if (l == 0xffffffffu) return;
-    const unsigned o = bt[e / kVgScanBlock] + l;
-    const unsigned k = key[e];
-    // end of the run: gallop, then bisect (the keys are sorted) -- ~2 log2(length) dependent loads instead of one per point
-    // (round 3: the walk that tested key[q] before every add was latency-bound, 130-520 us on leaves of hundreds of points)
-    int lo = e, step = 1;  // key[lo] == k
-    while (lo + step < n && key[lo + step] == k) { lo += step; step <<= 1; }
-    int hi = min(lo + step, n);  // key[hi] != k or hi == n
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (key[mid] == k) lo = mid; else hi = mid; }
-    const int c = hi - e;
-    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-    int q = e;
-    for (; q + 8 <= hi; q += 8) {  // eight loads in flight, adds in index order
-        float4 p[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = sorted[q + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { sx += p[u].x; sy += p[u].y; sz += p[u].z; si += p[u].w; }
+    const int lane = threadIdx.x & 63;
+    const unsigned l = e < n ? lx[e] : 0xffffffffu;
+    const bool head = l != 0xffffffffu;
+    unsigned o = 0u;
+    int hi = e, c = 0;
+    if (head) {
+        o = bt[e / kVgScanBlock] + l;
+        const unsigned k = key[e];
+        // end of the run: gallop, then bisect (the keys are sorted) -- ~2 log2(length) dependent loads instead of one per point
+        // (round 3: the walk that tested key[q] before every add was latency-bound, 130-520 us on leaves of hundreds of points)
+        int lo = e, step = 1;  // key[lo] == k
+        while (lo + step < n && key[lo + step] == k) { lo += step; step <<= 1; }
+        hi = min(lo + step, n);  // key[hi] != k or hi == n
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (key[mid] == k) lo = mid; else hi = mid; }
+        c = hi - e;
     }
-    for (; q < hi; ++q) {
-        const float4 p = sorted[q];
-        sx += p.x; sy += p.y; sz += p.z; si += p.w;
+    const bool long_run = head && c >= kVgLongLeaf;
+    if (head && !long_run) {
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        int q = e;
+        for (; q + 8 <= hi; q += 8) {  // eight loads in flight, adds in index order
+            float4 p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = sorted[q + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sx += p[u].x; sy += p[u].y; sz += p[u].z; si += p[u].w; }
+        }
+        for (; q < hi; ++q) {
+            const float4 p = sorted[q];
+            sx += p.x; sy += p.y; sz += p.z; si += p.w;
+        }
+        const float cf = (float)c;
+        ox[o] = __fdiv_rn(sx, cf);
+        oy[o] = __fdiv_rn(sy, cf);
+        oz[o] = __fdiv_rn(sz, cf);
+        oi[o] = __fdiv_rn(si, cf);
     }
-    const float cf = (float)c;
-    ox[o] = __fdiv_rn(sx, cf);
-    oy[o] = __fdiv_rn(sy, cf);
-    oz[o] = __fdiv_rn(sz, cf);
-    oi[o] = __fdiv_rn(si, cf);
+    // the long runs of this wave, one after the other, by all of its lanes (wave-uniform control flow)
+    unsigned long long pending = __ballot(long_run);
+    while (pending != 0ull) {
+        const int src = __ffsll((long long)pending) - 1;
+        pending &= pending - 1ull;
+        const int b = __shfl(e, src, 64), end = __shfl(hi, src, 64);
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        float4 nxt = (b + lane < end) ? sorted[b + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = b; q < end; q += 64) {
+            const float4 p = nxt;
+            if (q + 64 < end) nxt = (q + 64 + lane < end) ? sorted[q + 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int cnt = min(64, end - q);
+            if (cnt == 64) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    sx += __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(p.x), j));
+                    sy += __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(p.y), j));
+                    sz += __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(p.z), j));
+                    si += __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(p.w), j));
+                }
+            } else {
+                for (int j = 0; j < cnt; ++j) {
+                    sx += __shfl(p.x, j, 64); sy += __shfl(p.y, j, 64); sz += __shfl(p.z, j, 64); si += __shfl(p.w, j, 64);
+                }
+            }
+        }
+        if (lane == src) {
+            const float cf = (float)c;
+            ox[o] = __fdiv_rn(sx, cf);
+            oy[o] = __fdiv_rn(sy, cf);
+            oz[o] = __fdiv_rn(sz, cf);
+            oi[o] = __fdiv_rn(si, cf);
+        }
+    }
 }
 __global__ void __launch_bounds__(kVgBlock)
 vg_centroid(const unsigned* __restrict__ key, const float4* __restrict__ sorted, const int n, const unsigned* __restrict__ lx,

@@ -1,30 +1,44 @@
-"""Seeded random mapping-mode scenarios on the GPU (tests/refpin.py::make_fuzz_scenario: parameters far from the YAML sets, start poses anywhere in
-the room, 3-5 frames, iVox LRU capacities of a few hundred voxels) -- the scenarios on which the oracle equals the reference's own compiled code
-(tests/test_ref_pin.py::test_oracle_equals_compiled_reference_fuzz; profiles/r05_ref_pin_fuzz_*_scenarios.log).  After every frame: return value,
-iteration count, per-iteration n_valid / pose, flags, counts, ids, map_updated, map sizes (tests/test_gpu_mapping_replay.py::run_replay).
-One seed per kind here (the four that ran on a GPU in round 5); tools/gpu_fuzz_replay.py runs any range of seeds."""
+"""The HIP path on the scenarios the ORACLE was pinned on against the reference's own compiled code (tests/test_ref_pin.py, tests/refpin.py), on a GPU:
+  * `fuzz<seed>`   seeded random mapping-mode replays (kind by seed % 4; parameters far from the YAML sets, start poses anywhere in the room, 3-5 frames,
+                   iVox LRU capacities of a few hundred voxels);
+  * `lfuzz<seed>`  seeded localization-mode runs (IcpOptimized, LoamPointToPlaneKdtree, LoamPointToPlaneIVOX, IncrementalNDT by seed % 4), prior maps of
+                   random size, GetFitnessScore after every Match;
+  * `deg_*`        degenerate inputs: empty / tiny / far scans, LoamFull without corner features, the ICP <= 10 points abort (icp_optimized.h:55).
+After every frame: return value, iteration count, per-iteration n_valid / pose / residual sums, flags, counts, ids, map_updated, map sizes, fitness
+(tests/gpu_scenarios.py::run_scenario).  A slice runs here; ALL of them ran on an MI355X in round 6 through tools/gpu_fuzz_replay.py:
+200 mapping (seeds 4-203) + 40 localization + 14 degenerate scenarios, logs under profiles/r06_*_gpu_fuzz_*.log.  That run found two differences,
+both fixed: fls_get_fitness_score of an IncrementalNDT handle whose first Match stopped at the effective-point floor (incremental_ndt.h:306-309 returns
+before final_transformation_ is set, :335) answered FLS_ERR_STATE where the reference scores with the value-initialised matrix; and the iteration log of a
+Match on an empty cloud had no row where the oracle keeps one."""
 import pytest
 
 from funny_lidar_slam_amd import _lib
-from tests import refpin, util
-from tests.test_gpu_mapping_replay import run_replay
+from tests import gpu_scenarios
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3])
-def test_fuzz_scenario_equals_oracle(seed, monkeypatch, built):
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fuzz_scenario_equals_oracle(seed, built):
     assert _lib.device_count() >= 1, "gpu tests need an MI355X (gfx950): the HIP path has no CPU fallback"
-    sc = refpin.make_fuzz_scenario(seed)
-    if "ivox_capacity" in sc:  # the LRU capacity is a constructor constant of the reference (ivox_map.h); the handle takes it through its test hook
-        cap = sc["ivox_capacity"]
-        monkeypatch.setenv("FLS_IVOX_CAPACITY", str(cap))
-        orig = util.oracle_for
-
-        def with_cap(mode, y, loc=False):
-            o = orig(mode, y, loc)
-            o.set_ivox_capacity(cap)
-            return o
-        monkeypatch.setattr(util, "oracle_for", with_cap)
-    r, hist = run_replay(sc["name"], r=sc)
+    sc = gpu_scenarios.refpin.make_fuzz_scenario(seed)
+    hist = gpu_scenarios.run_scenario(sc["name"], sc)
     assert len(hist) == len(sc["frames"])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_localization_fuzz_scenario_equals_oracle(seed, built):
+    assert _lib.device_count() >= 1
+    name = f"lfuzz{seed}"
+    sc = gpu_scenarios.refpin.make_scenario(name)
+    hist = gpu_scenarios.run_scenario(name, sc)
+    assert len(hist) == len(sc["frames"]) and all("fitness" in h for h in hist)
+
+
+@pytest.mark.parametrize("name", list(gpu_scenarios.DEGENERATE) + ["deg_icp_le10"])
+def test_degenerate_scenario_equals_oracle(name, built):
+    assert _lib.device_count() >= 1
+    hist = gpu_scenarios.run_scenario(name)
+    assert len(hist) == 1
+    if name == "deg_icp_le10":
+        assert hist[0].get("abort") is True  # the reference aborts the process; the product answers with an error status

@@ -399,6 +399,33 @@ def test_match_batch_other_kinds(mode, y, cid, scale, loc):
     m.close()
 
 
+def test_match_batch_concurrent_source_filters_stress():
+    """Three and four stream lanes of IcpOptimized at once, twenty fresh handles in a row: every lane runs its own device VoxelGrid (exact sort: a persistent
+    task kernel per lane, co-resident on the device) before its iterations.  Every pose must equal, bit for bit, what a fresh handle computes alone.
+    Round 6: a fence-free hand-over inside that sort (write-through records) passed every single-stream test and the fuzz, and gave ~15 % of these jobs a
+    source cloud with an unsorted piece (n_source off by a hundred leaves, pose off by millimetres) -- found by this sequence, not by the one-shot test above."""
+    cfgs = [synth.make_config(0, job=j, scale=1.0) for j in range(4)]
+    maps = [cfgs[0]["map"]]
+    clusters = [util.cluster_for("IcpOptimized", c["scan"], None) for c in cfgs]
+    good = []
+    for j in range(4):
+        f = reg.make_matcher("IcpOptimized", reg.YAML_NCLT_ICP, is_localization_mode=True)
+        f.AddCloudToLocalMap(maps)
+        T = np.eye(4)
+        f.Match(clusters[j], T, update_map=False)
+        good.append((T.copy(), f.stats.iterations, f.stats.n_valid, f.stats.n_source))
+        f.close()
+    for rep in range(20):
+        m = reg.make_matcher("IcpOptimized", reg.YAML_NCLT_ICP, is_localization_mode=True)
+        m.AddCloudToLocalMap(maps)
+        for lanes in (3, 4):
+            oks, Ts, st = m.MatchBatch(clusters, [np.eye(4)] * 4, lanes=lanes)
+            for j in range(4):
+                assert (st[j].iterations, st[j].n_valid, st[j].n_source) == good[j][1:], (rep, lanes, j, st[j].n_source, good[j])
+                assert np.array_equal(Ts[j], good[j][0]), (rep, lanes, j)
+        m.close()
+
+
 @pytest.mark.parametrize("mode,y,cid,scale,loc", [("PointToPlane_IVOX", reg.YAML_NCLT_IVOX, 1, 0.1, False), ("IcpOptimized", reg.YAML_NCLT_ICP, 0, 1.0, True),
                                                   ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, 0.1, False), ("LoamFull_KdTree", reg.YAML_NCLT_LOAM_FULL, 3, 0.1, False)])
 def test_exact_tail_solvers(mode, y, cid, scale, loc, monkeypatch):

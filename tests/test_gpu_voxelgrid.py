@@ -136,6 +136,26 @@ def test_random_clouds_edge_cases():
     assert checked >= 8 and declined >= 1, (checked, declined)
 
 
+@pytest.mark.parametrize("copies,leaf", [(3, 0.4), (5, 1.0), (13, 0.4)])
+def test_keyframe_deque_clouds_dense_leaves_bit_identical(copies, leaf):
+    """The map-side filter of the kd-tree kinds (icp_optimized.h:187, loam_full_kdtree.h:92-100): the concatenated keyframe deque -- clouds beyond 131,072
+    points (the host-steered levels of the exact sort, 8,192-record LDS ranges, round 6), the same surfaces seen from neighbouring poses, leaves of
+    hundreds to thousands of points (summed by the head's wave: vg_centroid_body's long-run path, incl. partial last rounds).  Every leaf bit-identical."""
+    cfg = synth.make_config(2, with_map=False)
+    base = cfg["scan"][::2, :3] if copies > 5 else cfg["scan"][:, :3]
+    rng = np.random.default_rng(1000 + copies)
+    parts = []
+    for k in range(copies):  # a keyframe every ~1 m: the same cloud shifted by a few centimetres to a metre (k = 0, 1: exact duplicates)
+        shift = np.float32(0.0) if k < 2 else rng.uniform(-1.0, 1.0, size=3).astype(np.float32)
+        parts.append((base + shift).astype(np.float32))
+    cloud = np.concatenate(parts, axis=0)
+    cloud = np.concatenate([cloud, rng.random((cloud.shape[0], 1), dtype=np.float32)], axis=1)
+    assert cloud.shape[0] > 131072
+    r = check(cloud, leaf)
+    print(copies, leaf, cloud.shape[0], r)
+    assert r["max_leaf"] >= 128 and r["big"] > 1000
+
+
 def test_sparse_cloud_is_bit_identical():
     """every leaf holds at most two points: the whole output equals the reference's bit for bit"""
     rng = np.random.default_rng(3)
