@@ -163,7 +163,7 @@ def cpu_baseline_reference(cfg, y, budget_s=10.0):
     out = {"value": 1.0 / per[best][0], "unit": "scans/s", "cores": best, "threads": best, "host_cores": ncpu, "kind": "reference",
            "one_thread": 1.0 / per[1][0] if 1 in per else None,
            "scans_per_s_by_threads": {str(k): 1.0 / v[0] for k, v in per.items()},
-           "scaling_note": "beyond ~32 threads this build gets SLOWER (round 5: 64 threads 10.6, 256 threads 2.2 scans/s): the shim's Eigen stand-ins allocate per call and the "
+           "scaling_note": "beyond 16-32 threads this build gets SLOWER (rounds 5-6: 64 threads 10.6, 256 threads 2.2-2.5 scans/s): the shim's Eigen stand-ins allocate per call and the "
                            "allocator serialises them -- a property of the shim build, not of the reference with real Eigen + TBB; the best thread count is what `value` reports",
            "sample": f"{sum(v[1] for v in per.values())} Match calls (median per thread count, {budget_s:.0f} s budget) of the full 115,200-pt scan into the 1e6-pt iVox map "
                      f"({iters} GN iterations), the reference's own LoamPointToPlaneIVOX<double> compiled verbatim (oracle/ref_shim), shim Eigen / PCL; "

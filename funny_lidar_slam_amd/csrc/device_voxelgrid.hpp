@@ -82,6 +82,8 @@ struct DeviceExactSort {
     EsMailbox* mb_dev = nullptr;
     unsigned seq = 0;
     unsigned long long runs = 0, failures = 0, levels = 0;
+    int last_levels = 0;   // host-steered path: levels queued by the previous sort, and its size
+    size_t last_n = 0;
     ~DeviceExactSort() {
         EsMailbox* mine = mb_host;
         es_debug_mailbox().compare_exchange_strong(mine, nullptr);
@@ -149,7 +151,13 @@ struct DeviceExactSort {
     // The one-launch form for clouds up to kEsTaskMax records whose queue a preceding kernel initialises (vg_minmax_plan, EsInitArgs):
     // fused_prepare() before that kernel is queued, fused_launch() behind the kernel that writes the records.  `skip`: device word, non-zero
     // = nothing to sort.  The verdict (EsState::fail) stays on the device: the caller's last kernel forwards it.
-    bool fused_ok(const size_t n) const { return n >= 2 && n <= size_t(kEsTaskMax); }
+    // (kEsTaskMax until round 6: beyond it the host steered the level-synchronous top through a mailbox, two stream synchronisations and a round trip per
+    // top-up.  The pre-enqueued guess serves any size: levels that find nothing left are three ~2 us launches, ranges the guess leaves too long become
+    // tasks.  FLS_VG_FUSED_MAX for A/B)
+    bool fused_ok(const size_t n) const {
+        static const size_t lim = [] { const char* e = std::getenv("FLS_VG_FUSED_MAX"); return e ? size_t(std::atoll(e)) : (size_t(1) << 22); }();
+        return n >= 2 && n <= lim;
+    }
     EsInitArgs fused_prepare(const size_t n) {
         allocate(n);
         return EsInitArgs{st.p, queue.p, ready.p, work_cap};
@@ -171,7 +179,11 @@ struct DeviceExactSort {
         const unsigned big = big_threshold();
         int top = 0;
         if (big != 0u && n > size_t(big)) {
-            for (size_t m = n; m > size_t(big); m = m * 13 / 16) ++top;
+            // (a single scan keeps ~13/16 of a range in the larger child; the keyframe deques beyond kEsTaskMax records -- the same surfaces many times
+            // over -- split more evenly: ~0.7 measured, 15 levels for 1.55 M records where 13/16 all the way guesses 19, each empty level three launches)
+            size_t m = n;
+            for (; m > size_t(kEsTaskMax) && m > size_t(big); m = m * 7 / 10) ++top;
+            for (; m > size_t(big); m = m * 13 / 16) ++top;
             static const int extra = [] { const char* e = std::getenv("FLS_ES_TOP_EXTRA"); return e ? std::atoi(e) : 0; }();
             top = std::max(1, top + extra);
         }
@@ -240,10 +252,16 @@ struct DeviceExactSort {
         hipLaunchKernelGGL(es_level_begin, dim3(1), dim3(256), 0, s, key, val, unsigned(n), (const EsSeg*)prev, cur, work.p, work_cap, (const unsigned*)Lp.p,
                            (const unsigned*)Rl.p, st.p, mb_dev, next_seq(), 1, tile_seg.p, tile_cap, handover_threshold(), 0, (EsQueue*)nullptr, (const unsigned*)nullptr);
         // regime 1 (ranges longer than the hand-over threshold: only clouds beyond 131 k points get here)
+        // how many levels to queue before the first look at the mailbox: what the previous sort of this object needed (a keyframe deque changes by one
+        // frame in twenty-five between two calls), else a guess from halving splits -- LiDAR leaf indices split ~13/16, so the guess is short and the
+        // loop below tops up two levels at a time, one host round trip (~10 us of idle device) each
         int expected = 0;
         for (size_t m = n; m > size_t(handover_threshold()); m = (m + 1) / 2) ++expected;
         int chunk = expected ? expected + 1 : 0;
+        if (expected && last_levels > 0 && last_n != 0 && n >= last_n / 2 && n <= last_n * 2) chunk = std::max(1, last_levels);
+        int queued_levels = 0;
         for (;;) {
+            queued_levels += chunk;
             for (int c = 0; c < chunk; ++c) {
                 launch_lists(key, cur, s);
                 hipLaunchKernelGGL(es_swap_kernel, dim3(tile_cap), dim3(kEsBlock), 0, s, key, val, cur, (const EsState*)st.p, (const unsigned*)tile_seg.p,
@@ -259,6 +277,7 @@ struct DeviceExactSort {
             if (mb_host->n_cur == 0u) break;
             chunk = 2;
         }
+        last_levels = queued_levels; last_n = n;  // (an over-estimate by at most one top-up: empty levels cost three ~2 us launches)
         // regimes 2 + 3: one persistent launch over the task queue (the ranges regime 1 handed over are its first tasks)
         const unsigned n_work = mb_host->n_work;
         if (n_work) {
@@ -471,7 +490,8 @@ struct DeviceVoxelGrid {
         // (the reference sorts the FINITE points only: a cloud with a non-finite point is the host's, refuse_bad = 1)
         // (blocks: 48 in rounds 2-4 -- "few blocks: six header atomics each" -- left a 115,200-point scan to 12 k threads, 11-12 us in the trace
         // of the call; 160 blocks = three points per thread and < 1,000 atomics: FLS_VG_MINMAX_BLOCKS for A/B)
-        static const int mm_blocks = [] { const char* e = std::getenv("FLS_VG_MINMAX_BLOCKS"); return e ? std::min(kVgMinmaxMaxBlocks, std::max(1, std::atoi(e))) : 160; }();
+        static const int mm_env = [] { const char* e = std::getenv("FLS_VG_MINMAX_BLOCKS"); return e ? std::min(kVgMinmaxMaxBlocks, std::max(1, std::atoi(e))) : 0; }();
+        const int mm_blocks = mm_env ? mm_env : int(std::min<size_t>(kVgMinmaxMaxBlocks, std::max<size_t>(160, n / 4096)));  // (one row per block, no atomics but the ticket: more blocks for the keyframe deques)
         hipLaunchKernelGGL(vg_minmax_plan, dim3(unsigned(std::min(nb1, mm_blocks))), dim3(kVgBlock), 0, s, x, y, z, ni, inv, 1, d_acc.p, d_plan.p, es);
         hipLaunchKernelGGL(vg_index_plan, dim3(unsigned(nb1)), dim3(kVgBlock), 0, s, x, y, z, ni, (const VgPlan*)d_plan.p, sort.k0, sort.v0);
         exact.fused_launch(sort.k0, sort.v0, n, &d_plan.p->status, s);

@@ -300,7 +300,7 @@ struct IvoxImage {
     FlatHeader flat_header(size_t used_slots, size_t n_bricks_live) const {
         FlatHeader h{};
         std::memcpy(h.magic, "FLSIMG01", 8);
-        h.want_hash = want_hash ? 1u : 0u; h.have_bricks = have_bricks ? 1u : 0u;
+        h.want_hash = want_hash ? 1u : 0u; h.have_bricks = have_bricks ? 1u : 0u; h.use_dense = h.have_bricks;  // (the query takes the brick path exactly when the image carries bricks)
         h.mask = want_hash ? mask : 0u; h.dir_mask = have_bricks ? dir_mask : 0u;  // (a structure the image does not carry has no mask: flat_header_ok insists)
         h.used = used_slots; h.n_pts_live = n_pts_live; h.n_bricks_live = have_bricks ? n_bricks_live : 0; h.n_bricks_cap = n_bricks_cap;
         h.total_bytes = flat_bytes(h);

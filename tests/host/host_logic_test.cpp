@@ -307,6 +307,15 @@ int main() {
         { auto g = h; g.have_bricks = 0; CHECK(!IvoxImage::flat_header_ok(g, n)); }      // neither form
         { auto g = h; g.n_pts_live = 1001; CHECK(!IvoxImage::flat_header_ok(g, n)); }
         { auto g = h; g.total_bytes += 16; CHECK(!IvoxImage::flat_header_ok(g, n)); }
+        //  a mask without its table, a dense flag without bricks: the query would probe a table / slab the import never allocated
+        { auto g = h; g.mask = 1023; CHECK(!IvoxImage::flat_header_ok(g, n)); }
+        { auto g = h; g.use_dense = 0; CHECK(!IvoxImage::flat_header_ok(g, n)); }
+        {
+            IvoxImage t; t.have_bricks = false; t.want_hash = true; t.mask = 1023; t.dir_mask = 4095 /* stale: an image that fell back to the table */; t.n_pts_live = 10;
+            IvoxImage::FlatHeader g = t.flat_header(16, 0);
+            CHECK(g.dir_mask == 0u && g.use_dense == 0u && IvoxImage::flat_header_ok(g, size_t(g.total_bytes)));
+            g.dir_mask = 4095; CHECK(!IvoxImage::flat_header_ok(g, size_t(g.total_bytes)));
+        }
         CHECK(IvoxImage::kPoolBrickBytes > 25000 && IvoxImage::kPoolBrickBytes < 27000);
     }
     std::printf("host logic ok\n");
