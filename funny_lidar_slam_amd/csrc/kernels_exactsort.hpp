@@ -163,14 +163,21 @@ es_level_begin(unsigned* __restrict__ key, unsigned* __restrict__ val, const uns
         if (t > tile_cap) s_fail = 1u;
     }
     __syncthreads();
-    if (!s_fail)
-        for (unsigned s = threadIdx.x; s < nc; s += 256u) {  // tile -> range map (one load per workgroup in the three launches that follow)
-            const unsigned t0 = s_tiles[s], t1 = s + 1u < nc ? s_tiles[s + 1u] : s_total;
+    if (!s_fail) {
+        for (unsigned s = threadIdx.x; s < nc; s += 256u) {
             EsSeg g = s_cur[s];
-            g.tile0 = t0;
+            g.tile0 = s_tiles[s];
             cur[s] = g;
-            for (unsigned q = t0; q < t1; ++q) tile_seg[q] = s;
         }
+        // tile -> range map (one load per workgroup in the launches that follow), written by ALL threads: a keyframe deque's first levels are one or two
+        // ranges of 760 tiles, which one thread per range wrote one by one (round 6: es_level_begin 7-8 us per level on 1.55 M records)
+        const unsigned total = s_total;
+        for (unsigned q = threadIdx.x; q < total; q += 256u) {
+            unsigned lo = 0u, hi = nc;  // the last s with s_tiles[s] <= q
+            while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (s_tiles[mid] <= q) lo = mid; else hi = mid; }
+            tile_seg[q] = lo;
+        }
+    }
     if (threadIdx.x == 0) {
         const unsigned t = s_total;
         st->n_cur = s_fail ? 0u : nc;

@@ -95,6 +95,10 @@ int flo_get_counters(void* h, flo_counters* out);
 size_t flo_get_tie_flags(void* h, uint8_t* out, size_t cap);
 /* 0: the kNN stage skips its traffic / tie bookkeeping (an extra vector + sort per query): what cpu_baseline times */
 void flo_set_instrumentation(void* h, int on);
+/* TEST SWITCH, process-wide, off by default: exact distance ties of the iVox kNN candidates ordered by insertion id (what the device's (d2, id) keys do)
+ * instead of by libstdc++'s introselect permutation (what the reference does).  Only used to prove that a difference between the device and the
+ * oracle is a tie and nothing else. */
+void flo_set_tie_break_by_id(int on);
 /* last Match's per-iteration H (36, col-major) and g (6) for reduction-tolerance tests */
 int flo_get_last_system(void* h, double* H36, double* g6);
 size_t flo_map_size(void* h, int slot); /* points (iVox / kd maps) or voxels (NDT) */

@@ -152,11 +152,19 @@ struct VoxelNode {  // VoxelGridNode
     std::vector<int> gids_;  // oracle-only: global insertion id of each point
 };
 
+// TEST SWITCH (flo_set_tie_break_by_id; never set by the parity tests proper): candidates at EXACTLY equal distance ordered by their insertion id, the
+// order the device's (d2, id) keys impose, instead of being left to libstdc++'s introselect permutation as in the reference.  With it a Match whose only
+// difference from the device is a distance tie must become bit-identical to the device's -- the proof that a differing row IS a tie
+// (tests/test_gpu_fuzz_replay.py::test_scenarios_with_a_distance_tie_are_only_that; fuzz319 / lfuzz58 of the round-6 GPU runs).
+inline int& tie_break_by_id() { static int v = 0; return v; }
 struct DistPoint {  // voxel_grid_node.h:17-31  (operator< on dist only)
     double dist;
     VoxelNode* node;
     int idx;
-    bool operator<(const DistPoint& r) const { return dist < r.dist; }
+    bool operator<(const DistPoint& r) const {
+        if (tie_break_by_id() && dist == r.dist) return node->gids_[size_t(idx)] < r.node->gids_[size_t(r.idx)];
+        return dist < r.dist;
+    }
 };
 
 struct Near { P4 pt; int gid; };  // one element of nearest_points_[i] (+ id for parity checks)

@@ -1051,6 +1051,7 @@ int flo_get_last_system(void* h, double* H36, double* g6) {
     return 0;
 }
 void flo_set_instrumentation(void* h, int on) { static_cast<MatcherBase*>(h)->instrument = on != 0; }
+void flo_set_tie_break_by_id(int on) { flo::tie_break_by_id() = on != 0; }
 size_t flo_map_size(void* h, int slot) { return static_cast<MatcherBase*>(h)->MapSize(slot); }
 void flo_set_ivox_capacity(void* h, size_t cap) {  /* test hook: the reference hard-codes 1,000,000 (ivox_map.h:35) */
     auto* m = dynamic_cast<P2PlaneIvox*>(static_cast<MatcherBase*>(h));

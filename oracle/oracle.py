@@ -173,6 +173,8 @@ def lib():
         L.flo_get_tie_flags.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
         L.flo_set_instrumentation.restype = None
         L.flo_set_instrumentation.argtypes = [C.c_void_p, C.c_int]
+        L.flo_set_tie_break_by_id.restype = None
+        L.flo_set_tie_break_by_id.argtypes = [C.c_int]
         L.flo_get_last_system.argtypes = [C.c_void_p, dp, dp]
         L.flo_map_size.restype = C.c_size_t
         L.flo_map_size.argtypes = [C.c_void_p, C.c_int]
@@ -508,3 +510,9 @@ def knn_bruteforce(map_xyz, q, k):
     n = lib().flo_knn_bruteforce(pm, m.shape[0], pq, k, idx.ctypes.data_as(C.POINTER(C.c_int32)),
                                  d2.ctypes.data_as(C.POINTER(C.c_float)))
     return idx[:n], d2[:n]
+
+
+def set_tie_break_by_id(on: bool) -> None:
+    """TEST SWITCH (process-wide): exact distance ties of the iVox kNN ordered by insertion id like the device's keys, not by introselect (flo_api.h)."""
+    lib().flo_set_tie_break_by_id(1 if on else 0)
+

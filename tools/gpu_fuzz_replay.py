@@ -20,7 +20,7 @@ if what == "deg":
 else:
     prefix = {"mapping": "fuzz", "long": "fuzzL", "loc": "lfuzz"}[what]
     names = [f"{prefix}{s}" for s in range(first, first + count)]
-bad = []
+bad, ties = [], []
 t_all = time.perf_counter()
 for name in names:
     t0 = time.perf_counter()
@@ -33,8 +33,20 @@ for name in names:
     except BaseException as e:  # (pytest.raises failures derive from BaseException)
         if isinstance(e, KeyboardInterrupt):
             raise
-        bad.append(name)
-        print(name, "FAIL", repr(e)[:400], flush=True)
-        traceback.print_exc(limit=3)
-print(f"{what}: {len(names) - len(bad)} of {len(names)} scenarios equal to the oracle in {time.perf_counter() - t_all:.0f} s; failed: {bad}", flush=True)
+        # a difference that disappears when the oracle orders exactly tied kNN candidates by insertion id (the device's keys) is a distance tie: reported, not failed
+        tie_only = None
+        if isinstance(e, AssertionError):
+            try:
+                tie_only = gpu_scenarios.explain_difference_as_tie(name)
+            except BaseException:
+                tie_only = None
+        if tie_only:
+            ties.append(name)
+            print(name, "TIE: differs by an exact distance tie and nothing else (tests/gpu_scenarios.py::explain_difference_as_tie):", tie_only, flush=True)
+        else:
+            bad.append(name)
+            print(name, "FAIL", repr(e)[:400], flush=True)
+            traceback.print_exc(limit=3)
+print(f"{what}: {len(names) - len(bad) - len(ties)} of {len(names)} scenarios equal to the oracle in {time.perf_counter() - t_all:.0f} s; "
+      f"equal up to an exact distance tie (explain_difference_as_tie): {ties}; failed: {bad}", flush=True)
 sys.exit(1 if bad else 0)
