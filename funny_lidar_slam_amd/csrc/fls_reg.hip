@@ -361,7 +361,8 @@ fls_status fls_debug_voxel_grid_timed(int device_id, const float* pts, size_t n,
 
 fls_status fls_debug_exact_sort(int device_id, uint32_t* key, uint32_t* val, size_t n, int on_host) {
     if ((!key || !val) && n) return FLS_ERR_INVALID;
-    if (on_host)
+    if (on_host != 0 && on_host != 1 && on_host != 2) return FLS_ERR_INVALID;
+    if (on_host == 1)
         return guarded([&]() -> fls_status {  // (an allocation failure must not cross the C ABI: ADVICE r4)
             std::vector<VoxelLeafRec> r(n);
             for (size_t i = 0; i < n; ++i) r[i] = VoxelLeafRec{key[i], val[i]};
@@ -377,6 +378,25 @@ fls_status fls_debug_exact_sort(int device_id, uint32_t* key, uint32_t* val, siz
         FLS_HIP(hipMemcpy(dk.p, key, n * sizeof(unsigned), hipMemcpyHostToDevice));
         FLS_HIP(hipMemcpy(dv.p, val, n * sizeof(unsigned), hipMemcpyHostToDevice));
         DeviceExactSort es;
+        if (on_host == 2) {
+            // the launch sequence the one-stream VoxelGrid queues (DeviceExactSort::fused_launch: pre-enqueued top levels + the task kernel, no host
+            // round trip), with the initialisation vg_minmax_plan's last block does written from here
+            if (n < 2) return FLS_OK;
+            if (!es.fused_ok(n)) return FLS_ERR_STATE;
+            const EsInitArgs ia = es.fused_prepare(n);
+            FLS_HIP(hipMemset(ia.st, 0, sizeof(EsState)));
+            FLS_HIP(hipMemset(ia.ready, 0, ia.work_cap * sizeof(unsigned)));
+            const EsQueue q0{0u, 0u, 1u, 0u};
+            FLS_HIP(hipMemcpy(ia.q, &q0, sizeof(EsQueue), hipMemcpyHostToDevice));
+            es.fused_launch(dk.p, dv.p, n, nullptr, nullptr);
+            FLS_HIP(hipDeviceSynchronize());
+            EsState hs;
+            FLS_HIP(hipMemcpy(&hs, ia.st, sizeof(EsState), hipMemcpyDeviceToHost));
+            if (hs.fail != 0u) return FLS_ERR_STATE;
+            FLS_HIP(hipMemcpy(key, dk.p, n * sizeof(unsigned), hipMemcpyDeviceToHost));
+            FLS_HIP(hipMemcpy(val, dv.p, n * sizeof(unsigned), hipMemcpyDeviceToHost));
+            return FLS_OK;
+        }
         const bool queued = es.run(dk.p, dv.p, n, nullptr);
         FLS_HIP(hipDeviceSynchronize());
         if (!queued || es.failed_after_sync()) return FLS_ERR_STATE;

@@ -294,7 +294,8 @@ fls_status fls_debug_voxel_grid_timed(int device_id, const float* pts, size_t n,
 /* Test hook of the device VoxelGrid's sort (csrc/kernels_exactsort.hpp): sorts the n records {key[i], val[i]} in place BY KEY ONLY, leaving
  * records of equal key in exactly the order libstdc++'s std::sort leaves them in (what pcl::VoxelGrid's leaf sums depend on,
  * include/common/pointcloud_utility.h:216-271).  on_host = 1: std::sort on the host (the reference permutation, no GPU needed);
- * on_host = 0: the device kernels.  FLS_ERR_STATE: the device declined (a range still longer than 2,048 records when introsort's depth
+ * on_host = 0: the device kernels, host-steered sequence; on_host = 2: the launch sequence the one-stream VoxelGrid queues (pre-enqueued
+ * levels + the task kernel, no host round trip).  FLS_ERR_STATE: the device declined (a range still longer than 2,048 records when introsort's depth
  * limit is reached -- the heap-sort case of shorter ranges is reproduced on the device -- or more than 4 Mi records).
  * fls_debug_exact_sort_marks: progress stamps of the sort kernel last run with FLS_ES_DEBUG set (diagnostics, tools/es_marks.py). */
 fls_status fls_debug_exact_sort(int device_id, uint32_t* key, uint32_t* val, size_t n, int on_host);

@@ -16,23 +16,29 @@ def _need_gpu(built):
     assert _lib.device_count() >= 1, "gpu tests need an MI355X (gfx950): the HIP path has no CPU fallback"
 
 
-def sort_both(key):
+# device modes of the test hook: 0 = the host-steered sequence (DeviceExactSort::run), 2 = what the one-stream VoxelGrid queues (fused_launch: the
+# pre-enqueued levels above 32,768 records, then the task kernel -- no host round trip)
+DEV_MODES = (0, 2)
+
+
+def sort_both(key, dev_mode=0):
     L = _lib.lib()
     val = np.arange(key.size, dtype=np.uint32)
     out = []
-    for on_host in (1, 0):
+    for on_host in (1, dev_mode):
         k, v = key.astype(np.uint32).copy(), val.copy()
         rc = L.fls_debug_exact_sort(0, k.ctypes.data_as(C.POINTER(C.c_uint32)), v.ctypes.data_as(C.POINTER(C.c_uint32)), k.size, on_host)
         out.append((rc, k, v))
     return out
 
 
-def check(key, label):
-    (rh, kh, vh), (rd, kd, vd) = sort_both(key)
-    assert rh == 0 and rd == 0, (label, rh, rd)
-    assert np.array_equal(kh, kd), label
-    bad = np.flatnonzero(vh != vd)
-    assert bad.size == 0, (label, key.size, bad[:5], vh[bad[:5]], vd[bad[:5]])
+def check(key, label, modes=DEV_MODES):
+    for dev_mode in modes:
+        (rh, kh, vh), (rd, kd, vd) = sort_both(key, dev_mode)
+        assert rh == 0 and rd == 0, (label, dev_mode, rh, rd)
+        assert np.array_equal(kh, kd), (label, dev_mode)
+        bad = np.flatnonzero(vh != vd)
+        assert bad.size == 0, (label, dev_mode, key.size, bad[:5], vh[bad[:5]], vd[bad[:5]])
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 15, 16, 17, 33, 100, 1000, 4095, 4096, 4097, 8193, 20000, 115200, 300001])
@@ -94,6 +100,14 @@ def test_large_cloud_many_levels():
     check(rng.integers(0, 200000, 1400000), "1.4 M records (a LoamFull planar deque)")
 
 
+def test_pre_enqueued_sequence_large_clouds():
+    """the keyframe deques' size class through the sequence the one-stream VoxelGrid queues (test hook mode 2): 600 k, 1.55 M and 2.2 M records"""
+    rng = np.random.default_rng(77)
+    check(rng.integers(0, 90000, 600000), "600 k records", modes=(2,))
+    check(np.repeat(rng.integers(0, 40000, 100000), 16)[:1555200], "1.55 M records, runs of 16", modes=(2,))
+    check(rng.integers(0, 300000, 2200000), "2.2 M records", modes=(2,))
+
+
 def test_fuzz_against_std_sort():
     """tools/es_fuzz.py: 300 arrays around every regime boundary of the device sort (16 / 64 / 2,048 / 4,096 / 32,768 / 131,072 records), key
     distributions from all-equal to all-distinct, LiDAR-like piecewise-monotone keys, sorted / reversed / organ-pipe / sawtooth inputs: every
@@ -105,6 +119,11 @@ def test_fuzz_against_std_sort():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run([sys.executable, os.path.join(root, "tools", "es_fuzz.py"), "300", "4242"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    tail = run.stdout.strip().splitlines()[-1]
+    assert " 0 mismatches" in tail, tail
+    print(tail)
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "es_fuzz.py"), "200", "777", "2", "700000"], capture_output=True, text=True, timeout=900)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     tail = run.stdout.strip().splitlines()[-1]
     assert " 0 mismatches" in tail, tail

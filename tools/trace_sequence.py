@@ -3,8 +3,8 @@ duration and the idle gap in front of it.  usage: trace_sequence.py kernel_trace
 Prints N consecutive records starting FRAC of the way into the run (default: the middle), so that one steady-state call can be read
 launch by launch."""
 import csv, sys
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
 opt = {sys.argv[i]: sys.argv[i + 1] for i in range(1, len(sys.argv) - 1) if sys.argv[i].startswith("--")}
+args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and not sys.argv[i - 1].startswith("--")]
 frac, count = float(opt.get("--skip", 0.5)), int(opt.get("--n", 80))
 rows = []
 for r in csv.DictReader(open(args[0])):
