@@ -501,8 +501,8 @@ __device__ __forceinline__ void lu_tail(GnState* __restrict__ st, LuTailSmem& sm
 // Per point the seven contributions are now added by the wave reduction tree instead of sequentially (last-bit differences in H, g;
 // counts and flags are integers).
 constexpr int kNdtLanesBlock = 512;
-// FUSED = the Gauss-Newton tail in the last workgroup (FLS_FUSED_TAIL=1; measured slower for NDT, off by default).  A template
-// parameter, not a run-time branch: carrying the tail's code and LDS in the default kernel cost it 1.5 us per launch (13.3 vs 14.9 us).
+// FUSED = the Gauss-Newton tail in the last workgroup (default since round 6, FLS_FUSED_TAIL=0 for the separate gn_solve_lu_kernel launch; see
+// matcher_ndt.hpp::fused_tail for why it was slower until the pose moved to LDS).  A template parameter, not a run-time branch.
 template <bool FUSED>
 __global__ void __launch_bounds__(kNdtLanesBlock)
 ndt_lanes_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const int n,
@@ -516,6 +516,11 @@ ndt_lanes_kernel(const float* __restrict__ sx, const float* __restrict__ sy, con
     const int it = (FUSED && !first) ? st->iter : 0;
     if (done) return;
     __shared__ double wsum[kNdtLanesBlock / 64][32];
+    __shared__ double s_pose[16];
+    if (FUSED && threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s_pose[q] = P[q];
+    }
     const int i = (blockIdx.x * kNdtLanesBlock + threadIdx.x) >> 3, k = threadIdx.x & 7;
     double Hc[21], Bc[6], res = 0.0, cnt = 0.0;
 #pragma unroll
@@ -605,7 +610,10 @@ ndt_lanes_kernel(const float* __restrict__ sx, const float* __restrict__ sy, con
         __shared__ unsigned s_ticket;
         __shared__ LuTailSmem sm;
         if (!publish_row_and_arrive(v, threadIdx.x < 29, partials, ticket, shards, s_ticket)) return;
-        lu_tail<kNdtLanesBlock, true>(st, sm, partials, (int)gridDim.x, tail, P, it);
+        double Tl[16];  // (the pose parked in LDS at the start: sixteen doubles kept in registers across the per-point part cost the kernel its fourth wave per SIMD)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Tl[q] = s_pose[q];
+        lu_tail<kNdtLanesBlock, true>(st, sm, partials, (int)gridDim.x, tail, Tl, it);
     }
 }
 

@@ -70,9 +70,11 @@ struct NdtMatcher final : fls_matcher {
     SourceFilter src_filter;
     bool host_timing = false;  // FLS_HOST_TIMING=1: print the host-side split of every map update
     bool lanes_kernel = true;  // FLS_NDT_LANES=0: one lane per point (ndt_kernel) instead of one lane per neighbour voxel
-    bool fused_tail = false;   // FLS_FUSED_TAIL=1: the Gauss-Newton tail in the correspondence kernel's last workgroup instead of its own launch (gn_solve_lu_kernel).
-                               // Measured on configs[2] (457 workgroups of 512 threads): 83.9 us per Match fused vs 76-80 us with the separate 6.6 us launch -- the
-                               // write-through rows + fan-in + in-kernel tail cost more than the boundary they remove; IcpOptimized (205 small workgroups) gains 6 %.
+    bool fused_tail = true;    // the Gauss-Newton tail in the correspondence kernel's last workgroup instead of its own launch (gn_solve_lu_kernel); FLS_FUSED_TAIL=0: separate launch.
+                               // Rounds 3-5 measured the fused form SLOWER on configs[2] (83.9 vs 76-80 us per Match) and kept it off: ndt_lanes_kernel<true> held the pose
+                               // (sixteen doubles) in registers across the per-point part for the tail -- 144 VGPRs = 3 waves per SIMD = ONE 512-thread workgroup per CU, so
+                               // its 457 workgroups ran in two rounds.  Round 6 parks the pose in LDS: 118 VGPRs like the plain kernel, one round, and the launch the tail
+                               // no longer needs is a gain: 73.5-74.1 vs 78.3-79.6 us per Match, same pose to the last bit (tools/gpu_ab_ndt.py, profiles/r06_ai_*).
     DevBuf<unsigned> d_ticket;
     DevBuf<int> d_hit_vid;
     DevBuf<unsigned char> d_eff7;
