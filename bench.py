@@ -318,7 +318,9 @@ def bench_other_configs(reg, synth, util, O, budget_s=6.0):
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "detail": tdetail,
                          "algorithmic_bytes_per_iteration": bytes_iter, "correspondence_launch_us": 1e6 * avg_launch_s,
                          "note": "8d formula; kd-tree kinds: counters of the survey's 27-cell grid (cell = sqrt(gate)) at the final pose, the bracket covers one "
-                                 "iteration's correspondence launch(es)"},
+                                 "iteration's correspondence launch(es)"
+                                 + (" -- IncrementalNDT: since round 6 that launch also holds the fan-in and the Gauss-Newton tail (one launch per iteration; it was a "
+                                    "12.5 us correspondence launch + a 7.7 us solve launch), so `frac` fell from 0.10 to ~0.07 while the iteration got shorter" if mode == "IncrementalNDT" else "")},
             "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "scans/s", "cores": min(os.cpu_count() or 1, 64), "threads": min(os.cpu_count() or 1, 64), "host_cores": os.cpu_count() or 1, "kind": "port",
                              "sample": f"{reps} oracle Match calls (median), {int(o.stats.iterations)} iterations each"},
         }
