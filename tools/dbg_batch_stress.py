@@ -1,5 +1,5 @@
 """MatchBatch (lanes = 3, then 1, then 4) of four jobs on a fresh handle, N times; every pose against a fresh handle's pose (bitwise).
-usage: python tools/dbg_batch_stress.py N [icp|ndt] [scale]   (ndt at scale 1.0: 115,200-point scans -- the exact sort's pre-enqueued levels and the fused
+usage: python tools/dbg_batch_stress.py N [icp|ndt|ivox] [scale]   (ndt at scale 1.0: 115,200-point scans -- the exact sort's pre-enqueued levels and the fused
 Gauss-Newton tail of several lanes at once)"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +7,8 @@ import numpy as np
 from funny_lidar_slam_amd import registration as reg, synth
 from tests import util
 N = int(sys.argv[1]); kind = sys.argv[2] if len(sys.argv) > 2 else "icp"
-mode, y, cid, scale, loc = {"icp": ("IcpOptimized", reg.YAML_NCLT_ICP, 0, 1.0, True), "ndt": ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, 0.05, False)}[kind]
+mode, y, cid, scale, loc = {"icp": ("IcpOptimized", reg.YAML_NCLT_ICP, 0, 1.0, True), "ndt": ("IncrementalNDT", reg.YAML_NCLT_NDT, 2, 0.05, False),
+                              "ivox": ("PointToPlane_IVOX", reg.YAML_NCLT_IVOX, 1, 0.2, False)}[kind]
 if len(sys.argv) > 3: scale = float(sys.argv[3])
 cfgs = [synth.make_config(cid, job=j, scale=scale) for j in range(4)]
 maps = [cfgs[0]["map"]]
