@@ -610,6 +610,9 @@ icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
                    GnState* __restrict__ st, const int first, const Pose16 T0, const CellGridDev cg, const float gate, const double max_corr /* squared */,
                    int* __restrict__ nn_id, unsigned char* __restrict__ eff, double* __restrict__ partials,
                    unsigned* __restrict__ ticket /* nullptr: the tail runs as its own launch */, const int shards, const LuTailArgs tail) {
+#ifdef FLS_TIMING
+    const long long t_begin = (long long)__builtin_readcyclecounter();
+#endif
     const int done = first ? 0 : st->done;
     const int it = first ? 0 : st->iter;
     if (done) return;  // uniform over the launch
@@ -618,6 +621,9 @@ icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
     r.key = ~0ull; r.slot = 0u; r.found = 0; r.q = -1; r.kth = INFINITY;
     r.bx = r.by = r.bz = r.px = r.py = r.pz = 0.f;
     grid_knn_body<1, true, false>((int)blockIdx.x, sx, sy, sz, n, st, first, T0, cg, gate, nullptr, nullptr, nullptr, nullptr, &r);
+#ifdef FLS_TIMING
+    const long long t_knn = (long long)__builtin_readcyclecounter();  // (the search of this wave is done)
+#endif
     double T[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) T[k] = first ? T0.m[k] : st->T[k];
@@ -667,13 +673,23 @@ icp_knn_fit_kernel(const float* __restrict__ sx, const float* __restrict__ sy, c
     const double sr = wave_sum_dpp(res), sc = wave_sum_dpp(contrib ? 1.0 : 0.0);
     if (lane == 63) { row[27] = sr; row[28] = sc; }
 #endif
+#ifdef FLS_TIMING
+    const long long t_red = (long long)__builtin_readcyclecounter();  // (fit + matrix-core reduction + wave sums of this wave)
+#endif
     if (!ticket) { store_ids(); block_row_from_wave_sums(wsum, partials); return; }
     // fused Gauss-Newton tail (round 3): the row goes out write-through, the last workgroup to arrive solves and publishes
     __syncthreads();
+#ifdef FLS_TIMING
+    const long long t_sync = (long long)__builtin_readcyclecounter();  // (the workgroup's slowest wave has arrived)
+#endif
     const double v = threadIdx.x < 29 ? ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x] : 0.0;
     __shared__ unsigned s_ticket;
     __shared__ LuTailSmem sm;
     if (!publish_row_and_arrive(v, threadIdx.x < 29, partials, ticket, shards, s_ticket)) { store_ids(); return; }
+#ifdef FLS_TIMING
+    if (threadIdx.x == 0) { st->dbg[0] = t_begin; st->dbg[12] = t_knn; st->dbg[13] = t_red; st->dbg[14] = t_sync; }
+#endif
+    FLS_STAMP(1);
     lu_tail<256, true>(st, sm, partials, (int)gridDim.x, tail, T, it);
     store_ids();
 }

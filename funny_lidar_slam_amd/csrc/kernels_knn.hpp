@@ -431,7 +431,8 @@ __device__ __forceinline__ void lu_tail(GnState* __restrict__ st, LuTailSmem& sm
     const double rot_thr = a.rot_thr, pos_thr = a.pos_thr;
     Mailbox* const mb = a.mb;
     const unsigned match_id = a.match_id;
-    reduce_partials<NT, SC1>(partials, nrows, tot, red);
+    reduce_partials<NT, SC1, (NT <= 512 ? 32 : 16)>(partials, nrows, tot, red);  // (one trip for the fused kernels' 205 / 457 rows)
+    FLS_STAMP(3);
     if (threadIdx.x >= 64) return;  // wave 0 only
     const int lane = threadIdx.x;
     if (lane < 36) {
@@ -455,6 +456,7 @@ __device__ __forceinline__ void lu_tail(GnState* __restrict__ st, LuTailSmem& sm
         fast = __shfl(fast, 0, 64);
         if (!fast) det = lu6_solve_wave(Hs, inv, gs, xs, tr);
     }
+    FLS_STAMP(4);
     if (lane == 0) {
         st->n_valid = effective;
         st->sum_res = sres;
@@ -491,6 +493,7 @@ __device__ __forceinline__ void lu_tail(GnState* __restrict__ st, LuTailSmem& sm
         if (mb) {
             mailbox_publish(mb, Tl, dxo, sres, 0.0, it + 1, stop, conv, effective, 0, match_id);  // launch word: max_iterations << 24 | match id
         }
+        FLS_STAMP(5);
     }
 }
 

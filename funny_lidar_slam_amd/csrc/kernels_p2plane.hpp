@@ -202,16 +202,19 @@ __device__ __forceinline__ void reduce_rank1x3_mfma_and_store(const bool contrib
 constexpr int kSolveThreads = 1024;
 // SC1 = true: the rows were published write-through by OTHER workgroups of the SAME launch (the fused fit + solve
 // kernel): read them with relaxed agent-scope loads (sc1: served from memory, never from a stale L1 / L2 line).
-template <int NT, bool SC1 = false>
+// U = loads a thread keeps in flight per trip: one trip covers U * NT / 32 rows.  16 until round 6 -- IcpOptimized's 205 rows on a 256-thread
+// workgroup and IncrementalNDT's 457 rows on 512 threads took TWO dependent trips of cache-bypassing loads (2.0 us of the tail by the shader-clock
+// stamps, tools/gpu_icp_stamps.py); 32 makes it one.  The order of the additions is the same for every U.
+template <int NT, bool SC1 = false, int U = 16>
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, const int nrows, double* tot /*LDS 32*/,
                                                 double (*red)[33] /*LDS (NT/32) x 33*/) {
     constexpr int NG = NT / 32;
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
     double acc = 0.0;
-    for (int r = grp; r < nrows; r += 16 * NG) {
-        double v[16];
+    for (int r = grp; r < nrows; r += U * NG) {
+        double v[U];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int rr = r + u * NG;
             if (SC1) {
                 v[u] = rr < nrows ? __longlong_as_double((long long)__hip_atomic_load(
@@ -223,7 +226,7 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
             }
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc += v[u];
+        for (int u = 0; u < U; ++u) acc += v[u];
     }
     red[grp][col] = acc;
     __syncthreads();
@@ -307,10 +310,11 @@ __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem
                                           const double rot_thr, const double pos_thr, double (&Tl)[16], const double last_rot,
                                           const double last_pos, const int it, Mailbox* __restrict__ mb = nullptr,
                                           const unsigned match_id = 0u) {
-    if (nrows_a > 0) reduce_partials<NT, SC1>(partials_a, nrows_a, sm.tot_a, sm.red);
+    constexpr int RU = NT <= 256 ? 32 : 16;  // (LoamFull's 225 planar rows on a 256-thread workgroup in one trip)
+    if (nrows_a > 0) reduce_partials<NT, SC1, RU>(partials_a, nrows_a, sm.tot_a, sm.red);
     else { if (threadIdx.x < 32) sm.tot_a[threadIdx.x] = 0.0; __syncthreads(); }
     FLS_STAMP(2);
-    reduce_partials<NT, SC1>(partials_b, nrows_b, sm.tot_b, sm.red);
+    reduce_partials<NT, SC1, RU>(partials_b, nrows_b, sm.tot_b, sm.red);
     if (threadIdx.x >= 64) return;  // wave 0 only from here on
     FLS_STAMP(3);
     const int lane = threadIdx.x;
