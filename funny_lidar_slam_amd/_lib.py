@@ -17,7 +17,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 EXPORTED_SYMBOLS = [
     "fls_create", "fls_destroy", "fls_add_cloud_to_local_map", "fls_match", "fls_get_fitness_score",
     "fls_scan_upload", "fls_scan_upload_raw", "fls_match_resident", "fls_match_batch", "fls_map_export", "fls_map_import", "fls_map_image_bytes", "fls_map_image_export", "fls_map_image_import", "fls_get_iteration_log", "fls_get_correspondences", "fls_map_size",
-    "fls_set_profiling", "fls_get_kernel_time", "fls_get_traffic_counters", "fls_get_debug_stamps", "fls_debug_fullpiv_qr6", "fls_debug_voxel_grid", "fls_debug_voxel_grid_timed", "fls_debug_exact_sort", "fls_debug_exact_sort_marks", "fls_voxel_grid_cloud", "fls_loop_match", "fls_status_string", "fls_abi_version", "fls_abi_revision",
+    "fls_set_profiling", "fls_get_kernel_time", "fls_get_traffic_counters", "fls_get_debug_stamps", "fls_debug_fullpiv_qr6", "fls_debug_ldlt6", "fls_debug_voxel_grid", "fls_debug_voxel_grid_timed", "fls_debug_exact_sort", "fls_debug_exact_sort_marks", "fls_voxel_grid_cloud", "fls_loop_match", "fls_status_string", "fls_abi_version", "fls_abi_revision",
     "fls_device_count",
     "fls_replicas_create", "fls_replicas_refresh", "fls_replicas_match_batch", "fls_replicas_import_ms", "fls_replicas_destroy",
     # include/fls_features.h
@@ -197,6 +197,8 @@ def lib():
         L.fls_debug_exact_sort.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t, C.c_int]
         L.fls_debug_fullpiv_qr6.restype = C.c_int
         L.fls_debug_fullpiv_qr6.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
+        L.fls_debug_ldlt6.restype = C.c_int
+        L.fls_debug_ldlt6.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         L.fls_get_debug_stamps.restype = C.c_int
         L.fls_get_debug_stamps.argtypes = [hp, C.POINTER(C.c_int64)]
         L.fls_features_create.restype = C.c_int

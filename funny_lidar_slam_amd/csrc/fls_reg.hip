@@ -320,6 +320,24 @@ fls_status fls_debug_fullpiv_qr6(int device_id, const double* H, const double* g
     });
 }
 
+fls_status fls_debug_ldlt6(int device_id, const double* H, const double* g, int n, double* x, int32_t* ok) {
+    if (!H || !g || !x || !ok || n < 0) return FLS_ERR_INVALID;
+    if (n == 0) return FLS_OK;
+    return guarded([&]() -> fls_status {
+        FLS_HIP(hipSetDevice(device_id));
+        DevBuf<double> dH, dg, dx;
+        DevBuf<int> dok;
+        dH.reserve(size_t(n) * 36); dg.reserve(size_t(n) * 6); dx.reserve(size_t(n) * 6); dok.reserve(size_t(n));
+        FLS_HIP(hipMemcpy(dH.p, H, size_t(n) * 36 * sizeof(double), hipMemcpyHostToDevice));
+        FLS_HIP(hipMemcpy(dg.p, g, size_t(n) * 6 * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(debug_ldlt6_kernel, dim3(unsigned(n)), dim3(64), 0, nullptr, (const double*)dH.p, (const double*)dg.p, n, dx.p, dok.p);
+        FLS_HIP(hipGetLastError());
+        FLS_HIP(hipMemcpy(x, dx.p, size_t(n) * 6 * sizeof(double), hipMemcpyDeviceToHost));
+        FLS_HIP(hipMemcpy(ok, dok.p, size_t(n) * sizeof(int), hipMemcpyDeviceToHost));
+        return FLS_OK;
+    });
+}
+
 fls_status fls_debug_voxel_grid(int device_id, const float* pts, size_t n, int stride, float leaf, float* out, size_t cap, size_t* n_out) {
     if (!pts || !n_out || stride < 3 || !(leaf > 0.f) || (cap && !out)) return FLS_ERR_INVALID;
     *n_out = 0;

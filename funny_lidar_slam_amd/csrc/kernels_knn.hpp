@@ -451,9 +451,7 @@ __device__ __forceinline__ void lu_tail(GnState* __restrict__ st, LuTailSmem& sm
     if (!early_fail) {
         // SPD fast path (kernels_p2plane.hpp::ldlt_solve6_lane): positive pivots imply det(H) > 0, so the reference's exact
         // det == 0 test (icp_optimized.h:129, Q14) cannot fire; anything else goes through the restated LU inverse
-        int fast = 0;
-        if (lane == 0 && !((match_id >> 23) & 1u)) fast = ldlt_solve6_lane(Hs, gs, xs) ? 1 : 0;
-        fast = __shfl(fast, 0, 64);
+        const int fast = ldlt_fast_path(Hs, gs, xs, match_id);
         if (!fast) det = lu6_solve_wave(Hs, inv, gs, xs, tr);
     }
     FLS_STAMP(4);

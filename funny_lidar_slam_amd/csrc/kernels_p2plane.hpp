@@ -289,6 +289,22 @@ __device__ __forceinline__ bool publish_row_and_arrive(const double v, const boo
 __device__ __forceinline__ bool ldlt_solve6_lane(const double* __restrict__ H /* 6x6 column-major, LDS */, const double* __restrict__ g, double* __restrict__ x) {
     return hm::ldlt_solve6(H, g, x);  // host_math.hpp (__host__ __device__: tests/host/host_logic_test.cpp checks it on the CPU)
 }
+// The fast path as the tails call it (whole wave 0, uniform result; launch word bit 23 = FLS_TAIL_EXACT: no fast path).  Default since the end of
+// round 6: the factorisation with the matrix rows in lanes 0..5 (wave_solve.hpp::ldlt_solve6_wave); -DFLS_TAIL_LDLT_WAVE=0 builds the one-lane
+// form it replaced (A/B: tools/gpu_ab_libs.py).
+#ifndef FLS_TAIL_LDLT_WAVE
+#define FLS_TAIL_LDLT_WAVE 1
+#endif
+__device__ __forceinline__ int ldlt_fast_path(const double* __restrict__ H, const double* __restrict__ g, double* __restrict__ x, const unsigned launch_word) {
+    if ((launch_word >> 23) & 1u) return 0;
+#if FLS_TAIL_LDLT_WAVE
+    return ldlt_solve6_wave(H, g, x) ? 1 : 0;
+#else
+    int fast = 0;
+    if ((threadIdx.x & 63) == 0) fast = ldlt_solve6_lane(H, g, x) ? 1 : 0;
+    return __shfl(fast, 0, 64);
+#endif
+}
 
 // shared memory of the LOAM-family Gauss-Newton tail
 struct LoamTailSmem {
@@ -328,9 +344,7 @@ __device__ __forceinline__ void loam_tail(GnState* __restrict__ st, LoamTailSmem
     }
     if (lane < 6) { const double v = sm.tot_a[21 + lane] + sm.tot_b[21 + lane]; sm.gs[lane] = v; st->g[lane] = v; }
     __builtin_amdgcn_wave_barrier();
-    int fast = 0;
-    if (lane == 0 && !((match_id >> 23) & 1u)) fast = ldlt_solve6_lane(sm.Hs, sm.gs, sm.xs) ? 1 : 0;
-    fast = __shfl(fast, 0, 64);
+    const int fast = ldlt_fast_path(sm.Hs, sm.gs, sm.xs, match_id);
     if (!fast)
 #ifdef FLS_TIMING
     fullpiv_qr_solve6_wave(sm.Hs, sm.gs, sm.xs, sm.hc, sm.tr, sm.ctr, st->dbg);
@@ -390,6 +404,21 @@ debug_fullpiv_qr6_kernel(const double* __restrict__ H, const double* __restrict_
     __builtin_amdgcn_wave_barrier();
     fullpiv_qr_solve6_wave(Hs, gs, xs, hc, tr, ctr);
     if (threadIdx.x < 6) x[(size_t)s * 6 + threadIdx.x] = xs[threadIdx.x];
+}
+
+// test hook (fls_debug_ldlt6): one wave per 6x6 system, the fast path exactly as the tails call it; ok[s] = 1 where the fast path accepted the system
+__global__ void __launch_bounds__(64)
+debug_ldlt6_kernel(const double* __restrict__ H, const double* __restrict__ g, const int n, double* __restrict__ x, int* __restrict__ ok) {
+    const int s = blockIdx.x;
+    if (s >= n) return;
+    __shared__ double Hs[36], gs[6], xs[6];
+    if (threadIdx.x < 36) Hs[threadIdx.x] = H[(size_t)s * 36 + threadIdx.x];
+    if (threadIdx.x < 6) { gs[threadIdx.x] = g[(size_t)s * 6 + threadIdx.x]; xs[threadIdx.x] = 0.0; }
+    __builtin_amdgcn_wave_barrier();
+    const int fast = ldlt_fast_path(Hs, gs, xs, 0u);
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x < 6) x[(size_t)s * 6 + threadIdx.x] = fast ? xs[threadIdx.x] : 0.0;
+    if (threadIdx.x == 0) ok[s] = fast;
 }
 
 __global__ void __launch_bounds__(kSolveThreads)

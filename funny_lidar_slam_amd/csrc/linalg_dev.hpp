@@ -255,12 +255,27 @@ __device__ __forceinline__ void jacobi_svd3_v(const double (&A)[3][3], double (&
 __device__ inline double norm3d(const double* v) { return sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
 
 // SO3Exp (math_function.h:74-89): identity if |v| <= eps, else Rodrigues.  R 3x3 column-major.
+#ifndef FLS_TAIL_SINCOS
+#define FLS_TAIL_SINCOS 1  // 0: separate cos() and sin() calls (A/B builds)
+#endif
 __device__ inline void so3_exp_dev(const double* v, double* R) {
     for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
     const double sq = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
     const double theta = sqrt(sq);
     if (theta > FLS_DBL_EPS) {
         const double a[3] = {v[0] / theta, v[1] / theta, v[2] / theta};
+#if FLS_TAIL_SINCOS
+        double s, c;
+        sincos(theta, &s, &c);  // one argument reduction for both (the tail is one lone wave: every instruction costs ~8 cycles)
+        // R(i, j) = (c [i == j] + ((1 - c) a_i) a_j) + s hat(a)(i, j) with the products by 1.0 and 0.0 and the additions of 0.0 left out: the same
+        // bits for finite theta (x * 1.0 == x, x + 0.0 == x; only the sign of an exact zero can differ), 24 instructions instead of ~95
+        const double w[3] = {(1.0 - c) * a[0], (1.0 - c) * a[1], (1.0 - c) * a[2]};
+        const double sa[3] = {s * a[0], s * a[1], s * a[2]};
+        R[0] = c + w[0] * a[0];  R[4] = c + w[1] * a[1];  R[8] = c + w[2] * a[2];
+        R[1] = w[1] * a[0] + sa[2];  R[2] = w[2] * a[0] - sa[1];   // column 0: hat = (0, a2, -a1)
+        R[3] = w[0] * a[1] - sa[2];  R[5] = w[2] * a[1] + sa[0];   // column 1: hat = (-a2, 0, a0)
+        R[6] = w[0] * a[2] + sa[1];  R[7] = w[1] * a[2] - sa[0];   // column 2: hat = (a1, -a0, 0)
+#else
         const double c = cos(theta), s = sin(theta);
         double hat[9] = {0.0, a[2], -a[1], -a[2], 0.0, a[0], a[1], -a[0], 0.0};  // column-major SO3Hat(a)
         for (int j = 0; j < 3; ++j)
@@ -268,6 +283,7 @@ __device__ inline void so3_exp_dev(const double* v, double* R) {
                 const double id = (i == j) ? 1.0 : 0.0;
                 R[i + j * 3] = (c * id + ((1.0 - c) * a[i]) * a[j]) + s * hat[i + j * 3];
             }
+#endif
     }
 }
 // C = A*B, 3x3 column-major

@@ -300,4 +300,79 @@ __device__ __forceinline__ double lu6_solve_wave(double* M, double* inv, const d
     return det;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ldlt_solve6_wave: the SPD fast path of the Gauss-Newton tails (what hm::ldlt_solve6 does on one lane -- 425 instructions that a lone
+// wave issues at ~8 cycles each, 1.45 us of every iteration by the shader-clock stamps) with the ROWS of the working matrix in lanes
+// 0..5 (round 6).  Right-looking: at step j the pivot row leaves lane j through v_readlane (SGPRs), every lane scales its own column
+// entry and updates its own row -- the 15 trailing-row updates of a step are two instructions instead of thirty -- and the reciprocal of
+// the pivot is v_rcp_f64 + two Newton steps (the front half of the IEEE division sequence, <= 1 ulp) instead of a 13-instruction division.
+// The pivot rows are uniform values, so U = D^-1 (pivot rows) is known to every lane and the two triangular solves run uniformly without
+// further exchange.  Same matrix, same pivots up to rounding (the factorisation is the outer-product form of the same LDL^T); same
+// acceptance rule (every pivot > 0, d_min > 1e-9 d_max, finite solution) -- false sends the caller to the restated Eigen solver.
+// H: LDS, 6x6 column-major, symmetric, NOT modified.  xs: LDS, written by lane 0.  All 64 lanes of one wave must call.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_newton_f64(const double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ bool ldlt_solve6_wave(const double* __restrict__ H, const double* __restrict__ g, double* __restrict__ xs) {
+    const int lane = threadIdx.x & 63;
+    const int row = lane < 6 ? lane : 5;  // (lanes 6.. repeat row 5: their values are never read)
+    double a[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[k] = H[row + 6 * k];
+    double U[6][6], inv[6];
+    double dmax = 0.0, dmin = 1.0e300;
+    bool positive = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double p[6];
+#pragma unroll
+        for (int k = j; k < 6; ++k) p[k] = readlane_f64(a[k], j);
+        const double d = p[j];
+        positive = positive && (d > 0.0);  // false for NaN as well
+        dmax = d > dmax ? d : dmax;
+        dmin = d < dmin ? d : dmin;
+        const double iv = rcp_newton_f64(d);
+        inv[j] = iv;
+        const double l = lane > j ? a[j] * iv : 0.0;  // L(row, j); rows <= j keep what they hold (row j IS the pivot row)
+#pragma unroll
+        for (int k = j + 1; k < 6; ++k) {
+            U[j][k] = p[k] * iv;  // = L(k, j)
+            a[k] -= l * p[k];
+        }
+    }
+    if (!positive || !(dmin > 1.0e-9 * dmax)) return false;
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = g[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= U[k][i] * y[k];
+        y[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = y[i] * inv[i];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= U[i][k] * y[k];
+        y[i] = s;
+    }
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) finite = finite && (y[i] - y[i] == 0.0);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xs[i] = y[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    return finite;  // a non-finite right-hand side goes through the exact solver as well
+}
+
 }  // namespace fls

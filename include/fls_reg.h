@@ -37,9 +37,9 @@ extern "C" {
 #define FLS_ABI_VERSION 1
 /* Additive revision of ABI version 1: entry points are only ever ADDED under one FLS_ABI_VERSION (existing signatures, struct layouts and
  * status codes do not change), and this number counts the additions -- 1: fls_match_batch, map export / import; 2: fls_voxel_grid_cloud,
- * fls_features_*; 3: fls_replicas_*, fls_loop_match; 4: fls_debug_exact_sort; 5: fls_scan_upload_raw; 6: fls_map_image_*.  A caller built against revision r works with any library
+ * fls_features_*; 3: fls_replicas_*, fls_loop_match; 4: fls_debug_exact_sort; 5: fls_scan_upload_raw; 6: fls_map_image_*; 7: fls_debug_ldlt6.  A caller built against revision r works with any library
  * whose fls_abi_revision() >= r. */
-#define FLS_ABI_REVISION 6
+#define FLS_ABI_REVISION 7
 
 /* Which reference class the handle replaces (mode strings: include/common/constant_variable.h:21-25). */
 typedef enum fls_kind {
@@ -281,6 +281,11 @@ fls_status fls_get_debug_stamps(fls_handle h, int64_t out[16]);
  * caller-supplied systems: H (n x 36, column-major), g (n x 6) -> x (n x 6).  tests/test_gpu_solver.py checks it bit for bit
  * against the oracle's restatement, rank-deficient systems included.                                                      */
 fls_status fls_debug_fullpiv_qr6(int device_id, const double* H, const double* g, int n, double* x);
+
+/* test hook: the SPD fast path in front of that solver (unpivoted LDL^T with the matrix rows in lanes 0..5 of one wave; csrc/wave_solve.hpp::
+ * ldlt_solve6_wave) on n caller-supplied systems.  ok[s] = 1 where the fast path accepted system s (every pivot > 0, d_min > 1e-9 d_max, finite
+ * solution) and x[s] is its solution; 0 where a Match would have gone on to fls_debug_fullpiv_qr6's solver (x[s] = 0).  tests/test_gpu_solver.py. */
+fls_status fls_debug_ldlt6(int device_id, const double* H, const double* g, int n, double* x, int32_t* ok);
 
 /* test hook (= fls_voxel_grid_cloud(..., FLS_VOXELGRID_DEVICE, ...)): the device VoxelGrid (pcl::VoxelGrid<PointXYZI>::filter semantics; the default source filter
  * of the ICP / NDT kinds, FLS_DEVICE_VOXELGRID=1) on a caller-supplied cloud: pts (n x stride floats, intensity as in fls_match) -> out (cap x 4
