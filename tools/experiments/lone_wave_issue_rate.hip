@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+__device__ __forceinline__ double fma_t(double x, double a, double b) { return __builtin_fma(x, a, b); }
+__device__ __forceinline__ float fma_t(float x, float a, float b) { return __builtin_fmaf(x, a, b); }  // (the first run called __builtin_fma on floats: an f64 FMA between two conversions, 3 instructions -- its f32 lines are that)
 template <typename T, int CH>
 __global__ void chain_kernel(T* out, long long* ticks, const int n, const T a, const T b) {
     T x[CH];
@@ -15,7 +17,7 @@ __global__ void chain_kernel(T* out, long long* ticks, const int n, const T a, c
 #pragma unroll 16
     for (int i = 0; i < n; ++i) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c) x[c] = __builtin_fma(x[c], a, b);
+        for (int c = 0; c < CH; ++c) x[c] = fma_t(x[c], a, b);
     }
     const long long t1 = (long long)__builtin_readcyclecounter();
     T s = 0;

@@ -13,6 +13,9 @@ what = sys.argv[1] if len(sys.argv) > 1 else "mapping"
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 count = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 prefix = {"mapping": "fuzz", "long": "fuzzL", "loc": "lfuzz"}[what]
+# scenarios whose Gauss-Newton systems amplify last-bit differences beyond this tool's 1e-8 (still inside the 1e-4 contract); tools/cond_scenario.py prints the numbers
+SENSITIVE = {"fuzz355": "frame 0 starts with 13 valid points, cond(H) 3e8 and a step of 4.7 -- the summation order of H alone moves such a solution by up to 1e-7; "
+                        "4.5e-12 with the one-lane LDL^T of rounds 2-6, 7.3e-8 with the rows-in-lanes LDL^T: profiles/r06_av_fuzz355_conditioning.txt"}
 bad, ties, worst = [], [], 0.0
 t_all = time.perf_counter()
 for seed in range(first, first + count):
@@ -40,6 +43,8 @@ for seed in range(first, first + count):
                 inside = run.returncode in (0, 1) and len(frames) == len(sc["frames"]) and all(fr["ref_ok"] == fr["hip_ok"] and fr["dt"] <= 1e-4 and fr["dr"] <= 1e-4 for fr in frames)
                 if inside and name in ("fuzz319", "lfuzz58"):
                     ties.append(name); tag = "TIE (known: one exact distance tie)"
+                elif inside and name in SENSITIVE:
+                    ties.append(name); tag = "ILL-CONDITIONED (known: " + SENSITIVE[name] + ")"
                 else:
                     bad.append(name); tag = "FAIL"
             print(name, sc["mode"], tag, "frames", len(frames), "ok=", [fr["ref_ok"] for fr in frames], f"worst |dT| {wd:.1e}",
@@ -49,6 +54,6 @@ for seed in range(first, first + count):
         except Exception as e:
             bad.append(name)
             print(name, "FAIL", repr(e)[:300], run.stdout[-300:], run.stderr[-300:], flush=True)
-print(f"{what}: {count - len(bad) - len(ties)} of {count} scenarios: HIP adapter == compiled reference through RegistrationInterface (worst |dT| {worst:.1e}); known ties: {ties}; failed: {bad}; "
+print(f"{what}: {count - len(bad) - len(ties)} of {count} scenarios: HIP adapter == compiled reference through RegistrationInterface (worst |dT| {worst:.1e}); known ties / ill-conditioned: {ties}; failed: {bad}; "
       f"{time.perf_counter() - t_all:.0f} s", flush=True)
 sys.exit(1 if bad else 0)
