@@ -205,28 +205,68 @@ constexpr int kSolveThreads = 1024;
 // U = loads a thread keeps in flight per trip: one trip covers U * NT / 32 rows.  16 until round 6 -- IcpOptimized's 205 rows on a 256-thread
 // workgroup and IncrementalNDT's 457 rows on 512 threads took TWO dependent trips of cache-bypassing loads (2.0 us of the tail by the shader-clock
 // stamps, tools/gpu_icp_stamps.py); 32 makes it one.  The order of the additions is the same for every U.
+// Row tests (end of round 6): a guarded load is ten instructions (row index, compare, zero, exec mask, branch, 64-bit address, load, exec restore), and the
+// waves of a 256-thread tail workgroup are alone on their SIMDs, where an instruction costs 6-8 cycles.  The first (nrows - r0) / NG
+// rounds of a trip are in range for EVERY row group -- a uniform number -- so those loads need no per-lane test, and a 32-bit byte offset from the uniform base
+// needs no 64-bit address per load: two instructions per load instead of eleven.  Written as three straight-line variants chosen by ONE scalar branch (all U
+// rounds unguarded / all but the last four / none: a per-load choice was folded back into a guarded load by the compiler).  Same loads, same additions, same
+// order: bit-identical sums (tools/gpu_ab_libs.py: equal pose bits on every kind).  Measured (profiles/r06_aw_reduce_uniform_rounds_ab.log): IcpOptimized
+// 229.8 -> 225.9 us per Match (rows read + reduced 3,932 -> 3,480 ticks), LoamFull 236.8 -> 235.6; the 512-thread kernels (two waves per SIMD in the tail
+// workgroup: iVox, IncrementalNDT) measured 0.4-0.7 us per Match SLOWER with it and keep the guarded form, as do the 1,024-thread solve launches.
+#ifndef FLS_REDUCE_UNIFORM_ROUNDS
+#define FLS_REDUCE_UNIFORM_ROUNDS 1  // 0: every load guarded per lane everywhere (A/B builds)
+#endif
+template <int NT, bool SC1, int U, int F /* rounds without a row test */>
+__device__ __forceinline__ void reduce_partials_trip(const double* __restrict__ partials, const int r, const int nrows, const int col, double& acc) {
+    constexpr int NG = NT / 32;
+    // a 32-bit BYTE offset from the uniform base (rows x 256 bytes: far below 2^32): the load takes it as it is (scalar base + 32-bit lane offset)
+    auto load_row = [&](const int rr) -> double {
+        const unsigned boff = ((unsigned)rr * (unsigned)kPartialStride + (unsigned)col) * 8u;
+        const char* const a = reinterpret_cast<const char*>(partials) + boff;
+        if (SC1) return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        return *reinterpret_cast<const double*>(a);
+    };
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int rr = r + u * NG;
+        if (u < F) v[u] = load_row(rr);
+        else v[u] = rr < nrows ? load_row(rr) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += v[u];
+}
 template <int NT, bool SC1 = false, int U = 16>
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, const int nrows, double* tot /*LDS 32*/,
                                                 double (*red)[33] /*LDS (NT/32) x 33*/) {
     constexpr int NG = NT / 32;
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
     double acc = 0.0;
-    for (int r = grp; r < nrows; r += U * NG) {
-        double v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int rr = r + u * NG;
-            if (SC1) {
-                v[u] = rr < nrows ? __longlong_as_double((long long)__hip_atomic_load(
-                                        (const unsigned long long*)partials + (size_t)rr * kPartialStride + col, __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_AGENT))
-                                  : 0.0;
-            } else {
-                v[u] = rr < nrows ? partials[(size_t)rr * kPartialStride + col] : 0.0;
-            }
+    if constexpr (FLS_REDUCE_UNIFORM_ROUNDS && NT <= 256) {
+        for (int r = grp; r < nrows; r += U * NG) {
+            const int rounds = (nrows - (r - grp)) / NG;  // uniform: rounds of this trip whose row is in range for every row group
+            if (rounds >= U) reduce_partials_trip<NT, SC1, U, U>(partials, r, nrows, col, acc);
+            else if (rounds >= U - 4) reduce_partials_trip<NT, SC1, U, U - 4>(partials, r, nrows, col, acc);
+            else reduce_partials_trip<NT, SC1, U, 0>(partials, r, nrows, col, acc);
         }
+    } else {
+        for (int r = grp; r < nrows; r += U * NG) {
+            double v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc += v[u];
+            for (int u = 0; u < U; ++u) {
+                const int rr = r + u * NG;
+                if (SC1) {
+                    v[u] = rr < nrows ? __longlong_as_double((long long)__hip_atomic_load(
+                                            (const unsigned long long*)partials + (size_t)rr * kPartialStride + col, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT))
+                                      : 0.0;
+                } else {
+                    v[u] = rr < nrows ? partials[(size_t)rr * kPartialStride + col] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += v[u];
+        }
     }
     red[grp][col] = acc;
     __syncthreads();
